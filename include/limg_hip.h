@@ -1,0 +1,110 @@
+/* limg_hip.h -- C ABI of liblimg_hip.so: the MI355X (gfx950) implementation of limg's encode hot path.
+ *
+ * Drop-in boundary for the reference's `limg_encode3d_test` / `limg_encode3d_test_perf` / `limg_compare`
+ * (reference: src/limg.h:27-48; the reference has no FFI layer, its API is plain C++ functions).  Every entry point
+ * below names the reference interface it replaces.  Plain pointers and sizes only; no C++ or torch types.
+ * A header-only C++ shim with the *exact* reference signatures is in include/limg_hip_shim.hpp.
+ *
+ * Data layout (identical to the reference, src/limg.h:29-33 and SURVEY.md 8(b)):
+ *   pIn            row-major uint32 RGBA8, byte 0 = R, sizeX*sizeY elements, row stride sizeX
+ *   8 uint32 planes (pDecoded, pShiftABCX, pColAMin, pColAMax, pColBMin, pColBMax, pColCMin, pColCMax)
+ *   3 uint8  planes (pFactorsA, pFactorsB, pFactorsC), each sizeX*sizeY elements, row stride sizeX
+ * Ownership: the caller allocates and frees every image/plane buffer; the library never retains caller pointers.
+ * The context owns device staging buffers, per-block scratch and the dither noise table.
+ */
+#ifndef LIMG_HIP_H
+#define LIMG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* same numeric values as `enum limg_result` (src/limg.h:9-18) */
+typedef enum limg_hip_result
+{
+  limg_hip_success = 0,
+  limg_hip_error_Generic = 100, /* also: any HIP runtime failure */
+  limg_hip_error_InvalidParameter,
+  limg_hip_error_ArgumentNull,
+  limg_hip_error_OutOfBounds,
+  limg_hip_error_MemoryAllocationFailure
+} limg_hip_result;
+
+/* same member order and meaning as `struct limg_encode3d_info` (src/limg.h:29-33) */
+typedef struct limg_hip_encode3d_info
+{
+  uint32_t *pDecoded, *pShiftABCX, *pColAMin, *pColAMax, *pColBMin, *pColBMax, *pColCMin, *pColCMax;
+  uint8_t *pFactorsA, *pFactorsB, *pFactorsC;
+} limg_hip_encode3d_info;
+
+/* `limg_encode_3d_output<4>` (src/limg_internal.h:343-353): the per-block decomposition record, 64 bytes.
+ * For 3-channel input lane 3 of every array is 0 (the reference's 48-byte <3> layout is this minus lane 3). */
+typedef struct limg_hip_block_record
+{
+  float avg[4];
+  int16_t dirA_min[4], dirA_max[4], dirB_offset[4], dirB_mag[4], dirC_offset[4], dirC_mag[4];
+} limg_hip_block_record;
+
+/* Optional per-block ("compact") outputs of the device entry point; any pointer may be NULL. Device pointers. */
+typedef struct limg_hip_compact_out
+{
+  limg_hip_block_record *pRecords; /* blocksX*blocksY, raster order */
+  uint32_t *pShifts;               /* blocksX*blocksY: shiftA | shiftB << 8 | shiftC << 16 | ditherCalls << 24 */
+} limg_hip_compact_out;
+
+/* Knobs that have no parameter in the reference signature.  Zero-initialise, then set what you need. */
+typedef struct limg_hip_options
+{
+  int32_t forced_shift[3]; /* all three in 0..8: bypass the shift search (a10-a12) with this triple; otherwise {-1,-1,-1} */
+  int32_t reserved[5];
+} limg_hip_options;
+
+typedef struct limg_hip_context limg_hip_context;
+
+/* Create / destroy a context bound to HIP device `device` (-1 = current device).  No reference analogue
+ * (the reference keeps no state besides CPUID flags, src/limg_simd.cpp:57-60). */
+limg_hip_result limg_hip_init(int device, limg_hip_context **ppCtx);
+void limg_hip_shutdown(limg_hip_context **ppCtx);
+void limg_hip_default_options(limg_hip_options *pOptions);
+limg_hip_result limg_hip_set_options(limg_hip_context *pCtx, const limg_hip_options *pOptions);
+
+/* Replaces `limg_encode3d_test` (src/limg.h:35, src/limg.cpp:2175-2265).  HOST pointers; blocking.
+ * poolThreads: 0 == `pThreadPool = nullptr` (one dither chain over the image); T > 0 == a pool of T threads, i.e. T*4
+ * row strips each restarting the dither chain (src/limg.cpp:2114-2134).  bool parameters are ints (0 / non-0). */
+limg_hip_result limg_hip_encode3d(limg_hip_context *pCtx, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, limg_hip_encode3d_info *pInfo,
+                                  uint32_t errorFactor, int poolThreads, int fastBitCrushing);
+
+/* Replaces `limg_encode3d_test_perf` (src/limg.h:37, src/limg.cpp:2267-2327): same work, nothing stored. HOST pointer. */
+limg_hip_result limg_hip_encode3d_perf(limg_hip_context *pCtx, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, uint32_t errorFactor,
+                                       int poolThreads, int fastBitCrushing);
+
+/* Device-resident variant of `limg_encode3d_test`: every pointer (pIn, the 11 planes inside *pInfo, pCompact members)
+ * is a DEVICE pointer; pInfo / pCompact themselves are host structs.  Asynchronous on `stream` (a hipStream_t passed
+ * as void*; NULL = default stream).  pInfo == NULL gives the `_perf` behaviour (fit + search only). */
+limg_hip_result limg_hip_encode3d_device(limg_hip_context *pCtx, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha,
+                                         const limg_hip_encode3d_info *pInfo, const limg_hip_compact_out *pCompact, uint32_t errorFactor, int poolThreads,
+                                         int fastBitCrushing, void *stream);
+
+/* Replaces `limg_compare` (src/limg.h:48, src/limg.cpp:2455-2491): perceptual PSNR; HOST pointers. */
+double limg_hip_compare(limg_hip_context *pCtx, const uint32_t *pImageA, const uint32_t *pImageB, size_t sizeX, size_t sizeY, int hasAlpha,
+                        double *pMeanSquaredError, double *pMaxPossibleSquaredError);
+/* same on DEVICE pointers (blocking on `stream`) */
+double limg_hip_compare_device(limg_hip_context *pCtx, const uint32_t *pImageA, const uint32_t *pImageB, size_t sizeX, size_t sizeY, int hasAlpha,
+                               double *pMeanSquaredError, double *pMaxPossibleSquaredError, void *stream);
+
+/* Synthetic inputs of SURVEY.md 8(d), generated directly in HBM (DEVICE pointer, async on stream).
+ * (y0, fullWidth) let a rank generate only its row strip of a larger image. */
+limg_hip_result limg_hip_synth_random_gradient_device(uint32_t *pOut, size_t width, size_t height, uint64_t seed, int opaque, size_t y0, void *stream);
+limg_hip_result limg_hip_synth_photo_noise_device(uint32_t *pOut, size_t width, size_t height, uint64_t seed, size_t y0, void *stream);
+
+/* Introspection for the bench: names and launch count of the kernels one encode enqueues, bytes of context-owned HBM. */
+size_t limg_hip_context_device_bytes(const limg_hip_context *pCtx);
+const char *limg_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIMG_HIP_H */

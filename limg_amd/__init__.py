@@ -1,0 +1,185 @@
+"""limg_amd -- MI355X (gfx950) implementation of limg's encode hot path.
+
+This package is a thin ctypes view of the C ABI in include/limg_hip.h (liblimg_hip.so, built in-tree by limg_amd/build.py
+from the hand-written HIP sources in limg_amd/csrc).  It is plumbing for the tests and the bench: the product is the
+shared library.  There is NO CPU fallback: if the library is missing, or no HIP device is present, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liblimg_hip.so")
+
+P32 = ("pDecoded", "pShiftABCX", "pColAMin", "pColAMax", "pColBMin", "pColBMax", "pColCMin", "pColCMax")
+P8 = ("pFactorsA", "pFactorsB", "pFactorsC")
+PLANES = P32 + P8
+
+# every symbol include/limg_hip.h declares (checked by tests/test_host.py without a GPU)
+ABI_SYMBOLS = (
+    "limg_hip_init", "limg_hip_shutdown", "limg_hip_default_options", "limg_hip_set_options", "limg_hip_encode3d", "limg_hip_encode3d_perf",
+    "limg_hip_encode3d_device", "limg_hip_compare", "limg_hip_compare_device", "limg_hip_synth_random_gradient_device",
+    "limg_hip_synth_photo_noise_device", "limg_hip_context_device_bytes", "limg_hip_version",
+)
+
+RECORD_DTYPE = np.dtype([("avg", "<f4", 4), ("dirA_min", "<i2", 4), ("dirA_max", "<i2", 4), ("dirB_offset", "<i2", 4),
+                         ("dirB_mag", "<i2", 4), ("dirC_offset", "<i2", 4), ("dirC_mag", "<i2", 4)])
+
+
+class LimgHipError(RuntimeError):
+    pass
+
+
+class Info(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in PLANES]
+
+
+class CompactOut(C.Structure):
+    _fields_ = [("pRecords", C.c_void_p), ("pShifts", C.c_void_p)]
+
+
+class Options(C.Structure):
+    _fields_ = [("forced_shift", C.c_int32 * 3), ("reserved", C.c_int32 * 5)]
+
+
+def load_library(path=None):
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise LimgHipError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). There is no CPU fallback." % path)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64; if liblimg_hip.so pulled
+    # in /opt/rocm's copy first, torch's later initialisation would find "no HIP GPUs".  Importing torch first makes the
+    # loader resolve our DT_NEEDED libamdhip64.so.7 to the already-loaded copy (same SONAME).  C/C++ users are unaffected.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(path)
+    L.limg_hip_version.restype = C.c_char_p
+    L.limg_hip_init.restype = C.c_int
+    L.limg_hip_init.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.limg_hip_shutdown.argtypes = [C.POINTER(C.c_void_p)]
+    L.limg_hip_default_options.argtypes = [C.c_void_p]
+    L.limg_hip_set_options.restype = C.c_int
+    L.limg_hip_set_options.argtypes = [C.c_void_p, C.c_void_p]
+    L.limg_hip_encode3d.restype = C.c_int
+    L.limg_hip_encode3d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_int]
+    L.limg_hip_encode3d_perf.restype = C.c_int
+    L.limg_hip_encode3d_perf.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_uint32, C.c_int, C.c_int]
+    L.limg_hip_encode3d_device.restype = C.c_int
+    L.limg_hip_encode3d_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+    L.limg_hip_compare.restype = C.c_double
+    L.limg_hip_compare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+    L.limg_hip_compare_device.restype = C.c_double
+    L.limg_hip_compare_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.limg_hip_synth_random_gradient_device.restype = C.c_int
+    L.limg_hip_synth_random_gradient_device.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint64, C.c_int, C.c_size_t, C.c_void_p]
+    L.limg_hip_synth_photo_noise_device.restype = C.c_int
+    L.limg_hip_synth_photo_noise_device.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint64, C.c_size_t, C.c_void_p]
+    L.limg_hip_context_device_bytes.restype = C.c_size_t
+    L.limg_hip_context_device_bytes.argtypes = [C.c_void_p]
+    return L
+
+
+def _check(r, what):
+    if r != 0:
+        raise LimgHipError("%s failed with limg_hip_result %d" % (what, r))
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class LimgHip:
+    """One context on one GPU.  Host-array methods mirror the reference API (src/limg.h:35,37,48); *_device methods take
+    torch CUDA tensors (used only as device memory) and run asynchronously on torch's current stream."""
+
+    def __init__(self, device=-1):
+        self.lib = load_library()
+        self.ctx = C.c_void_p()
+        _check(self.lib.limg_hip_init(device, C.byref(self.ctx)), "limg_hip_init")
+
+    def close(self):
+        if self.ctx:
+            self.lib.limg_hip_shutdown(C.byref(self.ctx))
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_forced_shift(self, shift=None):
+        o = Options()
+        self.lib.limg_hip_default_options(C.byref(o))
+        if shift is not None:
+            for i in range(3):
+                o.forced_shift[i] = int(shift[i])
+        _check(self.lib.limg_hip_set_options(self.ctx, C.byref(o)), "limg_hip_set_options")
+
+    # ---- host pointers (drop-in for limg_encode3d_test / _perf / limg_compare) ---------------------------------------------
+    def encode3d(self, img, has_alpha, error_factor=100, pool_threads=0, fast=True):
+        img = np.ascontiguousarray(img, dtype=np.uint32)
+        h, w = img.shape
+        out = {k: np.zeros((h, w), dtype=np.uint32) for k in P32}
+        out.update({k: np.zeros((h, w), dtype=np.uint8) for k in P8})
+        info = Info(*[out[k].ctypes.data for k in PLANES])
+        _check(self.lib.limg_hip_encode3d(self.ctx, _np_ptr(img), w, h, int(has_alpha), C.byref(info), error_factor, pool_threads, int(fast)), "limg_hip_encode3d")
+        return out
+
+    def encode3d_perf(self, img, has_alpha, error_factor=100, pool_threads=0, fast=True):
+        img = np.ascontiguousarray(img, dtype=np.uint32)
+        h, w = img.shape
+        _check(self.lib.limg_hip_encode3d_perf(self.ctx, _np_ptr(img), w, h, int(has_alpha), error_factor, pool_threads, int(fast)), "limg_hip_encode3d_perf")
+
+    def compare(self, a, b, has_alpha):
+        a = np.ascontiguousarray(a, dtype=np.uint32)
+        b = np.ascontiguousarray(b, dtype=np.uint32)
+        mse, mx = C.c_double(), C.c_double()
+        p = self.lib.limg_hip_compare(self.ctx, _np_ptr(a), _np_ptr(b), a.shape[1], a.shape[0], int(has_alpha), C.byref(mse), C.byref(mx))
+        return p, mse.value
+
+    # ---- device pointers ------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _stream():
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def alloc_planes_device(self, w, h, device="cuda"):
+        import torch
+        d = {k: torch.empty((h, w), dtype=torch.int32, device=device) for k in P32}
+        d.update({k: torch.empty((h, w), dtype=torch.uint8, device=device) for k in P8})
+        return d
+
+    def encode3d_device(self, img, has_alpha, planes=None, error_factor=100, pool_threads=0, fast=True, records=None, shifts=None):
+        """img: torch int32 CUDA tensor (h, w); planes: dict from alloc_planes_device or None (`_perf` behaviour)."""
+        h, w = img.shape
+        info = None
+        if planes is not None:
+            info = Info(*[planes[k].data_ptr() for k in PLANES])
+        comp = None
+        if records is not None or shifts is not None:
+            comp = CompactOut(records.data_ptr() if records is not None else None, shifts.data_ptr() if shifts is not None else None)
+        _check(self.lib.limg_hip_encode3d_device(self.ctx, C.c_void_p(img.data_ptr()), w, h, int(has_alpha), C.byref(info) if info else None,
+                                                 C.byref(comp) if comp else None, error_factor, pool_threads, int(fast), self._stream()), "limg_hip_encode3d_device")
+
+    def compare_device(self, a, b, has_alpha):
+        mse, mx = C.c_double(), C.c_double()
+        h, w = a.shape
+        p = self.lib.limg_hip_compare_device(self.ctx, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), w, h, int(has_alpha), C.byref(mse), C.byref(mx), self._stream())
+        return p, mse.value
+
+    def synth_device(self, kind, w, h, seed=1, opaque=True, y0=0, device="cuda"):
+        import torch
+        out = torch.empty((h, w), dtype=torch.int32, device=device)
+        if kind == "random_gradient":
+            _check(self.lib.limg_hip_synth_random_gradient_device(C.c_void_p(out.data_ptr()), w, h, seed, int(opaque), y0, self._stream()), "synth")
+        elif kind == "photo_noise":
+            _check(self.lib.limg_hip_synth_photo_noise_device(C.c_void_p(out.data_ptr()), w, h, seed, y0, self._stream()), "synth")
+        else:
+            raise ValueError(kind)
+        return out
+
+    def device_bytes(self):
+        return self.lib.limg_hip_context_device_bytes(self.ctx)

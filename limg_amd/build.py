@@ -1,0 +1,47 @@
+"""Build liblimg_hip.so (hipcc, gfx950 only) in-tree: limg_amd/liblimg_hip.so.
+
+Numerics-critical flags: -ffp-contract=off (hipcc's default is fast contraction; the float stage must round every
+multiply and add separately, like the reference's SSE code) and no fast-math of any kind.  f32 division stays
+correctly rounded and f32 denormals stay enabled (hipcc defaults)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "liblimg_hip.so")
+SOURCES = ["limg_hip_kernels.hip", "limg_hip_synth.hip", "limg_hip_api.hip", "limg_hip_noise.cpp"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "limg_hip.h"), os.path.abspath(__file__)]
+    if not force and _newer(OUT, deps):
+        return OUT
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o")
+        cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if src.endswith(".cpp"):
+            cmd = [hipcc, "-O3", "-fPIC", "-std=c++17", "-Wall", "-x", "c++", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

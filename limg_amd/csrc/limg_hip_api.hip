@@ -1,0 +1,361 @@
+// limg_hip_api.hip -- host side of liblimg_hip.so: context, buffers, launch sequencing, the C ABI of include/limg_hip.h.
+// Mirrors the reference's driver (src/limg.cpp:2175-2265 threshold/flag setup, :2105-2138 strip partition).
+#include "limg_hip_internal.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+namespace limg_hip
+{
+  uint64_t chain_call(uint64_t h, unsigned n, uint8_t *noise64, bool forceSoft);
+  uint64_t fill_noise_table(uint64_t h, uint8_t *noise, size_t count);
+}
+
+using namespace limg_hip;
+
+#define HIP_TRY(expr)                                                                                                     \
+  do                                                                                                                      \
+  {                                                                                                                       \
+    const hipError_t e_ = (expr);                                                                                         \
+    if (e_ != hipSuccess)                                                                                                 \
+    {                                                                                                                     \
+      fprintf(stderr, "limg_hip: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__);            \
+      return limg_hip_error_Generic;                                                                                      \
+    }                                                                                                                     \
+  } while (0)
+
+struct DevBuf
+{
+  void *p = nullptr;
+  size_t cap = 0;
+  limg_hip_result ensure(size_t bytes)
+  {
+    if (bytes <= cap) return limg_hip_success;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    if (hipMalloc(&p, bytes) != hipSuccess) { p = nullptr; return limg_hip_error_MemoryAllocationFailure; }
+    cap = bytes;
+    return limg_hip_success;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct limg_hip_context
+{
+  int device = 0;
+  limg_hip_options opt;
+  DevBuf records, shifts, stripCalls, stripBase; // per-block / per-strip scratch
+  DevBuf noise;                                  // static dither noise table (full-block chains)
+  size_t noiseCount = 0;                         // entries generated so far
+  uint64_t noiseNext = kDitherSeed;              // chain value after the last generated entry
+  DevBuf noiseDyn;                               // data-dependent chains (images with partial blocks)
+  DevBuf in, planes;                             // staging for the host-pointer entry points
+  DevBuf cmp;                                    // 8-byte accumulator of limg_hip_compare
+};
+
+namespace
+{
+  constexpr size_t kNoiseChunk = 1u << 16; // table growth granularity (entries)
+
+  limg_hip_result grow_noise_table(limg_hip_context *c, size_t entries, hipStream_t stream)
+  {
+    if (entries <= c->noiseCount) return limg_hip_success;
+    const size_t want = ((entries + kNoiseChunk - 1) / kNoiseChunk) * kNoiseChunk;
+    // (re)generate on the host; one-time cost per context and image size class
+    std::vector<uint8_t> host(want * 64);
+    uint64_t h = kDitherSeed;
+    h = fill_noise_table(h, host.data(), want);
+    HIP_TRY(hipStreamSynchronize(stream));
+    const limg_hip_result r = c->noise.ensure(want * 64);
+    if (r != limg_hip_success) return r;
+    HIP_TRY(hipMemcpy(c->noise.p, host.data(), want * 64, hipMemcpyHostToDevice));
+    c->noiseCount = want;
+    c->noiseNext = h;
+    return limg_hip_success;
+  }
+
+  struct Partition { uint32_t chainCount, chainRows; };
+
+  // src/limg.cpp:2114-2134 in block rows
+  Partition partition(size_t sizeY, int poolThreads)
+  {
+    Partition pt = { 1, 0 };
+    if (poolThreads <= 0) return pt;
+    size_t thread_count = (size_t)poolThreads * 4;
+    size_t y_range = ((sizeY / kBlock) / thread_count) * kBlock;
+    if (y_range == 0)
+    {
+      thread_count = (size_t)poolThreads;
+      y_range = ((sizeY / kBlock) / thread_count) * kBlock;
+    }
+    if (y_range == 0) return pt; // every strip but the last is empty
+    pt.chainCount = (uint32_t)thread_count;
+    pt.chainRows = (uint32_t)(y_range / kBlock);
+    return pt;
+  }
+
+  uint32_t chain_of_row(const Partition &pt, uint32_t row)
+  {
+    if (pt.chainCount <= 1 || pt.chainRows == 0) return 0;
+    const uint32_t c = row / pt.chainRows;
+    return c < pt.chainCount - 1 ? c : pt.chainCount - 1;
+  }
+
+  limg_hip_result encode_device(limg_hip_context *c, const uint32_t *dIn, size_t sizeX, size_t sizeY, int hasAlpha, const limg_hip_encode3d_info *dInfo,
+                                const limg_hip_compact_out *compact, uint32_t errorFactor, int poolThreads, int fast, hipStream_t stream)
+  {
+    if (!c || !dIn) return limg_hip_error_ArgumentNull;
+    if (sizeX == 0 || sizeY == 0 || sizeX > 0x7FFFFFF8ull || sizeY > 0x7FFFFFF8ull) return limg_hip_error_InvalidParameter;
+    if (dInfo)
+    {
+      const void *const *pp = reinterpret_cast<const void *const *>(dInfo);
+      for (int i = 0; i < 11; i++)
+        if (!pp[i]) return limg_hip_error_ArgumentNull;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+
+    EncodeParams p;
+    memset(&p, 0, sizeof(p));
+    p.in = dIn;
+    p.sizeX = (uint32_t)sizeX; p.sizeY = (uint32_t)sizeY;
+    p.blocksX = (uint32_t)((sizeX + kBlock - 1) / kBlock);
+    p.blocksY = (uint32_t)((sizeY + kBlock - 1) / kBlock);
+    p.stripsX = (p.blocksX + kStripBlocks - 1) / kStripBlocks;
+    // thresholds and flags, src/limg.cpp:2186-2212
+    const uint64_t maxPixel = (uint64_t)0x6 * (errorFactor / 2) * 7, maxBlock = (uint64_t)0x4 * (errorFactor / 2) * 7;
+    p.maxPixel32 = maxPixel > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)maxPixel;
+    p.maxBlock = maxBlock;
+    p.crushBits = errorFactor != 0;
+    p.fast = fast != 0;
+    const bool forced = c->opt.forced_shift[0] >= 0 && c->opt.forced_shift[0] <= 8 && c->opt.forced_shift[1] >= 0 && c->opt.forced_shift[1] <= 8 &&
+                        c->opt.forced_shift[2] >= 0 && c->opt.forced_shift[2] <= 8;
+    for (int i = 0; i < 3; i++) p.forced[i] = forced ? c->opt.forced_shift[i] : -1;
+    const Partition pt = partition(sizeY, poolThreads);
+    p.chainCount = pt.chainCount; p.chainRows = pt.chainRows;
+
+    const size_t blocks = (size_t)p.blocksX * p.blocksY, strips = (size_t)p.stripsX * p.blocksY;
+    limg_hip_result r;
+    if (compact && compact->pRecords) p.records = compact->pRecords;
+    else { if ((r = c->records.ensure(blocks * sizeof(limg_hip_block_record))) != limg_hip_success) return r; p.records = (limg_hip_block_record *)c->records.p; }
+    if (compact && compact->pShifts) p.shifts = compact->pShifts;
+    else { if ((r = c->shifts.ensure(blocks * 4)) != limg_hip_success) return r; p.shifts = (uint32_t *)c->shifts.p; }
+    if ((r = c->stripCalls.ensure(strips * 4)) != limg_hip_success) return r;
+    if ((r = c->stripBase.ensure(strips * 4)) != limg_hip_success) return r;
+    p.stripCalls = (uint32_t *)c->stripCalls.p; p.stripBase = (uint32_t *)c->stripBase.p;
+    p.storePlanes = dInfo != nullptr;
+    if (dInfo) p.info = *dInfo;
+    const int channels = hasAlpha ? 4 : 3;
+    const bool ragged = (sizeX % kBlock) != 0 || (sizeY % kBlock) != 0;
+
+    if (dInfo && !ragged)
+    {
+      // longest chain, in blocks: every block makes at most 3 dither calls
+      uint32_t maxRows = p.blocksY;
+      if (pt.chainCount > 1) maxRows = p.blocksY - (pt.chainCount - 1) * pt.chainRows; // the last chain takes the remainder, never fewer rows than the others
+      if ((r = grow_noise_table(c, (size_t)maxRows * p.blocksX * 3, stream)) != limg_hip_success) return r;
+      p.noise = (const uint8_t *)c->noise.p;
+    }
+
+    launch_fit_search(p, channels, stream);
+    if (!dInfo)
+    {
+      HIP_TRY(hipGetLastError());
+      return limg_hip_success; // `_perf` behaviour: nothing to dither into, nothing to store
+    }
+
+    if (!ragged)
+    {
+      launch_strip_scan(p, stream);
+    }
+    else
+    {
+      // Partial edge blocks: the chain walk depends on each block's pixel count (G_N), so it is evaluated in raster
+      // order on the host from the per-block call counts (blocking; rare shape class -- config #1 is one).
+      std::vector<uint32_t> hShifts(blocks), hBase(strips);
+      HIP_TRY(hipMemcpyAsync(hShifts.data(), p.shifts, blocks * 4, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      size_t totalCalls = 0;
+      for (size_t i = 0; i < blocks; i++) totalCalls += hShifts[i] >> 24;
+      std::vector<uint8_t> hNoise((totalCalls + 1) * 64);
+      uint64_t h = kDitherSeed;
+      size_t call = 0;
+      for (uint32_t by = 0; by < p.blocksY; by++)
+      {
+        if (by == 0 || chain_of_row(pt, by) != chain_of_row(pt, by - 1)) h = kDitherSeed;
+        const unsigned ry = (unsigned)((sizeY - (size_t)by * kBlock) < kBlock ? (sizeY - (size_t)by * kBlock) : kBlock);
+        for (uint32_t bx = 0; bx < p.blocksX; bx++)
+        {
+          if (bx % kStripBlocks == 0) hBase[(size_t)by * p.stripsX + bx / kStripBlocks] = (uint32_t)call;
+          const unsigned rx = (unsigned)((sizeX - (size_t)bx * kBlock) < kBlock ? (sizeX - (size_t)bx * kBlock) : kBlock);
+          const uint32_t calls = hShifts[(size_t)by * p.blocksX + bx] >> 24;
+          for (uint32_t k = 0; k < calls; k++, call++) h = chain_call(h, rx * ry, hNoise.data() + call * 64, false);
+        }
+      }
+      if ((r = c->noiseDyn.ensure(hNoise.size())) != limg_hip_success) return r;
+      HIP_TRY(hipMemcpyAsync(c->noiseDyn.p, hNoise.data(), hNoise.size(), hipMemcpyHostToDevice, stream));
+      HIP_TRY(hipMemcpyAsync(p.stripBase, hBase.data(), strips * 4, hipMemcpyHostToDevice, stream));
+      HIP_TRY(hipStreamSynchronize(stream)); // the host vectors die with this scope
+      p.noise = (const uint8_t *)c->noiseDyn.p;
+    }
+    launch_dither_store(p, channels, stream);
+    HIP_TRY(hipGetLastError());
+    return limg_hip_success;
+  }
+}
+
+extern "C"
+{
+  const char *limg_hip_version(void) { return "limg_hip 0.1 (gfx950)"; }
+
+  void limg_hip_default_options(limg_hip_options *o)
+  {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->forced_shift[0] = o->forced_shift[1] = o->forced_shift[2] = -1;
+  }
+
+  limg_hip_result limg_hip_init(int device, limg_hip_context **ppCtx)
+  {
+    if (!ppCtx) return limg_hip_error_ArgumentNull;
+    *ppCtx = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+    {
+      fprintf(stderr, "limg_hip: no HIP device available -- this library has no CPU fallback\n");
+      return limg_hip_error_Generic;
+    }
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    if (device >= count) return limg_hip_error_InvalidParameter;
+    HIP_TRY(hipSetDevice(device));
+    limg_hip_context *c = new (std::nothrow) limg_hip_context();
+    if (!c) return limg_hip_error_MemoryAllocationFailure;
+    c->device = device;
+    limg_hip_default_options(&c->opt);
+    *ppCtx = c;
+    return limg_hip_success;
+  }
+
+  void limg_hip_shutdown(limg_hip_context **ppCtx)
+  {
+    if (!ppCtx || !*ppCtx) return;
+    limg_hip_context *c = *ppCtx;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    DevBuf *bufs[] = { &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->in, &c->planes, &c->cmp };
+    for (DevBuf *b : bufs) b->release();
+    delete c;
+    *ppCtx = nullptr;
+  }
+
+  limg_hip_result limg_hip_set_options(limg_hip_context *c, const limg_hip_options *o)
+  {
+    if (!c || !o) return limg_hip_error_ArgumentNull;
+    c->opt = *o;
+    return limg_hip_success;
+  }
+
+  size_t limg_hip_context_device_bytes(const limg_hip_context *c)
+  {
+    if (!c) return 0;
+    return c->records.cap + c->shifts.cap + c->stripCalls.cap + c->stripBase.cap + c->noise.cap + c->noiseDyn.cap + c->in.cap + c->planes.cap + c->cmp.cap;
+  }
+
+  limg_hip_result limg_hip_encode3d_device(limg_hip_context *c, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, const limg_hip_encode3d_info *pInfo,
+                                           const limg_hip_compact_out *pCompact, uint32_t errorFactor, int poolThreads, int fastBitCrushing, void *stream)
+  {
+    return encode_device(c, pIn, sizeX, sizeY, hasAlpha, pInfo, pCompact, errorFactor, poolThreads, fastBitCrushing, (hipStream_t)stream);
+  }
+
+  limg_hip_result limg_hip_encode3d(limg_hip_context *c, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, limg_hip_encode3d_info *pInfo, uint32_t errorFactor,
+                                    int poolThreads, int fastBitCrushing)
+  {
+    if (!c || !pIn || !pInfo) return limg_hip_error_ArgumentNull;
+    if (sizeX == 0 || sizeY == 0) return limg_hip_error_InvalidParameter;
+    void *const *hp = reinterpret_cast<void *const *>(pInfo);
+    for (int i = 0; i < 11; i++)
+      if (!hp[i]) return limg_hip_error_ArgumentNull;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t px = sizeX * sizeY;
+    limg_hip_result r;
+    if ((r = c->in.ensure(px * 4)) != limg_hip_success) return r;
+    if ((r = c->planes.ensure(px * 35 + 11 * 256)) != limg_hip_success) return r;
+    HIP_TRY(hipMemcpy(c->in.p, pIn, px * 4, hipMemcpyHostToDevice));
+    limg_hip_encode3d_info d;
+    uint8_t *base = (uint8_t *)c->planes.p;
+    void **dp = reinterpret_cast<void **>(&d);
+    size_t off = 0;
+    for (int i = 0; i < 11; i++)
+    {
+      dp[i] = base + off;
+      off += (i < 8 ? px * 4 : px);
+      off = (off + 255) & ~(size_t)255;
+    }
+    if ((r = encode_device(c, (const uint32_t *)c->in.p, sizeX, sizeY, hasAlpha, &d, nullptr, errorFactor, poolThreads, fastBitCrushing, nullptr)) != limg_hip_success) return r;
+    HIP_TRY(hipDeviceSynchronize());
+    for (int i = 0; i < 11; i++) HIP_TRY(hipMemcpy(hp[i], dp[i], i < 8 ? px * 4 : px, hipMemcpyDeviceToHost));
+    return limg_hip_success;
+  }
+
+  limg_hip_result limg_hip_encode3d_perf(limg_hip_context *c, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, uint32_t errorFactor, int poolThreads,
+                                         int fastBitCrushing)
+  {
+    if (!c || !pIn) return limg_hip_error_ArgumentNull;
+    if (sizeX == 0 || sizeY == 0) return limg_hip_error_InvalidParameter;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t px = sizeX * sizeY;
+    limg_hip_result r;
+    if ((r = c->in.ensure(px * 4)) != limg_hip_success) return r;
+    HIP_TRY(hipMemcpy(c->in.p, pIn, px * 4, hipMemcpyHostToDevice));
+    if ((r = encode_device(c, (const uint32_t *)c->in.p, sizeX, sizeY, hasAlpha, nullptr, nullptr, errorFactor, poolThreads, fastBitCrushing, nullptr)) != limg_hip_success) return r;
+    HIP_TRY(hipDeviceSynchronize());
+    return limg_hip_success;
+  }
+
+  double limg_hip_compare_device(limg_hip_context *c, const uint32_t *a, const uint32_t *b, size_t sizeX, size_t sizeY, int hasAlpha, double *pMse, double *pMax, void *stream)
+  {
+    if (!c || !a || !b || sizeX == 0 || sizeY == 0) return NAN;
+    if (hipSetDevice(c->device) != hipSuccess) return NAN;
+    if (c->cmp.ensure(8) != limg_hip_success) return NAN;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(c->cmp.p, 0, 8, s) != hipSuccess) return NAN;
+    launch_compare(a, b, (uint64_t)sizeX * sizeY, hasAlpha ? 4 : 3, (unsigned long long *)c->cmp.p, s);
+    unsigned long long err = 0;
+    if (hipMemcpyAsync(&err, c->cmp.p, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return NAN;
+    // maxError = limg_color_error(min, max): red diff 255^2 >= 0x4000 => factors {3,4,2,3}
+    const double maxError = 255.0 * 255.0 * (hasAlpha ? 12.0 : 9.0);
+    const double mse = (double)err / (double)(sizeX * sizeY);
+    if (pMse) *pMse = mse;
+    if (pMax) *pMax = maxError;
+    return 10.0 * log10(maxError / mse);
+  }
+
+  double limg_hip_compare(limg_hip_context *c, const uint32_t *a, const uint32_t *b, size_t sizeX, size_t sizeY, int hasAlpha, double *pMse, double *pMax)
+  {
+    if (!c || !a || !b || sizeX == 0 || sizeY == 0) return NAN;
+    if (hipSetDevice(c->device) != hipSuccess) return NAN;
+    const size_t bytes = sizeX * sizeY * 4;
+    if (c->in.ensure(bytes) != limg_hip_success || c->planes.ensure(bytes) != limg_hip_success) return NAN;
+    if (hipMemcpy(c->in.p, a, bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(c->planes.p, b, bytes, hipMemcpyHostToDevice) != hipSuccess) return NAN;
+    return limg_hip_compare_device(c, (const uint32_t *)c->in.p, (const uint32_t *)c->planes.p, sizeX, sizeY, hasAlpha, pMse, pMax, nullptr);
+  }
+
+  limg_hip_result limg_hip_synth_random_gradient_device(uint32_t *pOut, size_t width, size_t height, uint64_t seed, int opaque, size_t y0, void *stream)
+  {
+    if (!pOut) return limg_hip_error_ArgumentNull;
+    launch_synth_random_gradient(pOut, (uint32_t)width, (uint32_t)height, seed, opaque, (uint32_t)y0, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return limg_hip_success;
+  }
+
+  limg_hip_result limg_hip_synth_photo_noise_device(uint32_t *pOut, size_t width, size_t height, uint64_t seed, size_t y0, void *stream)
+  {
+    if (!pOut) return limg_hip_error_ArgumentNull;
+    launch_synth_photo_noise(pOut, (uint32_t)width, (uint32_t)height, seed, (uint32_t)y0, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return limg_hip_success;
+  }
+}

@@ -1,0 +1,48 @@
+// Internal declarations shared by the host API (limg_hip_api.hip) and the kernel files.  Not part of the C ABI.
+#ifndef LIMG_HIP_INTERNAL_H
+#define LIMG_HIP_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/limg_hip.h"
+
+namespace limg_hip
+{
+  constexpr int kBlock = 8;        // limg_MinBlockSize (reference: src/limg_internal.h:158)
+  constexpr int kStripBlocks = 32; // image blocks per workgroup ("work strip": 256 x 8 px)
+  constexpr uint64_t kDitherSeed = 0xCA7F00D15BADF00DULL; // reference: src/limg.cpp:1893
+
+  // Everything one encode needs on the device.  Passed by value to the kernels.
+  struct EncodeParams
+  {
+    const uint32_t *in;
+    uint32_t sizeX, sizeY, blocksX, blocksY, stripsX;
+    uint32_t maxPixel32;     // min(maxPixelBitCrushError, 2^32 - 1)
+    uint64_t maxBlock;       // maxBlockBitCrushError
+    int32_t crushBits, fast; // reference: src/limg.cpp:2192-2197
+    int32_t forced[3];       // -1 or forced shift
+    // chain partition (reference: src/limg.cpp:2114-2134), in block rows
+    uint32_t chainCount, chainRows; // chain c (< chainCount-1) owns block rows [c*chainRows, (c+1)*chainRows); the last owns the rest
+    // per-block scratch / compact outputs
+    limg_hip_block_record *records;
+    uint32_t *shifts;      // per block: sA | sB<<8 | sC<<16 | calls<<24
+    uint32_t *stripCalls;  // per work strip: number of dither calls (blocksY * stripsX, raster order)
+    uint32_t *stripBase;   // per work strip: index of its first dither call inside its chain (exclusive scan)
+    // pre-dither factor bytes live in the caller's factor planes between the two kernels
+    limg_hip_encode3d_info info;
+    int32_t storePlanes;   // 0: _perf behaviour
+    // dither noise: byte p of call k = low byte of the 16-bit lane the reference ANDs with ditherSize for pixel p
+    const uint8_t *noise;
+  };
+
+  void launch_fit_search(const EncodeParams &p, int channels, hipStream_t s);
+  void launch_strip_scan(const EncodeParams &p, hipStream_t s);
+  void launch_dither_store(const EncodeParams &p, int channels, hipStream_t s);
+
+  void launch_synth_random_gradient(uint32_t *out, uint32_t w, uint32_t h, uint64_t seed, int opaque, uint32_t y0, hipStream_t s);
+  void launch_synth_photo_noise(uint32_t *out, uint32_t w, uint32_t h, uint64_t seed, uint32_t y0, hipStream_t s);
+  void launch_compare(const uint32_t *a, const uint32_t *b, uint64_t count, int channels, unsigned long long *dErrorSum, hipStream_t s);
+}
+
+#endif

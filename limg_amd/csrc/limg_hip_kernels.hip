@@ -1,0 +1,988 @@
+// limg_hip_kernels.hip -- gfx950 kernels of the limg encode hot path.
+//
+// Path (reference file:line, all relative to the upstream repository):
+//   k_fit_search   : block gather src/limg.cpp:1899-1905, channel sums :466-497, direction fit + extrema
+//                    src/limg_factorization.h:578-794 (4 ch) / :382-576 (3 ch), colour-error state src/limg_internal.h:426-452,
+//                    per-pixel factors src/limg_factorization.h:98-197, shift search src/limg_bit_crush.h:331-392 + :502-666
+//                    (accurate mode :668-830) on top of the trial src/limg_bit_crush_simd.h:311-810
+//   k_strip_scan   : the dither chain order of src/limg.cpp:1893,1951-1958 turned into call indices (exclusive scan)
+//   k_dither_store : dither src/limg.cpp:824-879 (noise bytes come from the context's table), plane stores :2004-2093,
+//                    integer decode src/limg_decode.h:36-236
+//
+// Work decomposition: one 256-thread workgroup owns a "work strip" of 32 adjacent 8x8 image blocks (256 x 8 pixels): its
+// eight 1 KiB pixel rows are read with 16-byte-per-lane loads into LDS, each of the 4 waves then owns 8 blocks and works
+// with lane == pixel (wave64 == 64 pixels == one block).  Per-block control flow (the shift search) is wave-uniform.
+//
+// Float-stage numerics are those of the reference's SSE4.1 path executed strictly (see DESIGN.md "numerics"):
+//   * DPPS summation order (x0y0 + x1y1) + (x2y2 + x3y3), no FMA contraction (built with -ffp-contract=off);
+//   * RSQRTPS through the captured 2048-entry table (limg_rsqrt_x86_table.h) held in LDS;
+//   * the three direction accumulations run in *pixel order*: the per-pixel unit vectors of 8 blocks are parked in LDS
+//     and 32 lanes (8 blocks x 4 channels) each walk one serial 64-term chain -- the serial order costs ~2 instructions
+//     per term for 32 chains at once instead of a 64-step dependent chain per block;
+//   * correctly rounded division (hipcc default) and round-to-nearest-even conversions.
+#include "limg_hip_internal.h"
+#include "limg_rsqrt_x86_table.h"
+
+#include <float.h>
+
+namespace limg_hip
+{
+  namespace
+  {
+    constexpr int kThreads = 256;
+    constexpr int kWaves = 4;
+    constexpr int kBlocksPerWave = 8;
+    constexpr int kRowDw = 264; // LDS pixel-row stride in dwords: 256 px + 8 pad => bank = (8*row + x) mod 32, conflict-free per 32-lane half
+    constexpr int kVDw = 260;   // per-block stride of the parked contributions: 64 px * 4 ch + 4 pad => the (block, channel) walkers hit 32 distinct banks
+
+    __device__ const unsigned short d_rsqrt_x86_tab[2048] = LIMG_RSQRT_X86_TAB_INIT;
+
+    enum : uint32_t { kZeroA = 1u, kZeroB = 2u, kZeroC = 4u, kValid = 8u };
+
+    // per-block state parked in LDS between the phases of k_fit_search
+    struct Blk
+    {
+      float avg[4], dirA[4], dirB[4], dirC[4], est0[4];
+      float mm[6]; // minA maxA minB maxB minC maxC
+      float inv_count, invN[3];
+      uint32_t n, rx, flags, pad[3];
+      int16_t rec[24]; // dirA_min[4] dirA_max[4] dirB_offset[4] dirB_mag[4] dirC_offset[4] dirC_mag[4]
+    };
+    static_assert(sizeof(Blk) == 192, "Blk layout");
+
+    // ---- wave64 helpers -------------------------------------------------------------------------------------------
+    __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+    __device__ __forceinline__ void wave_lds_fence()
+    {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    template <int CTRL, int ROWMASK>
+    __device__ __forceinline__ int dpp(int oldv, int v) { return __builtin_amdgcn_update_dpp(oldv, v, CTRL, ROWMASK, 0xF, false); }
+
+    // integer sum over the wave; result is wave-uniform
+    __device__ __forceinline__ uint32_t wave_sum(uint32_t x)
+    {
+      int v = (int)x;
+      v += dpp<0xB1, 0xF>(0, v);  // quad_perm [1,0,3,2]
+      v += dpp<0x4E, 0xF>(0, v);  // quad_perm [2,3,0,1]
+      v += dpp<0x141, 0xF>(0, v); // row_half_mirror
+      v += dpp<0x140, 0xF>(0, v); // row_mirror
+      v += dpp<0x142, 0xA>(0, v); // row_bcast:15
+      v += dpp<0x143, 0xC>(0, v); // row_bcast:31
+      return (uint32_t)__builtin_amdgcn_readlane(v, 63);
+    }
+
+    // exact (order independent) float min / max over the wave; no NaN may be present
+    template <bool MAX>
+    __device__ __forceinline__ float wave_minmax(float x)
+    {
+      auto op = [](float a, float b) { return MAX ? __builtin_fmaxf(a, b) : __builtin_fminf(a, b); };
+      int v = __float_as_int(x);
+      v = __float_as_int(op(__int_as_float(v), __int_as_float(dpp<0xB1, 0xF>(v, v))));
+      v = __float_as_int(op(__int_as_float(v), __int_as_float(dpp<0x4E, 0xF>(v, v))));
+      v = __float_as_int(op(__int_as_float(v), __int_as_float(dpp<0x141, 0xF>(v, v))));
+      v = __float_as_int(op(__int_as_float(v), __int_as_float(dpp<0x140, 0xF>(v, v))));
+      v = __float_as_int(op(__int_as_float(v), __int_as_float(dpp<0x142, 0xA>(v, v))));
+      v = __float_as_int(op(__int_as_float(v), __int_as_float(dpp<0x143, 0xC>(v, v))));
+      return __int_as_float(__builtin_amdgcn_readlane(v, 63));
+    }
+
+    __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+    __device__ __forceinline__ float sgprf(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+    // ---- x86 float semantics --------------------------------------------------------------------------------------
+    // DPPS 0xFF / 0x7F
+    template <int CH>
+    __device__ __forceinline__ float dpps(const float a[4], const float b[4])
+    {
+      const float p0 = a[0] * b[0], p1 = a[1] * b[1], p2 = a[2] * b[2];
+      const float p3 = CH == 4 ? a[3] * b[3] : 0.0f;
+      return (p0 + p1) + (p2 + p3);
+    }
+
+    // RSQRTPS (Intel) through the table in LDS; argument is a finite positive normal number here
+    __device__ __forceinline__ float rsqrt_x86(const unsigned short *tab, float x)
+    {
+      const uint32_t b = __float_as_uint(x);
+      const uint32_t idx = ((b >> 13) & 0x7FFu) ^ 0x400u; // [exponent lsb : top 10 mantissa bits], odd exponents first
+      const int e = (int)((b >> 23) & 0xFF);
+      const int k = (e - 127) >> 1;
+      return __uint_as_float(((uint32_t)(126 - k) << 23) | ((uint32_t)tab[idx] << 11));
+    }
+
+    // MINPS / MAXPS operand semantics (second operand when unordered); inputs here are never NaN but keep the form
+    __device__ __forceinline__ float minps(float a, float b) { return a < b ? a : b; }
+    __device__ __forceinline__ float maxps(float a, float b) { return a > b ? a : b; }
+
+    // sign-normalised unit vector of one pixel's difference vector (src/limg_factorization.h:605-623 and twins)
+    template <int CH>
+    __device__ __forceinline__ void unit_contribution(const unsigned short *tab, const float d[4], bool active, float out[4])
+    {
+      const bool nz = !(d[0] == 0.0f && d[1] == 0.0f && d[2] == 0.0f && d[3] == 0.0f);
+      const float e3 = FLT_EPSILON * 3, e2 = FLT_EPSILON * 2, e1 = FLT_EPSILON;
+      const float hmin0 = minps(d[0] - e3, d[2] - e1), hmin1 = minps(d[1] - e2, d[3] - 0.0f);
+      const float hmax0 = maxps(d[0] + e3, d[2] + e1), hmax1 = maxps(d[1] + e2, d[3] + 0.0f);
+      const float abs_min = __builtin_fabsf(minps(hmin0, hmin1));
+      const float mx = maxps(hmax0, hmax1);
+      float len2 = dpps<CH>(d, d);
+      len2 = nz ? len2 : 1.0f; // keep the table index sane on skipped lanes
+      float inv = rsqrt_x86(tab, len2);
+      inv = (abs_min > mx) ? -inv : inv;
+      const bool use = nz && active;
+#pragma unroll
+      for (int c = 0; c < 4; c++) out[c] = use ? d[c] * inv : 0.0f;
+    }
+
+    __device__ __forceinline__ void px_to_float(uint32_t px, float f[4])
+    {
+      f[0] = (float)(px & 0xFF); f[1] = (float)((px >> 8) & 0xFF); f[2] = (float)((px >> 16) & 0xFF); f[3] = (float)(px >> 24);
+    }
+
+    __device__ __forceinline__ int cvt_rne(float x) { return (int)__builtin_rintf(x); }
+
+    __device__ __forceinline__ void store_v(float *V, int lane, const float v[4])
+    {
+      *reinterpret_cast<float4 *>(V + lane * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+
+    // Pixel-order accumulation of the parked contributions of this wave's 8 blocks: lane (b, c) walks V[b][0..63][c].
+    __device__ __forceinline__ void serial_sums(const float *V, Blk *blk, int which, int lane)
+    {
+      wave_lds_fence();
+      if (lane < 32)
+      {
+        const int b = lane >> 2, c = lane & 3;
+        const float *src = V + b * kVDw + c;
+        float s = 0.0f;
+#pragma unroll 16
+        for (int i = 0; i < 64; i++) s = s + src[i * 4];
+        const float dir = s * blk[b].inv_count;
+        float *dst = which == 0 ? blk[b].dirA : (which == 1 ? blk[b].dirB : blk[b].dirC);
+        dst[c] = dir;
+      }
+      wave_lds_fence();
+    }
+
+    // ---- integer stage ------------------------------------------------------------------------------------------------
+    // (1 << s) + decode_bias(s)  (src/limg_bit_crush_simd.h:611-619): 1,2,4,8,17,36,85,255,256
+    __device__ __forceinline__ uint32_t shift_mul(uint32_t s)
+    {
+      const uint64_t biasPacked = (1ull << 28) | (4ull << 35) | (21ull << 42) | (127ull << 49); // 7 bits per shift value
+      return (1u << s) + (uint32_t)((biasPacked >> (7 * s)) & 127u);
+    }
+
+    struct RecU // wave-uniform integer view of a record for the reconstruct (RGB lanes only; alpha never reaches the trial error)
+    {
+      int nA[3], nB[3], nC[3], mA[3], mB[3], mC[3];
+    };
+
+    // a9: one bit-crush trial.  Returns pass / fail (wave-uniform); blockError valid on pass.
+    __device__ __forceinline__ bool trial(const uint32_t px, const uint32_t fA, const uint32_t fB, const uint32_t fC, const RecU &r, const uint32_t sA,
+                                          const uint32_t sB, const uint32_t sC, const bool active, const uint32_t maxPixel32, const uint64_t maxBlockN,
+                                          uint32_t &blockError)
+    {
+      const uint32_t dA = (fA >> sA) * shift_mul(sA), dB = (fB >> sB) * shift_mul(sB), dC = (fC >> sC) * shift_mul(sC);
+      uint32_t dsq[3];
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+      {
+        const int nA = sA > 7 ? 0 : r.nA[c], nB = sB > 7 ? 0 : r.nB[c], nC = sC > 7 ? 0 : r.nC[c];
+        const int mA = r.mA[c], mB = sB > 7 ? 128 : r.mB[c], mC = sC > 7 ? 128 : r.mC[c];
+        int est = ((int)(dA * (uint32_t)nA + (uint32_t)mA) >> 8) + ((int)(dB * (uint32_t)nB + (uint32_t)mB) >> 8) + ((int)(dC * (uint32_t)nC + (uint32_t)mC) >> 8);
+        est = est < 0 ? 0 : (est > 255 ? 255 : est);
+        const int d = (int)((px >> (8 * c)) & 0xFF) - est;
+        dsq[c] = (uint32_t)(d * d);
+      }
+      const bool low_red = (int)dsq[0] < 0x4000;
+      uint32_t err = dsq[0] * (low_red ? 2u : 3u) + dsq[2] * (low_red ? 3u : 2u) + dsq[1] * 4u;
+      err = active ? err : 0u;
+      const bool any_fail = __builtin_amdgcn_ballot_w64(err > maxPixel32) != 0ull;
+      const uint32_t be = wave_sum(err);
+      blockError = be;
+      return !any_fail && ((uint64_t)be * 16ull < maxBlockN);
+    }
+
+    // a10-a12 search driver; everything in here is wave-uniform
+    template <typename TRY>
+    __device__ __forceinline__ void search_fast(TRY &&T, uint32_t shift[3])
+    {
+      uint32_t be;
+      // guess, src/limg_bit_crush.h:331-392
+      if (T(4, 5, 6, be))
+      {
+        shift[0] = 4; shift[1] = 5; shift[2] = 6;
+        if (T(5, 8, 8, be)) { shift[0] = 5; shift[1] = 8; shift[2] = 8; }
+        else if (T(4, 6, 8, be)) { shift[0] = 4; shift[1] = 6; shift[2] = 8; }
+      }
+      else if (T(2, 4, 5, be)) { shift[0] = 2; shift[1] = 4; shift[2] = 5; }
+
+      // stepwise, src/limg_bit_crush.h:502-614 (uint8_t counters upstream; values stay < 16 here so plain ints behave identically)
+      uint32_t max_shift = shift[0] + shift[1] + shift[2];
+      {
+        uint32_t a = shift[0] & 15, b = shift[1] & 15, c = (shift[2] & 15) + 2;
+        for (; a <= 8; a += 2)
+        {
+          for (; b <= 8; b += 2)
+          {
+            for (; c <= 8; c += 2)
+            {
+              if (a + b + c > max_shift)
+              {
+                if (T(a, b, c, be)) { shift[0] = a; shift[1] = b; shift[2] = c; max_shift = a + b + c; }
+                else
+                  break;
+              }
+            }
+            if (c == b) break;
+            c = b;
+          }
+          if (b == a) break;
+          b = a;
+        }
+      }
+      {
+        const uint32_t pre_a = shift[0], pre_b = shift[1], pre_c = shift[2];
+        const uint32_t max_a = (!(pre_a & 1) && pre_a != 8) ? 1 : 0, max_b = (!(pre_b & 1) && pre_b != 8) ? 1 : 0, max_c = (!(pre_c & 1) && pre_c != 8) ? 1 : 0;
+        uint32_t fine = 0, a = 0, b = 0, c = 1;
+        for (; a <= max_a; a++)
+        {
+          for (; b <= max_b; b++)
+          {
+            for (; c <= max_c; c++)
+            {
+              if (a + b + c > fine)
+              {
+                if (T(pre_a + a, pre_b + b, pre_c + c, be)) { shift[0] = pre_a + a; shift[1] = pre_b + b; shift[2] = pre_c + c; fine = a + b + c; }
+                else
+                  break;
+              }
+            }
+            if (c == 0) break;
+            c = 0;
+          }
+          if (b == 0) break;
+          b = 0;
+        }
+      }
+    }
+
+    template <typename TRY>
+    __device__ __forceinline__ void search_accurate(TRY &&T, uint32_t shift[3])
+    {
+      // src/limg_bit_crush.h:668-830
+      uint32_t be, max_shift = 0, min_be = 0xFFFFFFFFu;
+      bool have = false; // min_block_error == (size_t)-1 upstream
+      if (T(4, 5, 6, be))
+      {
+        shift[0] = 4; shift[1] = 5; shift[2] = 6; max_shift = 15; min_be = be; have = true;
+        if (T(5, 8, 8, be)) { shift[0] = 5; shift[1] = 8; shift[2] = 8; max_shift = 21; min_be = be; }
+        else if (T(4, 6, 8, be)) { shift[0] = 4; shift[1] = 6; shift[2] = 8; max_shift = 18; min_be = be; }
+      }
+      else if (T(2, 4, 5, be)) { shift[0] = 2; shift[1] = 4; shift[2] = 5; max_shift = 11; min_be = be; have = true; }
+      {
+        uint32_t a = 0, b = 0, c = 1;
+        for (; a <= 8; a++)
+        {
+          for (; b <= 8; b++)
+          {
+            for (; c <= 8; c++)
+            {
+              if (a + b + c > max_shift && (a != shift[0] || b != shift[1] || c != shift[2]))
+              {
+                if (T(a, b, c, be)) { shift[0] = a; shift[1] = b; shift[2] = c; max_shift = a + b + c; min_be = be; have = true; }
+                else
+                  break;
+              }
+            }
+            if (c == 0) break;
+            c = 0;
+          }
+          if (b == 0) break;
+          b = 0;
+        }
+      }
+      if (max_shift > 0)
+      {
+        uint32_t a = shift[0], b = shift[1], c = shift[2] + 1;
+        for (; a <= 8; a++)
+        {
+          for (; b <= 8; b++)
+          {
+            for (; c <= 8; c++)
+            {
+              if (a + b + c == max_shift)
+              {
+                if (T(a, b, c, be))
+                {
+                  if (!have || min_be > be) { shift[0] = a; shift[1] = b; shift[2] = c; min_be = be; have = true; }
+                }
+                else
+                  break;
+              }
+            }
+            if (c == 0) break;
+            c = 0;
+          }
+          if (b == 0) break;
+          b = 0;
+        }
+      }
+    }
+
+    // =====================================================================================================================
+    // kernel 1: fit + factors + shift search
+    // =====================================================================================================================
+    template <int CH>
+    __global__ __launch_bounds__(kThreads) void k_fit_search(const EncodeParams p)
+    {
+      __shared__ __attribute__((aligned(16))) unsigned short s_rsq[2048];
+      __shared__ __attribute__((aligned(16))) uint32_t s_strip[8 * kRowDw];
+      __shared__ __attribute__((aligned(16))) float s_V[kWaves * kBlocksPerWave * kVDw];
+      __shared__ __attribute__((aligned(16))) Blk s_blk[kStripBlocks];
+      __shared__ uint32_t s_calls[kWaves];
+
+      const int tid = (int)threadIdx.x;
+      const int lane = tid & 63, wave = tid >> 6;
+      const uint32_t strip = blockIdx.x % p.stripsX, by = blockIdx.x / p.stripsX;
+      const uint32_t x0 = strip * (kStripBlocks * kBlock), y0 = by * kBlock;
+      const uint32_t stripW = min(p.sizeX - x0, (uint32_t)(kStripBlocks * kBlock)); // pixels
+      const uint32_t ry = min(p.sizeY - y0, (uint32_t)kBlock);
+
+      // ---- stage: rsqrt table + the strip's pixel rows into LDS ------------------------------------------------------
+      for (int i = tid; i < 2048 / 8; i += kThreads)
+        reinterpret_cast<uint4 *>(s_rsq)[i] = reinterpret_cast<const uint4 *>(d_rsqrt_x86_tab)[i];
+      if ((p.sizeX & 3u) == 0)
+      {
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++)
+        {
+          const uint32_t row = pass * 4 + (tid >> 6), col = (tid & 63) * 4; // 4 px per lane
+          if (row < ry && col < stripW)
+          {
+            const uint4 v = *reinterpret_cast<const uint4 *>(p.in + (size_t)(y0 + row) * p.sizeX + x0 + col);
+            *reinterpret_cast<uint4 *>(&s_strip[row * kRowDw + col]) = v;
+          }
+        }
+      }
+      else
+      {
+        for (uint32_t i = tid; i < 8 * 256; i += kThreads)
+        {
+          const uint32_t row = i >> 8, col = i & 255;
+          if (row < ry && col < stripW) s_strip[row * kRowDw + col] = p.in[(size_t)(y0 + row) * p.sizeX + x0 + col];
+        }
+      }
+      __syncthreads();
+
+      float *V = s_V + wave * kBlocksPerWave * kVDw;
+      Blk *blk = s_blk + wave * kBlocksPerWave;
+
+      // per-block geometry helpers (wave-uniform)
+      auto geom = [&](int b, uint32_t &rx, uint32_t &n) -> bool
+      {
+        const uint32_t sb = wave * kBlocksPerWave + b;
+        const uint32_t bx = strip * kStripBlocks + sb;
+        if (bx >= p.blocksX) { rx = 0; n = 0; return false; }
+        rx = min(p.sizeX - bx * kBlock, (uint32_t)kBlock);
+        n = rx * ry;
+        return true;
+      };
+      auto load_px = [&](int b, uint32_t rx, uint32_t n, float pf[4]) -> uint32_t
+      {
+        const uint32_t sb = wave * kBlocksPerWave + b;
+        uint32_t lx, ly;
+        if (rx == 8) { lx = lane & 7; ly = lane >> 3; }
+        else { const uint32_t l = (uint32_t)lane < n ? (uint32_t)lane : 0u; ly = l / rx; lx = l - ly * rx; }
+        uint32_t px = s_strip[ly * kRowDw + sb * kBlock + lx];
+        px = (uint32_t)lane < n ? px : 0u;
+        px_to_float(px, pf);
+        return px;
+      };
+
+      // ---- phase A: sums, average, first direction pass (a4, a5/a6 pass 1) ------------------------------------------
+      for (int b = 0; b < kBlocksPerWave; b++)
+      {
+        uint32_t rx, n;
+        const bool valid = geom(b, rx, n);
+        if (!valid)
+        {
+          if (lane == 0) { blk[b].flags = 0; blk[b].n = 0; blk[b].inv_count = 0.0f; }
+          continue;
+        }
+        float pf[4];
+        const uint32_t px = load_px(b, rx, n, pf);
+        const uint32_t s02 = wave_sum(px & 0x00FF00FFu), s13 = wave_sum((px >> 8) & 0x00FF00FFu);
+        const float inv_count = 1.0f / (float)n;
+        float avg[4];
+        avg[0] = (float)(int)(s02 & 0xFFFF) * inv_count;
+        avg[1] = (float)(int)(s13 & 0xFFFF) * inv_count;
+        avg[2] = (float)(int)(s02 >> 16) * inv_count;
+        avg[3] = CH == 4 ? (float)(int)(s13 >> 16) * inv_count : 0.0f;
+        float d[4], v[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) d[c] = pf[c] - avg[c];
+        if (CH == 3) d[3] = 0.0f;
+        unit_contribution<CH>(s_rsq, d, (uint32_t)lane < n, v);
+        store_v(V + b * kVDw, lane, v);
+        if (lane == 0)
+        {
+          blk[b].avg[0] = avg[0]; blk[b].avg[1] = avg[1]; blk[b].avg[2] = avg[2]; blk[b].avg[3] = avg[3];
+          blk[b].inv_count = inv_count; blk[b].n = n; blk[b].rx = rx; blk[b].flags = kValid;
+#pragma unroll
+          for (int k = 0; k < 6; k++) blk[b].mm[k] = 0.0f;
+#pragma unroll
+          for (int c = 0; c < 4; c++) { blk[b].dirB[c] = 0.0f; blk[b].dirC[c] = 0.0f; blk[b].est0[c] = 0.0f; }
+        }
+      }
+      serial_sums(V, blk, 0, lane);
+
+      // ---- phase B: factor A extrema, residual -> second direction (pass 2) --------------------------------------------
+      for (int b = 0; b < kBlocksPerWave; b++)
+      {
+        uint32_t rx, n;
+        if (!geom(b, rx, n)) continue;
+        float dirA[4], avg[4], pf[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) { dirA[c] = sgprf(blk[b].dirA[c]); avg[c] = sgprf(blk[b].avg[c]); }
+        const bool zeroA = (dirA[0] == 0.0f && dirA[1] == 0.0f && dirA[2] == 0.0f && dirA[3] == 0.0f);
+        if (zeroA)
+        {
+          if (lane == 0) blk[b].flags |= kZeroA | kZeroB | kZeroC;
+          continue;
+        }
+        load_px(b, rx, n, pf);
+        const bool active = (uint32_t)lane < n;
+        const float invA = 1.0f / dpps<CH>(dirA, dirA);
+        float l[4], e[4], v[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) l[c] = pf[c] - avg[c];
+        const float fA = dpps<CH>(l, dirA) * invA;
+        const float mn = __builtin_fminf(0.0f, wave_minmax<false>(active ? fA : 0.0f));
+        const float mx = __builtin_fmaxf(0.0f, wave_minmax<true>(active ? fA : 0.0f));
+#pragma unroll
+        for (int c = 0; c < 4; c++) e[c] = pf[c] - (avg[c] + fA * dirA[c]);
+        if (CH == 3) e[3] = 0.0f;
+        unit_contribution<CH>(s_rsq, e, active, v);
+        store_v(V + b * kVDw, lane, v);
+        if (lane == 0) { blk[b].mm[0] = mn; blk[b].mm[1] = mx; }
+      }
+      serial_sums(V, blk, 1, lane);
+
+      // ---- phase C: factor B (and, 3 ch, C) extrema; 4 ch: residual -> third direction (pass 3) ---------------------
+      for (int b = 0; b < kBlocksPerWave; b++)
+      {
+        uint32_t rx, n;
+        if (!geom(b, rx, n)) continue;
+        const uint32_t flags = (uint32_t)sgpr((int)blk[b].flags);
+        if (flags & kZeroA) continue;
+        float dirA[4], dirB[4], avg[4], pf[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) { dirA[c] = sgprf(blk[b].dirA[c]); dirB[c] = sgprf(blk[b].dirB[c]); avg[c] = sgprf(blk[b].avg[c]); }
+        const bool zeroB = (dirB[0] == 0.0f && dirB[1] == 0.0f && dirB[2] == 0.0f && dirB[3] == 0.0f);
+        if (zeroB)
+        { // 1/0 = inf => every fB is NaN upstream => B and (through the NaN estimate) C collapse to 0
+          if (lane == 0) blk[b].flags |= kZeroB | kZeroC;
+          continue;
+        }
+        load_px(b, rx, n, pf);
+        const bool active = (uint32_t)lane < n;
+        const float invA = 1.0f / dpps<CH>(dirA, dirA);
+        const float invB = 1.0f / dpps<CH>(dirB, dirB);
+        float l[4], est[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) l[c] = pf[c] - avg[c];
+        const float fA = dpps<CH>(l, dirA) * invA;
+#pragma unroll
+        for (int c = 0; c < 4; c++) { est[c] = avg[c] + fA * dirA[c]; l[c] = pf[c] - est[c]; }
+        const float fB = dpps<CH>(l, dirB) * invB;
+        const float mnB = wave_minmax<false>(active ? fB : FLT_MAX);
+        const float mxB = wave_minmax<true>(active ? fB : -FLT_MAX);
+        if (CH == 4)
+        {
+          float e[4], v[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) { est[c] = est[c] + fB * dirB[c]; e[c] = pf[c] - est[c]; }
+          unit_contribution<CH>(s_rsq, e, active, v);
+          store_v(V + b * kVDw, lane, v);
+          if (lane == 0)
+          {
+            blk[b].mm[2] = mnB; blk[b].mm[3] = mxB;
+            blk[b].est0[0] = est[0]; blk[b].est0[1] = est[1]; blk[b].est0[2] = est[2]; blk[b].est0[3] = est[3];
+          }
+        }
+        else
+        {
+          // dirC = dirA x dirB (src/limg_factorization.h:498-507)
+          float dirC[4];
+          dirC[0] = dirA[1] * dirB[2] - dirA[2] * dirB[1];
+          dirC[1] = dirA[2] * dirB[0] - dirA[0] * dirB[2];
+          dirC[2] = dirA[0] * dirB[1] - dirA[1] * dirB[0];
+          dirC[3] = 0.0f;
+          const bool zeroC = (dirC[0] == 0.0f && dirC[1] == 0.0f && dirC[2] == 0.0f);
+          float mnC = 0.0f, mxC = 0.0f;
+          if (!zeroC)
+          {
+            const float invC = 1.0f / dpps<CH>(dirC, dirC);
+            float e[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) e[c] = pf[c] - (est[c] + fB * dirB[c]);
+            const float fC = dpps<CH>(e, dirC) * invC;
+            mnC = wave_minmax<false>(active ? fC : FLT_MAX);
+            mxC = wave_minmax<true>(active ? fC : -FLT_MAX);
+          }
+          if (lane == 0)
+          {
+            blk[b].mm[2] = mnB; blk[b].mm[3] = mxB; blk[b].mm[4] = mnC; blk[b].mm[5] = mxC;
+            blk[b].dirC[0] = dirC[0]; blk[b].dirC[1] = dirC[1]; blk[b].dirC[2] = dirC[2]; blk[b].dirC[3] = 0.0f;
+            if (zeroC) blk[b].flags |= kZeroC;
+          }
+        }
+      }
+      if (CH == 4)
+      {
+        // blocks that skipped phase C left stale pass-2 contributions in V; their dirC is never used (flags)
+        serial_sums(V, blk, 2, lane);
+        // ---- phase D: factor C extrema (pass 4).  Upstream never advances its estimate pointer in this loop
+        //      (src/limg_factorization.h:748-758), so every pixel is measured against pixel 0's A+B estimate.
+        for (int b = 0; b < kBlocksPerWave; b++)
+        {
+          uint32_t rx, n;
+          if (!geom(b, rx, n)) continue;
+          const uint32_t flags = (uint32_t)sgpr((int)blk[b].flags);
+          if (flags & (kZeroA | kZeroB)) continue;
+          float dirC[4], est0[4], pf[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) { dirC[c] = sgprf(blk[b].dirC[c]); est0[c] = sgprf(blk[b].est0[c]); }
+          const bool zeroC = (dirC[0] == 0.0f && dirC[1] == 0.0f && dirC[2] == 0.0f && dirC[3] == 0.0f);
+          if (zeroC)
+          {
+            if (lane == 0) blk[b].flags |= kZeroC;
+            continue;
+          }
+          load_px(b, rx, n, pf);
+          const bool active = (uint32_t)lane < n;
+          const float invC = 1.0f / dpps<CH>(dirC, dirC);
+          float l[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) l[c] = pf[c] - est0[c];
+          const float fC = dpps<CH>(l, dirC) * invC;
+          const float mnC = wave_minmax<false>(active ? fC : FLT_MAX);
+          const float mxC = wave_minmax<true>(active ? fC : -FLT_MAX);
+          if (lane == 0) { blk[b].mm[4] = mnC; blk[b].mm[5] = mxC; }
+        }
+      }
+      wave_lds_fence();
+
+      // ---- records (src/limg_factorization.h:764-790): 8 blocks x 24 values, one value per lane ---------------------
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+      {
+        const int idx = r * 64 + lane;
+        const int b = idx / 24, kc = idx - b * 24, k = kc >> 2, c = kc & 3;
+        const uint32_t flags = blk[b].flags;
+        const float *dir = k < 2 ? blk[b].dirA : (k < 4 ? blk[b].dirB : blk[b].dirC);
+        float m = blk[b].mm[k];
+        float dv = dir[c];
+        const bool dead = (k >= 4 && (flags & kZeroC)) || (k >= 2 && (flags & kZeroB)) || (flags & kZeroA);
+        if (dead) { m = 0.0f; dv = 0.0f; }
+        float val = m * dv;
+        if (k < 2) val = blk[b].avg[c] + val;
+        int q = cvt_rne(val);
+        if ((CH == 3 && c == 3) || !(flags & kValid)) q = 0;
+        blk[b].rec[kc] = (int16_t)q;
+      }
+      wave_lds_fence();
+      // colour-error state (src/limg_internal.h:426-452): 1 / |n|^2 per factor, serial limg_dot order
+      if (lane < 24)
+      {
+        const int b = lane / 3, f = lane - b * 3;
+        float s = 0.0f;
+        bool nz = false;
+#pragma unroll
+        for (int c = 0; c < CH; c++)
+        {
+          const float nrm = (float)((int)blk[b].rec[f * 8 + 4 + c] - (int)blk[b].rec[f * 8 + c]);
+          nz |= nrm != 0.0f;
+          s = s + nrm * nrm;
+        }
+        blk[b].invN[f] = nz ? 1.0f / s : 0.0f;
+      }
+      __syncthreads(); // all waves are done with V: wave 0's V region becomes the factor-byte staging area
+
+      uint8_t *stage = reinterpret_cast<uint8_t *>(s_V); // [3 planes][8 rows][256 px]
+      uint32_t waveCalls = 0;
+
+      // ---- phase E: per-pixel factors (a8) + shift search (a10-a12) ----------------------------------------------------
+      for (int b = 0; b < kBlocksPerWave; b++)
+      {
+        uint32_t rx, n;
+        if (!geom(b, rx, n)) continue;
+        const uint32_t sb = wave * kBlocksPerWave + b;
+        const uint32_t bx = strip * kStripBlocks + sb;
+        float pf[4];
+        const uint32_t px = load_px(b, rx, n, pf);
+        const bool active = (uint32_t)lane < n;
+
+        int rec[24];
+#pragma unroll
+        for (int i = 0; i < 24; i++) rec[i] = sgpr((int)blk[b].rec[i]);
+        const float invA = sgprf(blk[b].invN[0]), invB = sgprf(blk[b].invN[1]), invC = sgprf(blk[b].invN[2]);
+
+        uint32_t fA, fB, fC;
+        {
+          float nA[4], nB[4], nC[4], mnA[4], ofB[4], ofC[4], t[4], est[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++)
+          {
+            nA[c] = (float)(rec[4 + c] - rec[c]); nB[c] = (float)(rec[12 + c] - rec[8 + c]); nC[c] = (float)(rec[20 + c] - rec[16 + c]);
+            mnA[c] = (float)rec[c]; ofB[c] = (float)rec[8 + c]; ofC[c] = (float)rec[16 + c];
+          }
+#pragma unroll
+          for (int c = 0; c < 4; c++) t[c] = pf[c] - mnA[c];
+          const float fa = dpps<CH>(t, nA) * invA;
+          int q = cvt_rne(255.0f * fa); q = q < 255 ? q : 255; q = q > 0 ? q : 0; fA = (uint32_t)q;
+#pragma unroll
+          for (int c = 0; c < 4; c++) { est[c] = mnA[c] + nA[c] * fa; t[c] = (pf[c] - est[c]) - ofB[c]; }
+          const float fb = dpps<CH>(t, nB) * invB;
+          q = cvt_rne(255.0f * fb); q = q < 255 ? q : 255; q = q > 0 ? q : 0; fB = (uint32_t)q;
+#pragma unroll
+          for (int c = 0; c < 4; c++) { est[c] = est[c] + nB[c] * fb; t[c] = (pf[c] - est[c]) - ofC[c]; }
+          const float fc = dpps<CH>(t, nC) * invC;
+          q = cvt_rne(255.0f * fc); q = q < 255 ? q : 255; q = q > 0 ? q : 0; fC = (uint32_t)q;
+        }
+
+        uint32_t shift[3] = { 0, 0, 0 };
+        if (p.forced[0] >= 0)
+        {
+          shift[0] = (uint32_t)p.forced[0]; shift[1] = (uint32_t)p.forced[1]; shift[2] = (uint32_t)p.forced[2];
+        }
+        else if (p.crushBits)
+        {
+          RecU r;
+#pragma unroll
+          for (int c = 0; c < 3; c++)
+          {
+            r.nA[c] = rec[4 + c] - rec[c]; r.nB[c] = rec[12 + c] - rec[8 + c]; r.nC[c] = rec[20 + c] - rec[16 + c];
+            r.mA[c] = (int)(((uint32_t)rec[c] << 8) + 128u); r.mB[c] = (int)(((uint32_t)rec[8 + c] << 8) + 128u); r.mC[c] = (int)(((uint32_t)rec[16 + c] << 8) + 128u);
+          }
+          const uint64_t maxBlockN = p.maxBlock * (uint64_t)n;
+          auto T = [&](uint32_t a, uint32_t bb, uint32_t c, uint32_t &be) -> bool { return trial(px, fA, fB, fC, r, a, bb, c, active, p.maxPixel32, maxBlockN, be); };
+          if (p.fast) search_fast(T, shift);
+          else search_accurate(T, shift);
+        }
+
+        // dither calls this block will make (src/limg.cpp:1951-1958)
+        const uint32_t calls = (shift[0] && shift[0] != 8 ? 1u : 0u) + (shift[1] && shift[1] != 8 ? 1u : 0u) + (shift[2] && shift[2] != 8 ? 1u : 0u);
+        waveCalls += calls;
+
+        const size_t bi = (size_t)by * p.blocksX + bx;
+        if (lane == 0) p.shifts[bi] = shift[0] | (shift[1] << 8) | (shift[2] << 16) | (calls << 24);
+        if (p.records && lane < 16)
+        {
+          uint32_t w;
+          if (lane < 4) w = __float_as_uint(blk[b].avg[lane]);
+          else w = reinterpret_cast<const uint32_t *>(blk[b].rec)[lane - 4];
+          reinterpret_cast<uint32_t *>(p.records + bi)[lane] = w;
+        }
+        if (p.storePlanes && active)
+        {
+          uint32_t lx, ly;
+          if (rx == 8) { lx = lane & 7; ly = lane >> 3; }
+          else { ly = (uint32_t)lane / rx; lx = (uint32_t)lane - ly * rx; }
+          const uint32_t o = ly * 256 + sb * kBlock + lx;
+          stage[o] = (uint8_t)fA; stage[2048 + o] = (uint8_t)fB; stage[4096 + o] = (uint8_t)fC;
+        }
+      }
+      if (lane == 0) s_calls[wave] = waveCalls;
+      __syncthreads();
+      if (tid == 0) p.stripCalls[(size_t)by * p.stripsX + strip] = s_calls[0] + s_calls[1] + s_calls[2] + s_calls[3];
+
+      // ---- pre-dither factor bytes -> the caller's factor planes (rewritten in place by k_dither_store) -------------
+      if (p.storePlanes)
+      {
+        uint8_t *planes[3] = { p.info.pFactorsA, p.info.pFactorsB, p.info.pFactorsC };
+        if ((p.sizeX & 15u) == 0)
+        {
+          for (int i = tid; i < 384; i += kThreads)
+          {
+            const int pl = i >> 7, row = (i & 127) >> 4, col = (i & 15) * 16;
+            if ((uint32_t)row < ry && (uint32_t)col < stripW)
+              *reinterpret_cast<uint4 *>(planes[pl] + (size_t)(y0 + row) * p.sizeX + x0 + col) = *reinterpret_cast<const uint4 *>(stage + pl * 2048 + row * 256 + col);
+          }
+        }
+        else
+        {
+          for (int i = tid; i < 3 * 2048; i += kThreads)
+          {
+            const int pl = i >> 11, row = (i & 2047) >> 8, col = i & 255;
+            if ((uint32_t)row < ry && (uint32_t)col < stripW) planes[pl][(size_t)(y0 + row) * p.sizeX + x0 + col] = stage[i];
+          }
+        }
+      }
+    }
+
+    // =====================================================================================================================
+    // kernel 2: exclusive scan of the per-strip dither-call counts in raster order, restarting at every chain boundary
+    // =====================================================================================================================
+    __global__ __launch_bounds__(1024) void k_strip_scan(const EncodeParams p)
+    {
+      __shared__ uint32_t s_sum[1024];
+      __shared__ uint32_t s_flag[1024];
+      const uint32_t total = p.blocksY * p.stripsX;
+      const uint32_t per = (total + 1023u) / 1024u;
+      const uint32_t t = threadIdx.x;
+      const uint32_t begin = min(t * per, total), end = min(begin + per, total);
+      auto chain_of = [&](uint32_t e) -> uint32_t
+      {
+        const uint32_t row = e / p.stripsX;
+        if (p.chainCount <= 1 || p.chainRows == 0) return 0u;
+        const uint32_t c = row / p.chainRows;
+        return c < p.chainCount - 1 ? c : p.chainCount - 1;
+      };
+      auto is_head = [&](uint32_t e) -> bool { return e == 0 || chain_of(e) != chain_of(e - 1); };
+
+      uint32_t sum = 0, flag = 0;
+      for (uint32_t e = begin; e < end; e++)
+      {
+        if (is_head(e)) { sum = 0; flag = 1; }
+        sum += p.stripCalls[e];
+      }
+      s_sum[t] = sum; s_flag[t] = flag;
+      __syncthreads();
+      // segmented inclusive scan (Hillis-Steele) over the 1024 partials
+      for (uint32_t off = 1; off < 1024; off <<= 1)
+      {
+        uint32_t vs = s_sum[t], vf = s_flag[t];
+        if (t >= off && !vf) { vs += s_sum[t - off]; vf = s_flag[t - off]; }
+        __syncthreads();
+        s_sum[t] = vs; s_flag[t] = vf;
+        __syncthreads();
+      }
+      uint32_t run = (t == 0) ? 0u : s_sum[t - 1]; // calls in the current chain before this thread's chunk
+      for (uint32_t e = begin; e < end; e++)
+      {
+        if (is_head(e)) run = 0;
+        p.stripBase[e] = run;
+        run += p.stripCalls[e];
+      }
+    }
+
+    // =====================================================================================================================
+    // kernel 3: dither (a13), plane stores (a15), decode (a16)
+    // =====================================================================================================================
+    template <int CH>
+    __global__ __launch_bounds__(kThreads) void k_dither_store(const EncodeParams p)
+    {
+      __shared__ __attribute__((aligned(16))) uint8_t s_fac[3 * 8 * 256];       // pre-dither factor bytes of the strip
+      __shared__ __attribute__((aligned(16))) uint32_t s_dec[kWaves][8 * 64];   // decoded pixels, per wave [row][64]
+      __shared__ __attribute__((aligned(16))) uint8_t s_out[kWaves][3][8 * 64]; // output factor bytes, per wave [plane][row][64]
+      __shared__ uint32_t s_cst[7][kStripBlocks];                               // per-block constants of the 7 uniform planes
+      __shared__ uint32_t s_shift[kStripBlocks];
+      __shared__ uint32_t s_first[kStripBlocks];                                // first dither-call index of each block
+
+      const int tid = (int)threadIdx.x;
+      const int lane = tid & 63, wave = tid >> 6;
+      const uint32_t strip = blockIdx.x % p.stripsX, by = blockIdx.x / p.stripsX;
+      const uint32_t x0 = strip * (kStripBlocks * kBlock), y0 = by * kBlock;
+      const uint32_t stripW = min(p.sizeX - x0, (uint32_t)(kStripBlocks * kBlock));
+      const uint32_t ry = min(p.sizeY - y0, (uint32_t)kBlock);
+      const uint32_t nBlocks = min(p.blocksX - strip * kStripBlocks, (uint32_t)kStripBlocks);
+      const uint8_t *planesIn[3] = { p.info.pFactorsA, p.info.pFactorsB, p.info.pFactorsC };
+
+      if ((p.sizeX & 15u) == 0)
+      {
+        for (int i = tid; i < 384; i += kThreads)
+        {
+          const int pl = i >> 7, row = (i & 127) >> 4, col = (i & 15) * 16;
+          if ((uint32_t)row < ry && (uint32_t)col < stripW)
+            *reinterpret_cast<uint4 *>(s_fac + pl * 2048 + row * 256 + col) = *reinterpret_cast<const uint4 *>(planesIn[pl] + (size_t)(y0 + row) * p.sizeX + x0 + col);
+        }
+      }
+      else
+      {
+        for (int i = tid; i < 3 * 2048; i += kThreads)
+        {
+          const int pl = i >> 11, row = (i & 2047) >> 8, col = i & 255;
+          if ((uint32_t)row < ry && (uint32_t)col < stripW) s_fac[i] = planesIn[pl][(size_t)(y0 + row) * p.sizeX + x0 + col];
+        }
+      }
+      if (wave == 0)
+      {
+        // shifts + exclusive prefix of the calls of the strip's blocks (32 lanes)
+        uint32_t w = 0;
+        if ((uint32_t)lane < nBlocks) w = p.shifts[(size_t)by * p.blocksX + strip * kStripBlocks + lane];
+        const uint32_t calls = w >> 24;
+        uint32_t incl = calls;
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1)
+        {
+          const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+          if (lane >= off) incl += up;
+        }
+        if (lane < kStripBlocks)
+        {
+          s_shift[lane] = w;
+          s_first[lane] = p.stripBase[(size_t)by * p.stripsX + strip] + incl - calls;
+        }
+      }
+      __syncthreads();
+
+      for (int b = 0; b < kBlocksPerWave; b++)
+      {
+        const uint32_t sb = wave * kBlocksPerWave + b;
+        const uint32_t bx = strip * kStripBlocks + sb;
+        if (bx >= p.blocksX) continue;
+        const uint32_t rx = min(p.sizeX - bx * kBlock, (uint32_t)kBlock), n = rx * ry;
+        const bool active = (uint32_t)lane < n;
+        uint32_t lx, ly;
+        if (rx == 8) { lx = lane & 7; ly = lane >> 3; }
+        else { const uint32_t l = active ? (uint32_t)lane : 0u; ly = l / rx; lx = l - ly * rx; }
+        const uint32_t o = ly * 256 + sb * kBlock + lx;
+        const uint32_t w = (uint32_t)sgpr((int)s_shift[sb]);
+        const uint32_t shift[3] = { w & 0xFF, (w >> 8) & 0xFF, (w >> 16) & 0xFF };
+        uint32_t call = (uint32_t)sgpr((int)s_first[sb]);
+
+        uint32_t f[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+        {
+          uint32_t v = s_fac[k * 2048 + o];
+          const uint32_t s = shift[k];
+          if (s != 0 && s != 8)
+          { // src/limg.cpp:824-879: (lane16 & ditherSize) - ditherOffset, add, clamp, shift
+            const uint32_t nz = p.noise[(size_t)call * 64 + (active ? lane : 0)];
+            int t = (int)v + ((int)(nz & ((1u << s) - 1u)) - (int)(1u << (s - 1)));
+            t = t < 0 ? 0 : (t > 255 ? 255 : t);
+            v = (uint32_t)t >> s;
+            call++;
+          }
+          f[k] = v;
+        }
+
+        const limg_hip_block_record *rec = p.records + (size_t)by * p.blocksX + bx;
+        int r16[24];
+        {
+          const uint32_t *rw = reinterpret_cast<const uint32_t *>(rec) + 4;
+#pragma unroll
+          for (int i = 0; i < 12; i++)
+          {
+            const uint32_t d = (uint32_t)sgpr((int)rw[i]);
+            r16[2 * i] = (int)(int16_t)(d & 0xFFFF); r16[2 * i + 1] = (int)(int16_t)(d >> 16);
+          }
+        }
+        // decode, src/limg_decode.h:137-236 / :36-135
+        const uint32_t dA = f[0] * shift_mul(shift[0]), dB = f[1] * shift_mul(shift[1]), dC = f[2] * shift_mul(shift[2]);
+        uint32_t decoded = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+        {
+          int nA = r16[4 + c] - r16[c], nB = r16[12 + c] - r16[8 + c], nC = r16[20 + c] - r16[16 + c];
+          int mA = r16[c], mB = r16[8 + c], mC = r16[16 + c];
+          if (c < 3)
+          {
+            if (shift[0] > 7) nA = 0;
+            if (shift[1] > 7) { nB = 0; mB = 0; }
+            if (shift[2] > 7) { nC = 0; mC = 0; }
+          }
+          else if (CH == 3) { nA = nB = nC = 0; mA = mB = mC = 0xFFFF; }
+          int est = ((int)(dA * (uint32_t)nA + (((uint32_t)mA << 8) + 128u)) >> 8) + ((int)(dB * (uint32_t)nB + (((uint32_t)mB << 8) + 128u)) >> 8) +
+                    ((int)(dC * (uint32_t)nC + (((uint32_t)mC << 8) + 128u)) >> 8);
+          est = est < 0 ? 0 : (est > 255 ? 255 : est);
+          decoded |= (uint32_t)est << (8 * c);
+        }
+        if (active)
+        {
+          const uint32_t wo = ly * 64 + b * kBlock + lx;
+          s_dec[wave][wo] = decoded;
+#pragma unroll
+          for (int k = 0; k < 3; k++) s_out[wave][k][wo] = (uint8_t)(f[k] << shift[k]); // shift 8 => 0 (src/limg.cpp:2054-2062)
+        }
+        if (lane == 0)
+        {
+          const uint32_t pat[9] = { 0, 0x22, 0x44, 0x66, 0x88, 0xAA, 0xCC, 0xEE, 0xFF };
+          s_cst[0][sb] = 0xFF000000u | (pat[shift[0]] << 16) | (pat[shift[1]] << 8) | pat[shift[2]];
+        }
+        if (lane < 6)
+        { // colour planes, src/limg.cpp:2018-2036
+          uint32_t col = 0;
+#pragma unroll
+          for (int c = 0; c < CH; c++)
+          {
+            int v = r16[lane * 4 + c] + (lane >= 2 ? 0x80 : 0);
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            col |= (uint32_t)v << (8 * c);
+          }
+          if (CH == 3) col |= 0xFF000000u;
+          s_cst[1 + lane][sb] = col;
+        }
+      }
+      wave_lds_fence();
+
+      // ---- stores.  Each wave owns a 64-px wide column of the strip ----------------------------------------------------
+      const uint32_t wx0 = x0 + wave * 64;
+      if (wx0 < p.sizeX)
+      {
+        const uint32_t ww = min(p.sizeX - wx0, 64u);
+        uint32_t *planes32[8] = { p.info.pDecoded, p.info.pShiftABCX, p.info.pColAMin, p.info.pColAMax, p.info.pColBMin, p.info.pColBMax, p.info.pColCMin, p.info.pColCMax };
+        uint8_t *planes8[3] = { p.info.pFactorsA, p.info.pFactorsB, p.info.pFactorsC };
+        const bool in = (uint32_t)lane < ww;
+        uint32_t cst[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) cst[k] = s_cst[k][wave * kBlocksPerWave + (lane >> 3)];
+        for (uint32_t row = 0; row < ry; row++)
+        {
+          const size_t g = (size_t)(y0 + row) * p.sizeX + wx0 + lane;
+          if (in)
+          {
+            planes32[0][g] = s_dec[wave][row * 64 + lane];
+#pragma unroll
+            for (int k = 0; k < 7; k++) planes32[1 + k][g] = cst[k];
+          }
+        }
+        if ((p.sizeX & 3u) == 0)
+        { // 4 bytes per lane: lane -> (row = lane >> 4, 4-px chunk = lane & 15), two passes cover 8 rows
+#pragma unroll
+          for (int pass = 0; pass < 2; pass++)
+          {
+            const uint32_t row = pass * 4 + (lane >> 4), ch = (lane & 15) * 4;
+            if (row < ry && ch < ww)
+            {
+              const size_t g = (size_t)(y0 + row) * p.sizeX + wx0 + ch;
+#pragma unroll
+              for (int k = 0; k < 3; k++) *reinterpret_cast<uint32_t *>(planes8[k] + g) = *reinterpret_cast<const uint32_t *>(&s_out[wave][k][row * 64 + ch]);
+            }
+          }
+        }
+        else
+        {
+          for (uint32_t row = 0; row < ry; row++)
+            if (in)
+            {
+              const size_t g = (size_t)(y0 + row) * p.sizeX + wx0 + lane;
+#pragma unroll
+              for (int k = 0; k < 3; k++) planes8[k][g] = s_out[wave][k][row * 64 + lane];
+            }
+        }
+      }
+    }
+  } // namespace
+
+  void launch_fit_search(const EncodeParams &p, int channels, hipStream_t s)
+  {
+    const dim3 grid(p.stripsX * p.blocksY), block(kThreads);
+    if (channels == 4) hipLaunchKernelGGL(k_fit_search<4>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(k_fit_search<3>, grid, block, 0, s, p);
+  }
+
+  void launch_strip_scan(const EncodeParams &p, hipStream_t s) { hipLaunchKernelGGL(k_strip_scan, dim3(1), dim3(1024), 0, s, p); }
+
+  void launch_dither_store(const EncodeParams &p, int channels, hipStream_t s)
+  {
+    const dim3 grid(p.stripsX * p.blocksY), block(kThreads);
+    if (channels == 4) hipLaunchKernelGGL(k_dither_store<4>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(k_dither_store<3>, grid, block, 0, s, p);
+  }
+} // namespace limg_hip

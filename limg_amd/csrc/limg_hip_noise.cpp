@@ -1,0 +1,149 @@
+// limg_hip_noise.cpp -- host side of the dither chain (reference: src/limg.cpp:824-879 AES path, :799-822 PCG tail).
+//
+// The reference's dither PRNG state walk is independent of the image data and of the shift: the n-th dither call of a
+// chain starts from G^n(seed0) where G = "eight AESDEC rounds on {h, ~h}, keep the low 64 bits" for a full 8x8 block
+// (verified against the reference by tests/golden/chain.json).  So the noise every full block adds
+// is a constant stream: call k, pixel p -> the low byte of 16-bit lane (p & 7) of the state after round (p >> 3) + 1.
+// This file produces that stream (64 bytes per call) once per context; the kernels index it with the exclusive scan of
+// the per-block dither-call counts.  For images with partial edge blocks the chain depends on the data (G_N differs per
+// block size): `limg_hip_walk_chain` then evaluates it sequentially from the per-block call counts.
+//
+// Host-only translation unit (no HIP): uses AES-NI when the CPU has it, a T-table software round otherwise.
+#include <stdint.h>
+#include <string.h>
+#include <stddef.h>
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
+namespace limg_hip
+{
+  namespace
+  {
+    const uint8_t kInvSbox[256] = {
+      0x52, 0x09, 0x6a, 0xd5, 0x30, 0x36, 0xa5, 0x38, 0xbf, 0x40, 0xa3, 0x9e, 0x81, 0xf3, 0xd7, 0xfb, 0x7c, 0xe3, 0x39, 0x82, 0x9b, 0x2f, 0xff, 0x87, 0x34, 0x8e, 0x43, 0x44, 0xc4, 0xde, 0xe9, 0xcb,
+      0x54, 0x7b, 0x94, 0x32, 0xa6, 0xc2, 0x23, 0x3d, 0xee, 0x4c, 0x95, 0x0b, 0x42, 0xfa, 0xc3, 0x4e, 0x08, 0x2e, 0xa1, 0x66, 0x28, 0xd9, 0x24, 0xb2, 0x76, 0x5b, 0xa2, 0x49, 0x6d, 0x8b, 0xd1, 0x25,
+      0x72, 0xf8, 0xf6, 0x64, 0x86, 0x68, 0x98, 0x16, 0xd4, 0xa4, 0x5c, 0xcc, 0x5d, 0x65, 0xb6, 0x92, 0x6c, 0x70, 0x48, 0x50, 0xfd, 0xed, 0xb9, 0xda, 0x5e, 0x15, 0x46, 0x57, 0xa7, 0x8d, 0x9d, 0x84,
+      0x90, 0xd8, 0xab, 0x00, 0x8c, 0xbc, 0xd3, 0x0a, 0xf7, 0xe4, 0x58, 0x05, 0xb8, 0xb3, 0x45, 0x06, 0xd0, 0x2c, 0x1e, 0x8f, 0xca, 0x3f, 0x0f, 0x02, 0xc1, 0xaf, 0xbd, 0x03, 0x01, 0x13, 0x8a, 0x6b,
+      0x3a, 0x91, 0x11, 0x41, 0x4f, 0x67, 0xdc, 0xea, 0x97, 0xf2, 0xcf, 0xce, 0xf0, 0xb4, 0xe6, 0x73, 0x96, 0xac, 0x74, 0x22, 0xe7, 0xad, 0x35, 0x85, 0xe2, 0xf9, 0x37, 0xe8, 0x1c, 0x75, 0xdf, 0x6e,
+      0x47, 0xf1, 0x1a, 0x71, 0x1d, 0x29, 0xc5, 0x89, 0x6f, 0xb7, 0x62, 0x0e, 0xaa, 0x18, 0xbe, 0x1b, 0xfc, 0x56, 0x3e, 0x4b, 0xc6, 0xd2, 0x79, 0x20, 0x9a, 0xdb, 0xc0, 0xfe, 0x78, 0xcd, 0x5a, 0xf4,
+      0x1f, 0xdd, 0xa8, 0x33, 0x88, 0x07, 0xc7, 0x31, 0xb1, 0x12, 0x10, 0x59, 0x27, 0x80, 0xec, 0x5f, 0x60, 0x51, 0x7f, 0xa9, 0x19, 0xb5, 0x4a, 0x0d, 0x2d, 0xe5, 0x7a, 0x9f, 0x93, 0xc9, 0x9c, 0xef,
+      0xa0, 0xe0, 0x3b, 0x4d, 0xae, 0x2a, 0xf5, 0xb0, 0xc8, 0xeb, 0xbb, 0x3c, 0x83, 0x53, 0x99, 0x61, 0x17, 0x2b, 0x04, 0x7e, 0xba, 0x77, 0xd6, 0x26, 0xe1, 0x69, 0x14, 0x63, 0x55, 0x21, 0x0c, 0x7d
+    };
+
+    // round key of src/limg.cpp:837: _mm_set_epi64x(0x2A76E98006CB4CAD, 0x824A73EAAB705E1D), as four little-endian column words
+    const uint32_t kKey[4] = { 0xAB705E1Du, 0x824A73EAu, 0x06CB4CADu, 0x2A76E980u };
+
+    uint32_t g_td[4][256]; // Td_r[x]: InvMixColumns contribution of InvSubBytes(x) sitting in row r, as a little-endian column word
+    bool g_td_ready = false;
+
+    inline uint8_t xtime(uint8_t x) { return (uint8_t)((x << 1) ^ ((x >> 7) * 0x1B)); }
+
+    void build_tables()
+    {
+      if (g_td_ready) return;
+      for (int x = 0; x < 256; x++)
+      {
+        const uint8_t s = kInvSbox[x];
+        const uint8_t s2 = xtime(s), s4 = xtime(s2), s8 = xtime(s4);
+        const uint8_t m9 = (uint8_t)(s8 ^ s), m11 = (uint8_t)(s8 ^ s2 ^ s), m13 = (uint8_t)(s8 ^ s4 ^ s), m14 = (uint8_t)(s8 ^ s4 ^ s2);
+        // InvMixColumns matrix rows: [14 11 13 9; 9 14 11 13; 13 9 14 11; 11 13 9 14]; input row r feeds matrix column r
+        g_td[0][x] = (uint32_t)m14 | ((uint32_t)m9 << 8) | ((uint32_t)m13 << 16) | ((uint32_t)m11 << 24);
+        g_td[1][x] = (uint32_t)m11 | ((uint32_t)m14 << 8) | ((uint32_t)m9 << 16) | ((uint32_t)m13 << 24);
+        g_td[2][x] = (uint32_t)m13 | ((uint32_t)m11 << 8) | ((uint32_t)m14 << 16) | ((uint32_t)m9 << 24);
+        g_td[3][x] = (uint32_t)m9 | ((uint32_t)m13 << 8) | ((uint32_t)m11 << 16) | ((uint32_t)m14 << 24);
+      }
+      g_td_ready = true;
+    }
+
+    // AESDEC: InvShiftRows, InvSubBytes, InvMixColumns, xor round key.  State = 4 little-endian column words.
+    inline void aesdec_soft(uint32_t st[4])
+    {
+      uint32_t o[4];
+      for (int c = 0; c < 4; c++)
+      {
+        // output column c takes row r from input column (c - r) & 3
+        o[c] = g_td[0][st[c] & 0xFF] ^ g_td[1][(st[(c + 3) & 3] >> 8) & 0xFF] ^ g_td[2][(st[(c + 2) & 3] >> 16) & 0xFF] ^ g_td[3][(st[(c + 1) & 3] >> 24) & 0xFF] ^ kKey[c];
+      }
+      memcpy(st, o, 16);
+    }
+
+#if defined(__x86_64__)
+    __attribute__((target("aes,sse4.1"))) void walk_aesni(uint64_t &h, unsigned rounds, uint8_t *noise)
+    {
+      const __m128i key = _mm_set_epi64x(0x2A76E98006CB4CADLL, (long long)0x824A73EAAB705E1DULL);
+      const __m128i pick = _mm_set_epi8(-1, -1, -1, -1, -1, -1, -1, -1, 14, 12, 10, 8, 6, 4, 2, 0);
+      __m128i st = _mm_set_epi64x((long long)~h, (long long)h);
+      for (unsigned j = 0; j < rounds; j++)
+      {
+        st = _mm_aesdec_si128(st, key);
+        if (noise) _mm_storel_epi64(reinterpret_cast<__m128i *>(noise + 8 * j), _mm_shuffle_epi8(st, pick));
+      }
+      h = (uint64_t)_mm_cvtsi128_si64(st);
+    }
+#endif
+
+    void walk_soft(uint64_t &h, unsigned rounds, uint8_t *noise)
+    {
+      build_tables();
+      uint32_t st[4];
+      const uint64_t inv = ~h;
+      memcpy(st, &h, 8);
+      memcpy(st + 2, &inv, 8);
+      for (unsigned j = 0; j < rounds; j++)
+      {
+        aesdec_soft(st);
+        if (noise)
+          for (int i = 0; i < 8; i++) noise[8 * j + i] = (uint8_t)(st[i >> 1] >> (16 * (i & 1)));
+      }
+      memcpy(&h, st, 8);
+    }
+
+    bool have_aesni()
+    {
+#if defined(__x86_64__)
+      static const bool v = __builtin_cpu_supports("aes") && __builtin_cpu_supports("sse4.1");
+      return v;
+#else
+      return false;
+#endif
+    }
+
+    inline uint32_t pcg_step(uint64_t &h)
+    { // src/limg.cpp:866-871
+      h = h * 6364136223846793005ULL + 1;
+      const uint32_t xorshifted_hi = (uint32_t)(((h >> 18) ^ h) >> 27);
+      const uint32_t rot_hi = (uint32_t)(h >> 59);
+      return (xorshifted_hi >> rot_hi) | (xorshifted_hi << ((uint32_t)(-(int32_t)rot_hi) & 31));
+    }
+  }
+
+  // One dither call over `n` pixels starting from chain value `h`: writes n noise bytes (padded to 64), returns G_n(h).
+  uint64_t chain_call(uint64_t h, unsigned n, uint8_t *noise64, bool forceSoft)
+  {
+    const unsigned rounds = n >= 8 ? n / 8 : 0;
+    if (rounds)
+    {
+#if defined(__x86_64__)
+      if (have_aesni() && !forceSoft) walk_aesni(h, rounds, noise64);
+      else
+#endif
+        walk_soft(h, rounds, noise64);
+    }
+    for (unsigned i = rounds * 8; i < n; i++)
+    {
+      const uint32_t r = pcg_step(h);
+      if (noise64) noise64[i] = (uint8_t)r;
+    }
+    return h;
+  }
+
+  // Static table for chains made of full 8x8 blocks only: entries [first, first + count) given the chain value at `first`.
+  // Returns the chain value after the last generated entry (so the table can be grown later).
+  uint64_t fill_noise_table(uint64_t h, uint8_t *noise, size_t count)
+  {
+    for (size_t k = 0; k < count; k++) h = chain_call(h, 64, noise + k * 64, false);
+    return h;
+  }
+}
