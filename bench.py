@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py -- limg encode hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W         (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path over one image: `limg_encode3d_test`-equivalent work (fit, factors, shift search,
+dither, all 11 planes stored, decode) through the C ABI of liblimg_hip.so, input already resident in HBM.
+Workload at every N: BASELINE.json configs[2], a synthetic 8192x8192 RGBA photo-noise image per GPU (seed = 1 + rank;
+the metric is quoted on "8K RGBA"), errorFactor 100, fast bit crushing, single dither chain.  Images are independent,
+so N GPUs encode N images with no data-path collective ("weak" scaling); the only torch.distributed traffic is the
+barrier and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the whole encode (its three kernel launches together) against the HBM
+roofline with the algorithmic 39 B/px of SURVEY.md 8(d): achieved = 39 B * pixels / (sum of the three kernels' average
+durations, HIP events on the launch stream inside the timed region); per-kernel times are in `roofline.kernels_ms`.
+`cpu_baseline` times the real reference (oracle/_ref, kind "reference") -- or, where that build is absent, the CPU
+oracle (kind "port") -- on a bounded band of the same image on this host's cores (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_PX = 39          # 4 B read + 35 B written (plane-compatible mode)
+HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(width, seed, budget_s=25.0):
+    """Real reference (or oracle port) on a band of the bench image; returns the dict for the JSON line."""
+    import numpy as np
+    from oracle.bind import Oracle, Ref, ref_available
+    orc = Oracle()
+    rows = 1024
+    band = orc.photo_noise(width, rows, seed)  # the first `rows` rows of the bench image (the generator is row-local)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    out = {}
+    if ref_available():
+        ref = Ref()
+        kind = "reference"
+
+        def run(pool):
+            t = time.perf_counter()
+            ref.encode3d(band, True, error_factor=100, pool_threads=pool)
+            return time.perf_counter() - t
+    else:
+        kind = "port"
+
+        def run(pool):
+            t = time.perf_counter()
+            orc.encode3d(band, True, error_factor=100, pool_threads=pool, worker_threads=max(pool, 1))
+            return time.perf_counter() - t
+    t1 = run(0)                      # single thread, single dither chain (== pThreadPool nullptr)
+    reps = max(1, min(5, int((budget_s * 0.4) / max(t1, 1e-3))))
+    tn = min(run(cores) for _ in range(reps))  # pool of `cores` threads (cores*4 strips), the reference's own threaded mode
+    px = width * rows
+    out = {"value": round(px / tn / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": kind,
+           "sample": "first %d rows (%dx%d, %.1f Mpx) of the bench image, limg_encode3d_test-equivalent (all planes + decode), "
+                     "thread pool of %d; single-thread: %.2f Mpixels/s" % (rows, width, rows, px / 1e6, cores, px / t1 / 1e6)}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=8192)
+    ap.add_argument("--workload", default="photo_noise", choices=["photo_noise", "random_gradient"])
+    ap.add_argument("--error-factor", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import numpy as np
+    import limg_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    n_gpus = max(world, 1)
+    if args.gpus != n_gpus and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    W = H = args.size
+    g = limg_amd.LimgHip(local_rank if world > 1 else 0)
+    img = g.synth_device(args.workload, W, H, seed=1 + rank)
+    planes = g.alloc_planes_device(W, H)
+    torch.cuda.synchronize()
+
+    def step():
+        g.encode3d_device(img, True, planes, error_factor=args.error_factor, pool_threads=0, fast=True)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    g.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernels = g.profile_end(args.steps)
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    torch.cuda.synchronize()
+
+    px = W * H
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = n_gpus * px * args.steps / elapsed / 1e6
+    psnr, _ = g.compare_device(img, planes["pDecoded"], True)
+
+    if rank == 0:
+        kavg = kernels.mean(axis=0) if len(kernels) else np.zeros(3)
+        ksum = float(kavg.sum())
+        achieved = ALGO_BYTES_PER_PX * px / (ksum * 1e-3) / 1e9 if ksum > 0 else 0.0
+        line = {
+            "metric": "encode Mpixels/s, 8K RGBA (limg_encode3d_test-equivalent: all 11 planes stored)",
+            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/i32 integer stage + f32 float stage (bit-exact vs the reference's strict SSE build)", "data": "synthetic",
+            "config": {"workload": "synthetic %dx%d RGBA %s (seed 1+rank) per GPU, errorFactor %d, fast bit-crush, single dither chain"
+                                   % (W, H, args.workload, args.error_factor),
+                       "images_per_step": n_gpus, "parallelism": "independent image per GPU, no data-path collective", "psnr_db": round(psnr, 4)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": None, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PX * px,
+                         "kernels_ms": {"k_fit_search": round(float(kavg[0]), 4), "k_strip_scan": round(float(kavg[1]), 4), "k_dither_store": round(float(kavg[2]), 4)},
+                         "note": "whole encode = 3 launches; achieved = 39 B/px * pixels / sum of the three average kernel durations (HIP events)"},
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(W, 1)
+            except Exception as e:  # the checker must never sink the measurement
+                line["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(line), flush=True)
+    g.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

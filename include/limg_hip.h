@@ -100,6 +100,12 @@ double limg_hip_compare_device(limg_hip_context *pCtx, const uint32_t *pImageA, 
 limg_hip_result limg_hip_synth_random_gradient_device(uint32_t *pOut, size_t width, size_t height, uint64_t seed, int opaque, size_t y0, void *stream);
 limg_hip_result limg_hip_synth_photo_noise_device(uint32_t *pOut, size_t width, size_t height, uint64_t seed, size_t y0, void *stream);
 
+/* Per-kernel timing for the bench (HIP events recorded on the stream each profiled encode is launched on).
+ * limg_hip_profile_end writes 3 floats per profiled encode: k_fit_search, k_strip_scan (or the host chain walk of ragged
+ * images), k_dither_store, in milliseconds; returns the number of encodes written or -1. */
+limg_hip_result limg_hip_profile_begin(limg_hip_context *pCtx);
+int limg_hip_profile_end(limg_hip_context *pCtx, float *pMs, int maxEncodes);
+
 /* Introspection for the bench: names and launch count of the kernels one encode enqueues, bytes of context-owned HBM. */
 size_t limg_hip_context_device_bytes(const limg_hip_context *pCtx);
 const char *limg_hip_version(void);

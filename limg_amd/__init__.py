@@ -20,7 +20,7 @@ PLANES = P32 + P8
 ABI_SYMBOLS = (
     "limg_hip_init", "limg_hip_shutdown", "limg_hip_default_options", "limg_hip_set_options", "limg_hip_encode3d", "limg_hip_encode3d_perf",
     "limg_hip_encode3d_device", "limg_hip_compare", "limg_hip_compare_device", "limg_hip_synth_random_gradient_device",
-    "limg_hip_synth_photo_noise_device", "limg_hip_context_device_bytes", "limg_hip_version",
+    "limg_hip_synth_photo_noise_device", "limg_hip_context_device_bytes", "limg_hip_version", "limg_hip_profile_begin", "limg_hip_profile_end",
 )
 
 RECORD_DTYPE = np.dtype([("avg", "<f4", 4), ("dirA_min", "<i2", 4), ("dirA_max", "<i2", 4), ("dirB_offset", "<i2", 4),
@@ -76,6 +76,10 @@ def load_library(path=None):
     L.limg_hip_synth_random_gradient_device.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint64, C.c_int, C.c_size_t, C.c_void_p]
     L.limg_hip_synth_photo_noise_device.restype = C.c_int
     L.limg_hip_synth_photo_noise_device.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint64, C.c_size_t, C.c_void_p]
+    L.limg_hip_profile_begin.restype = C.c_int
+    L.limg_hip_profile_begin.argtypes = [C.c_void_p]
+    L.limg_hip_profile_end.restype = C.c_int
+    L.limg_hip_profile_end.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.limg_hip_context_device_bytes.restype = C.c_size_t
     L.limg_hip_context_device_bytes.argtypes = [C.c_void_p]
     return L
@@ -180,6 +184,17 @@ class LimgHip:
         else:
             raise ValueError(kind)
         return out
+
+    def profile_begin(self):
+        _check(self.lib.limg_hip_profile_begin(self.ctx), "limg_hip_profile_begin")
+
+    def profile_end(self, max_encodes=4096):
+        """-> float32 array (n, 3): per profiled encode the milliseconds of k_fit_search, k_strip_scan, k_dither_store."""
+        buf = np.zeros((max_encodes, 3), dtype=np.float32)
+        n = self.lib.limg_hip_profile_end(self.ctx, _np_ptr(buf), max_encodes)
+        if n < 0:
+            raise LimgHipError("limg_hip_profile_end failed")
+        return buf[:n]
 
     def device_bytes(self):
         return self.lib.limg_hip_context_device_bytes(self.ctx)

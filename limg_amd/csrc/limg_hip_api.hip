@@ -55,6 +55,10 @@ struct limg_hip_context
   DevBuf noiseDyn;                               // data-dependent chains (images with partial blocks)
   DevBuf in, planes;                             // staging for the host-pointer entry points
   DevBuf cmp;                                    // 8-byte accumulator of limg_hip_compare
+  // optional per-kernel timing (bench): 4 events per encode, recorded on the caller's stream, read back in one go
+  bool profiling = false;
+  std::vector<hipEvent_t> events;
+  size_t eventsUsed = 0;
 };
 
 namespace
@@ -76,6 +80,18 @@ namespace
     c->noiseCount = want;
     c->noiseNext = h;
     return limg_hip_success;
+  }
+
+  void mark(limg_hip_context *c, hipStream_t stream)
+  {
+    if (!c->profiling) return;
+    if (c->eventsUsed == c->events.size())
+    {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return;
+      c->events.push_back(e);
+    }
+    (void)hipEventRecord(c->events[c->eventsUsed++], stream);
   }
 
   struct Partition { uint32_t chainCount, chainRows; };
@@ -160,9 +176,12 @@ namespace
       p.noise = (const uint8_t *)c->noise.p;
     }
 
+    mark(c, stream);
     launch_fit_search(p, channels, stream);
+    mark(c, stream);
     if (!dInfo)
     {
+      mark(c, stream); mark(c, stream);
       HIP_TRY(hipGetLastError());
       return limg_hip_success; // `_perf` behaviour: nothing to dither into, nothing to store
     }
@@ -201,7 +220,9 @@ namespace
       HIP_TRY(hipStreamSynchronize(stream)); // the host vectors die with this scope
       p.noise = (const uint8_t *)c->noiseDyn.p;
     }
+    mark(c, stream);
     launch_dither_store(p, channels, stream);
+    mark(c, stream);
     HIP_TRY(hipGetLastError());
     return limg_hip_success;
   }
@@ -247,6 +268,7 @@ extern "C"
     (void)hipDeviceSynchronize();
     DevBuf *bufs[] = { &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->in, &c->planes, &c->cmp };
     for (DevBuf *b : bufs) b->release();
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     delete c;
     *ppCtx = nullptr;
   }
@@ -256,6 +278,32 @@ extern "C"
     if (!c || !o) return limg_hip_error_ArgumentNull;
     c->opt = *o;
     return limg_hip_success;
+  }
+
+  limg_hip_result limg_hip_profile_begin(limg_hip_context *c)
+  {
+    if (!c) return limg_hip_error_ArgumentNull;
+    c->profiling = true;
+    c->eventsUsed = 0;
+    return limg_hip_success;
+  }
+
+  // Stops profiling, waits for the recorded work and writes, per profiled encode, {fit_search, scan (+ host chain walk for ragged
+  // images), dither_store} milliseconds into pMs[3 * i ...].  Returns the number of encodes written (<= maxEncodes), or -1.
+  int limg_hip_profile_end(limg_hip_context *c, float *pMs, int maxEncodes)
+  {
+    if (!c || !pMs) return -1;
+    c->profiling = false;
+    const int n = (int)(c->eventsUsed / 4);
+    int written = 0;
+    for (int i = 0; i < n && i < maxEncodes; i++, written++)
+    {
+      if (hipEventSynchronize(c->events[4 * i + 3]) != hipSuccess) return -1;
+      for (int k = 0; k < 3; k++)
+        if (hipEventElapsedTime(&pMs[3 * i + k], c->events[4 * i + k], c->events[4 * i + k + 1]) != hipSuccess) return -1;
+    }
+    c->eventsUsed = 0;
+    return written;
   }
 
   size_t limg_hip_context_device_bytes(const limg_hip_context *c)

@@ -205,6 +205,85 @@ namespace limg_hip
       return !any_fail && ((uint64_t)be * 16ull < maxBlockN);
     }
 
+    // ---- a9, packed form ------------------------------------------------------------------------------------------------
+    // Same integers as `trial` above, arranged for gfx950's packed 16-bit VALU:
+    //  * per factor X the three RGB terms  tXc = (decX * nX[c] + (minX[c] << 8) + 128) >> 8  are kept between trials
+    //    (R,G packed in one VGPR, B in another) and only recomputed when that factor's shift changes -- the stepwise search
+    //    mostly moves one shift at a time;
+    //  * px - clamp(S, 0, 255) == clamp(px - S, px - 255, px), so the clamp and the difference are v_pk_max/min against
+    //    per-pixel bounds prepared once per block;
+    //  * the weighted squared error is one v_dot2_u32_u16.
+    // The R term of every factor carries a +0x2000 bias (folded into the additive constant, so it costs nothing) which keeps
+    // the low halves positive: the three packed terms can then be summed with one plain 32-bit add3 without a borrow reaching
+    // the G half.  Valid while every record value is small (|v| <= 8000, far above what a fit of byte pixels can produce:
+    // |A| <= 765, |B| <= 1020, |C| <= 2040); phase E falls back to the generic 32-bit form otherwise.
+    typedef short short2_t __attribute__((ext_vector_type(2)));
+    typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+    constexpr int kTermBias = 0x2000;
+    constexpr int kRecordLimit = 8000;
+
+    struct TrialState
+    {
+      // per pixel, fixed for the block
+      uint32_t fA, fB, fC;
+      uint32_t pxRGb; // (R + 3 * bias) | G << 16
+      uint32_t loRG, hiRG;
+      int pxB;
+      // wave-uniform record view: n* scalars, m* = (min << 8) + 128 (+ bias << 8 for R)
+      int nA[3], nB[3], nC[3];
+      int mA[3], mB[3], mC[3];
+      // cached terms and the shifts they were built for
+      uint32_t tA_RG, tB_RG, tC_RG;
+      int tA_B, tB_B, tC_B;
+      uint32_t cA, cB, cC;
+    };
+
+    __device__ __forceinline__ void make_terms(const uint32_t f, const uint32_t s, const int n[3], const int m[3], uint32_t &tRG, int &tB)
+    {
+      const int d = (int)__umul24(f >> s, shift_mul(s)); // <= 255 * 256
+      const int t0 = __mul24(d, n[0]) + m[0], t1 = __mul24(d, n[1]) + m[1], t2 = __mul24(d, n[2]) + m[2];
+      tRG = __builtin_amdgcn_perm((uint32_t)t1, (uint32_t)t0, 0x06050201u); // ((t1 >> 8) & 0xFFFF) << 16 | ((t0 >> 8) & 0xFFFF)
+      tB = t2 >> 8;
+    }
+
+    template <bool FULL>
+    __device__ __forceinline__ bool trial_packed(TrialState &t, const uint32_t sA, const uint32_t sB, const uint32_t sC, const bool active,
+                                                 const uint32_t maxPixel32, const uint32_t blockLimit, uint32_t &blockError)
+    {
+      if (sA != t.cA) { make_terms(t.fA, sA, t.nA, t.mA, t.tA_RG, t.tA_B); t.cA = sA; } // shift 8: f >> 8 == 0 => term == minA, as upstream
+      if (sB != t.cB)
+      {
+        if (sB > 7) { t.tB_RG = (uint32_t)kTermBias; t.tB_B = 0; } // upstream zeroes minB / minC too (src/limg_bit_crush_simd.h:593-609)
+        else make_terms(t.fB, sB, t.nB, t.mB, t.tB_RG, t.tB_B);
+        t.cB = sB;
+      }
+      if (sC != t.cC)
+      {
+        if (sC > 7) { t.tC_RG = (uint32_t)kTermBias; t.tC_B = 0; }
+        else make_terms(t.fC, sC, t.nC, t.mC, t.tC_RG, t.tC_B);
+        t.cC = sC;
+      }
+      const uint32_t estRG = t.tA_RG + t.tB_RG + t.tC_RG; // low half: R estimate + 3 * bias; no carry / borrow crosses the halves
+      const int estB = t.tA_B + t.tB_B + t.tC_B;
+      short2_t e = __builtin_bit_cast(short2_t, t.pxRGb) - __builtin_bit_cast(short2_t, estRG);
+      e = __builtin_elementwise_max(e, __builtin_bit_cast(short2_t, t.loRG));
+      e = __builtin_elementwise_min(e, __builtin_bit_cast(short2_t, t.hiRG));
+      int dB = t.pxB - estB;
+      dB = dB > t.pxB - 255 ? dB : t.pxB - 255;
+      dB = dB < t.pxB ? dB : t.pxB;
+      const ushort2_t eu = __builtin_bit_cast(ushort2_t, e);
+      const ushort2_t sq = eu * eu; // d^2 <= 65025 fits 16 bits; (-d)^2 mod 2^16 == d^2
+      const uint32_t sqB = (uint32_t)__mul24(dB, dB);
+      const bool low_red = sq.x < 0x4000;
+      const uint32_t wRG = low_red ? 0x00040002u : 0x00040003u;
+      uint32_t err = __builtin_amdgcn_udot2(sq, __builtin_bit_cast(ushort2_t, wRG), __umul24(sqB, low_red ? 3u : 2u), false);
+      if (!FULL) err = active ? err : 0u;
+      if (__builtin_amdgcn_ballot_w64(err > maxPixel32) != 0ull) return false;
+      const uint32_t be = wave_sum(err);
+      blockError = be;
+      return be < blockLimit; // be * 16 < maxBlock * n, see phase E
+    }
+
     // a10-a12 search driver; everything in here is wave-uniform
     template <typename TRY>
     __device__ __forceinline__ void search_fast(TRY &&T, uint32_t shift[3])
@@ -661,17 +740,57 @@ namespace limg_hip
         }
         else if (p.crushBits)
         {
-          RecU r;
-#pragma unroll
-          for (int c = 0; c < 3; c++)
-          {
-            r.nA[c] = rec[4 + c] - rec[c]; r.nB[c] = rec[12 + c] - rec[8 + c]; r.nC[c] = rec[20 + c] - rec[16 + c];
-            r.mA[c] = (int)(((uint32_t)rec[c] << 8) + 128u); r.mB[c] = (int)(((uint32_t)rec[8 + c] << 8) + 128u); r.mC[c] = (int)(((uint32_t)rec[16 + c] << 8) + 128u);
-          }
           const uint64_t maxBlockN = p.maxBlock * (uint64_t)n;
-          auto T = [&](uint32_t a, uint32_t bb, uint32_t c, uint32_t &be) -> bool { return trial(px, fA, fB, fC, r, a, bb, c, active, p.maxPixel32, maxBlockN, be); };
-          if (p.fast) search_fast(T, shift);
-          else search_accurate(T, shift);
+          // be * 16 < maxBlock * n  <=>  be < ceil(maxBlock * n / 16); clamped to 32 bits (be itself never gets near 2^32)
+          const uint64_t lim64 = (maxBlockN + 15ull) >> 4;
+          const uint32_t blockLimit = (uint32_t)sgpr((int)(lim64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)lim64));
+          int big = 0;
+#pragma unroll
+          for (int i = 0; i < 24; i++) big |= (rec[i] > kRecordLimit || rec[i] < -kRecordLimit) ? 1 : 0;
+          if (!big)
+          {
+            TrialState t;
+            t.fA = fA; t.fB = fB; t.fC = fC;
+            const uint32_t R = px & 0xFF, G = (px >> 8) & 0xFF;
+            t.pxRGb = (R + 3u * kTermBias) | (G << 16);
+            t.hiRG = R | (G << 16);
+            t.loRG = ((R - 255u) & 0xFFFFu) | ((G - 255u) << 16);
+            t.pxB = (int)((px >> 16) & 0xFF);
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+            {
+              const int bias = c == 0 ? (kTermBias << 8) : 0;
+              t.nA[c] = rec[4 + c] - rec[c]; t.nB[c] = rec[12 + c] - rec[8 + c]; t.nC[c] = rec[20 + c] - rec[16 + c];
+              t.mA[c] = (rec[c] << 8) + 128 + bias; t.mB[c] = (rec[8 + c] << 8) + 128 + bias; t.mC[c] = (rec[16 + c] << 8) + 128 + bias;
+            }
+            t.cA = t.cB = t.cC = 0xFFu;
+            t.tA_RG = t.tB_RG = t.tC_RG = 0; t.tA_B = t.tB_B = t.tC_B = 0;
+            if (n == 64)
+            {
+              auto T = [&](uint32_t a, uint32_t bb, uint32_t c, uint32_t &be) -> bool { return trial_packed<true>(t, a, bb, c, true, p.maxPixel32, blockLimit, be); };
+              if (p.fast) search_fast(T, shift);
+              else search_accurate(T, shift);
+            }
+            else
+            {
+              auto T = [&](uint32_t a, uint32_t bb, uint32_t c, uint32_t &be) -> bool { return trial_packed<false>(t, a, bb, c, active, p.maxPixel32, blockLimit, be); };
+              if (p.fast) search_fast(T, shift);
+              else search_accurate(T, shift);
+            }
+          }
+          else
+          {
+            RecU r;
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+            {
+              r.nA[c] = rec[4 + c] - rec[c]; r.nB[c] = rec[12 + c] - rec[8 + c]; r.nC[c] = rec[20 + c] - rec[16 + c];
+              r.mA[c] = (int)(((uint32_t)rec[c] << 8) + 128u); r.mB[c] = (int)(((uint32_t)rec[8 + c] << 8) + 128u); r.mC[c] = (int)(((uint32_t)rec[16 + c] << 8) + 128u);
+            }
+            auto T = [&](uint32_t a, uint32_t bb, uint32_t c, uint32_t &be) -> bool { return trial(px, fA, fB, fC, r, a, bb, c, active, p.maxPixel32, maxBlockN, be); };
+            if (p.fast) search_fast(T, shift);
+            else search_accurate(T, shift);
+          }
         }
 
         // dither calls this block will make (src/limg.cpp:1951-1958)
