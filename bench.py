@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--workload", default="photo_noise", choices=["photo_noise", "random_gradient"])
     ap.add_argument("--error-factor", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--forced-shift", type=int, default=-1, help="bypass the shift search with this shift on all three factors (bit-crush sweep)")
     args = ap.parse_args()
 
     import torch
@@ -100,6 +101,8 @@ def main():
 
     W = H = args.size
     g = limg_amd.LimgHip(local_rank if world > 1 else 0)
+    if args.forced_shift >= 0:
+        g.set_forced_shift((args.forced_shift,) * 3)
     img = g.synth_device(args.workload, W, H, seed=1 + rank)
     planes = g.alloc_planes_device(W, H)
     torch.cuda.synchronize()
@@ -142,7 +145,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/i32 integer stage + f32 float stage (bit-exact vs the reference's strict SSE build)", "data": "synthetic",
             "config": {"workload": "synthetic %dx%d RGBA %s (seed 1+rank) per GPU, errorFactor %d, fast bit-crush, single dither chain"
-                                   % (W, H, args.workload, args.error_factor),
+                                   % (W, H, args.workload, args.error_factor) + ("" if args.forced_shift < 0 else ", forced shift %d" % args.forced_shift),
                        "images_per_step": n_gpus, "parallelism": "independent image per GPU, no data-path collective", "psnr_db": round(psnr, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": None, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PX * px,

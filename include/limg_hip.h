@@ -106,6 +106,16 @@ limg_hip_result limg_hip_synth_photo_noise_device(uint32_t *pOut, size_t width, 
 limg_hip_result limg_hip_profile_begin(limg_hip_context *pCtx);
 int limg_hip_profile_end(limg_hip_context *pCtx, float *pMs, int maxEncodes);
 
+/* Host-only helpers (no GPU touched): the data-independent dither noise stream and the strip partition rule.
+ *  limg_hip_host_noise_table : `calls` x 64 noise bytes of a chain of full 8x8 blocks starting at the reference's seed
+ *                              (src/limg.cpp:1893); byte p of call k is what the AES dither ANDs with ditherSize for pixel p.
+ *  limg_hip_host_chain_call  : one dither call's state walk over `pixelCount` (<= 64) pixels: returns the next chain value
+ *                              (src/limg.cpp:824-879), optionally writing the noise bytes (64-byte buffer).
+ *  limg_hip_host_partition   : src/limg.cpp:2114-2134 in block rows: chain c < count-1 owns rows [c*rows, (c+1)*rows), the last the rest. */
+limg_hip_result limg_hip_host_noise_table(uint8_t *pOut, size_t calls);
+uint64_t limg_hip_host_chain_call(uint64_t chainValue, size_t pixelCount, uint8_t *pNoise64, int forceSoftwareAes);
+limg_hip_result limg_hip_host_partition(size_t sizeY, int poolThreads, uint32_t *pChainCount, uint32_t *pChainBlockRows);
+
 /* Introspection for the bench: names and launch count of the kernels one encode enqueues, bytes of context-owned HBM. */
 size_t limg_hip_context_device_bytes(const limg_hip_context *pCtx);
 const char *limg_hip_version(void);

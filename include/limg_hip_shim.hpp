@@ -1,0 +1,74 @@
+// limg_hip_shim.hpp -- header-only C++ shim that re-exposes the reference's own signatures (src/limg.h:27-48) on top of
+// the C ABI of liblimg_hip.so, so a caller written against limg.h (e.g. src/main.cpp:282-332) relinks unchanged:
+//
+//     #include "limg_hip_shim.hpp"      // instead of "limg.h"
+//     limg_encode3d_test(pIn, sizeX, sizeY, hasAlpha, &info, errorFactor, pThreadPool, fastBitCrushing);
+//
+// The reference's thread pool only matters for its dither-chain partition (one chain per row strip, src/limg.cpp:2114-2134):
+// the shim carries the thread count in an opaque `limg_thread_pool` so the GPU reproduces the same partition.
+#ifndef LIMG_HIP_SHIM_HPP
+#define LIMG_HIP_SHIM_HPP
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "limg_hip.h"
+
+enum limg_result
+{
+  limg_success = 0,
+  limg_error_Generic = 100,
+  limg_error_InvalidParameter,
+  limg_error_ArgumentNull,
+  limg_error_OutOfBounds,
+  limg_error_MemoryAllocationFailure,
+};
+
+struct limg_thread_pool { size_t threads; };
+inline limg_thread_pool *limg_thread_pool_new(const size_t threads) { return new limg_thread_pool{ threads }; }
+inline void limg_thread_pool_destroy(limg_thread_pool **pp) { if (pp && *pp) { delete *pp; *pp = nullptr; } }
+inline size_t limg_thread_pool_thread_count(limg_thread_pool *p) { return p ? p->threads : 0; }
+
+struct limg_encode3d_info
+{
+  uint32_t *pDecoded, *pShiftABCX, *pColAMin, *pColAMax, *pColBMin, *pColBMax, *pColCMin, *pColCMax;
+  uint8_t *pFactorsA, *pFactorsB, *pFactorsC;
+};
+
+namespace limg_hip_shim
+{
+  inline limg_hip_context *context()
+  {
+    static limg_hip_context *ctx = nullptr;
+    if (!ctx && limg_hip_init(-1, &ctx) != limg_hip_success) ctx = nullptr;
+    return ctx;
+  }
+}
+
+inline limg_result limg_encode3d_test(const uint32_t *pIn, const size_t sizeX, const size_t sizeY, const bool hasAlpha, limg_encode3d_info *pInfo, const uint32_t errorFactor,
+                                      limg_thread_pool *pThreadPool, const bool fastBitCrushing)
+{
+  static_assert(sizeof(limg_encode3d_info) == sizeof(limg_hip_encode3d_info), "layout");
+  limg_hip_context *c = limg_hip_shim::context();
+  if (!c) return limg_error_Generic;
+  return (limg_result)limg_hip_encode3d(c, pIn, sizeX, sizeY, hasAlpha ? 1 : 0, reinterpret_cast<limg_hip_encode3d_info *>(pInfo), errorFactor,
+                                        pThreadPool ? (int)pThreadPool->threads : 0, fastBitCrushing ? 1 : 0);
+}
+
+inline limg_result limg_encode3d_test_perf(const uint32_t *pIn, const size_t sizeX, const size_t sizeY, const bool hasAlpha, const uint32_t errorFactor, limg_thread_pool *pThreadPool,
+                                           const bool fastBitCrushing)
+{
+  limg_hip_context *c = limg_hip_shim::context();
+  if (!c) return limg_error_Generic;
+  return (limg_result)limg_hip_encode3d_perf(c, pIn, sizeX, sizeY, hasAlpha ? 1 : 0, errorFactor, pThreadPool ? (int)pThreadPool->threads : 0, fastBitCrushing ? 1 : 0);
+}
+
+inline double limg_compare(const uint32_t *pImageA, const uint32_t *pImageB, const size_t sizeX, const size_t sizeY, const bool hasAlpha, double *pMeanSquaredError,
+                           double *pMaxPossibleSquaredError)
+{
+  limg_hip_context *c = limg_hip_shim::context();
+  if (!c) return 0.0;
+  return limg_hip_compare(c, pImageA, pImageB, sizeX, sizeY, hasAlpha ? 1 : 0, pMeanSquaredError, pMaxPossibleSquaredError);
+}
+
+#endif // LIMG_HIP_SHIM_HPP

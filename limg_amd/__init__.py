@@ -21,6 +21,7 @@ ABI_SYMBOLS = (
     "limg_hip_init", "limg_hip_shutdown", "limg_hip_default_options", "limg_hip_set_options", "limg_hip_encode3d", "limg_hip_encode3d_perf",
     "limg_hip_encode3d_device", "limg_hip_compare", "limg_hip_compare_device", "limg_hip_synth_random_gradient_device",
     "limg_hip_synth_photo_noise_device", "limg_hip_context_device_bytes", "limg_hip_version", "limg_hip_profile_begin", "limg_hip_profile_end",
+    "limg_hip_host_noise_table", "limg_hip_host_chain_call", "limg_hip_host_partition",
 )
 
 RECORD_DTYPE = np.dtype([("avg", "<f4", 4), ("dirA_min", "<i2", 4), ("dirA_max", "<i2", 4), ("dirB_offset", "<i2", 4),
@@ -80,6 +81,12 @@ def load_library(path=None):
     L.limg_hip_profile_begin.argtypes = [C.c_void_p]
     L.limg_hip_profile_end.restype = C.c_int
     L.limg_hip_profile_end.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.limg_hip_host_noise_table.restype = C.c_int
+    L.limg_hip_host_noise_table.argtypes = [C.c_void_p, C.c_size_t]
+    L.limg_hip_host_chain_call.restype = C.c_uint64
+    L.limg_hip_host_chain_call.argtypes = [C.c_uint64, C.c_size_t, C.c_void_p, C.c_int]
+    L.limg_hip_host_partition.restype = C.c_int
+    L.limg_hip_host_partition.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.limg_hip_context_device_bytes.restype = C.c_size_t
     L.limg_hip_context_device_bytes.argtypes = [C.c_void_p]
     return L

@@ -306,6 +306,29 @@ extern "C"
     return written;
   }
 
+  // ---- host-only helpers (no GPU needed; exposed so the host logic can be tested on CPU-only machines) --------------------
+  limg_hip_result limg_hip_host_noise_table(uint8_t *pOut, size_t calls)
+  {
+    if (!pOut) return limg_hip_error_ArgumentNull;
+    fill_noise_table(kDitherSeed, pOut, calls);
+    return limg_hip_success;
+  }
+
+  uint64_t limg_hip_host_chain_call(uint64_t chainValue, size_t pixelCount, uint8_t *pNoise64, int forceSoftwareAes)
+  {
+    if (pixelCount > 64) return 0;
+    return chain_call(chainValue, (unsigned)pixelCount, pNoise64, forceSoftwareAes != 0);
+  }
+
+  limg_hip_result limg_hip_host_partition(size_t sizeY, int poolThreads, uint32_t *pChainCount, uint32_t *pChainBlockRows)
+  {
+    if (!pChainCount || !pChainBlockRows) return limg_hip_error_ArgumentNull;
+    const Partition pt = partition(sizeY, poolThreads);
+    *pChainCount = pt.chainCount;
+    *pChainBlockRows = pt.chainRows;
+    return limg_hip_success;
+  }
+
   size_t limg_hip_context_device_bytes(const limg_hip_context *c)
   {
     if (!c) return 0;

@@ -1,0 +1,111 @@
+"""CPU-only checks of the product's host side: the C ABI exports every symbol include/limg_hip.h declares, the host-only
+helpers (dither noise stream, chain walk, strip partition) agree with the oracle / golden vectors, and the library
+refuses to work without a GPU instead of falling back."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import limg_amd
+    if not os.path.exists(limg_amd.LIB_PATH):
+        from limg_amd import build
+        build.build()
+    return limg_amd.load_library()
+
+
+def test_abi_exports_every_declared_symbol(lib):
+    import limg_amd
+    hdr = open(os.path.join(ROOT, "include", "limg_hip.h")).read()
+    declared = set(re.findall(r"\b(limg_hip_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(limg_amd.ABI_SYMBOLS), declared ^ set(limg_amd.ABI_SYMBOLS)
+    for s in declared:
+        assert getattr(lib, s) is not None
+    assert lib.limg_hip_version().decode().startswith("limg_hip")
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    ctx = C.c_void_p()
+    assert lib.limg_hip_init(0, C.byref(ctx)) == 100  # limg_error_Generic: no device, no fallback
+    assert not ctx
+
+
+def test_product_does_not_reference_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "limg_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")):
+                txt = open(os.path.join(root, f)).read()
+                assert "oracle/" not in txt.replace("oracle/_ref", "").replace("nothing in oracle/", "") or f in ("__init__.py",), (f,)
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+    # the two rsqrt tables (checker copy and product copy) are the same generated data
+    a = open(os.path.join(ROOT, "oracle", "limg_rsqrt_x86_table.h")).read()
+    b = open(os.path.join(ROOT, "limg_amd", "csrc", "limg_rsqrt_x86_table.h")).read()
+    assert a == b
+
+
+def test_noise_stream_matches_oracle_dither(lib, oracle):
+    calls = 300
+    tab = np.zeros((calls, 64), dtype=np.uint8)
+    assert lib.limg_hip_host_noise_table(tab.ctypes.data_as(C.c_void_p), calls) == 0
+    rng = np.random.default_rng(1)
+    h = 0xCA7F00D15BADF00D
+    for k in range(calls):
+        f = rng.integers(0, 256, 64, dtype=np.uint8)
+        s = int(rng.integers(1, 8))
+        h2, want = oracle.dither(s, h, f)
+        t = f.astype(np.int32) + ((tab[k].astype(np.int32) & ((1 << s) - 1)) - (1 << (s - 1)))
+        got = (np.clip(t, 0, 255) >> s).astype(np.uint8)
+        assert np.array_equal(got, want), k
+        h = h2
+
+
+@pytest.mark.parametrize("soft", [0, 1])
+def test_chain_walk_known_answers(lib, soft):
+    c = gu.chain()
+    for n in (64, 16, 20, 40, 7, 15):
+        h = 0xCA7F00D15BADF00D
+        for want in c["aes_%d" % n]:
+            buf = np.zeros(64, dtype=np.uint8)
+            h = lib.limg_hip_host_chain_call(h, n, buf.ctypes.data_as(C.c_void_p), soft)
+            assert "%016x" % h == want, (n, soft)
+
+
+def test_chain_walk_partial_block_noise(lib, oracle):
+    for n in (15, 16, 20, 7, 63, 40):
+        rng = np.random.default_rng(n)
+        f = rng.integers(0, 256, n, dtype=np.uint8)
+        for s in range(1, 8):
+            buf = np.zeros(64, dtype=np.uint8)
+            h = lib.limg_hip_host_chain_call(0x1234567890ABCDEF, n, buf.ctypes.data_as(C.c_void_p), 0)
+            oh, want = oracle.dither(s, 0x1234567890ABCDEF, f)
+            t = f.astype(np.int32) + ((buf[:n].astype(np.int32) & ((1 << s) - 1)) - (1 << (s - 1)))
+            assert h == oh and np.array_equal((np.clip(t, 0, 255) >> s).astype(np.uint8), want), (n, s)
+
+
+@pytest.mark.parametrize("size_y,pool", [(8192, 0), (8192, 2), (618, 8), (200, 2), (64, 3), (24, 8), (8, 1), (1000, 7)])
+def test_partition_rule(lib, size_y, pool):
+    cc, rr = C.c_uint32(), C.c_uint32()
+    assert lib.limg_hip_host_partition(size_y, pool, C.byref(cc), C.byref(rr)) == 0
+    # literal restatement of src/limg.cpp:2114-2134
+    if pool == 0:
+        want = (1, 0)
+    else:
+        tc = pool * 4
+        yr = ((size_y // 8) // tc) * 8
+        if yr == 0:
+            tc = pool
+            yr = ((size_y // 8) // tc) * 8
+        want = (tc, yr // 8) if yr else (1, 0)
+    assert (cc.value, rr.value) == want
