@@ -22,6 +22,7 @@
 //   * correctly rounded division (hipcc default) and round-to-nearest-even conversions.
 #include "limg_hip_internal.h"
 #include "limg_rsqrt_x86_table.h"
+#include "limg_search_table.h"
 
 #include <float.h>
 
@@ -36,6 +37,8 @@ namespace limg_hip
     constexpr int kVDw = 260;   // per-block stride of the parked contributions: 64 px * 4 ch + 4 pad => the (block, channel) walkers hit 32 distinct banks
 
     __device__ const unsigned short d_rsqrt_x86_tab[2048] = LIMG_RSQRT_X86_TAB_INIT;
+    // decision automaton of the default shift search (tools/make_search_table.py); read with scalar loads
+    __constant__ uint2 d_search_tab[LIMG_SEARCH_STATES] = LIMG_SEARCH_TABLE_INIT;
 
     enum : uint32_t { kZeroA = 1u, kZeroB = 2u, kZeroC = 4u, kValid = 8u };
 
@@ -222,6 +225,11 @@ namespace limg_hip
     constexpr int kTermBias = 0x2000;
     constexpr int kRecordLimit = 8000;
 
+    // 24-bit integer multiplies (full rate; v_mul_lo_u32 is quarter rate).  Operands here always fit: see kRecordLimit.
+    __device__ __forceinline__ int mul_i24(int a, int b) { int r; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+    __device__ __forceinline__ uint32_t mul_u24(uint32_t a, uint32_t b) { uint32_t r; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+    __device__ __forceinline__ int mad_i24(int a, int b, int c) { int r; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
     struct TrialState
     {
       // per pixel, fixed for the block
@@ -240,8 +248,8 @@ namespace limg_hip
 
     __device__ __forceinline__ void make_terms(const uint32_t f, const uint32_t s, const int n[3], const int m[3], uint32_t &tRG, int &tB)
     {
-      const int d = (int)__umul24(f >> s, shift_mul(s)); // <= 255 * 256
-      const int t0 = __mul24(d, n[0]) + m[0], t1 = __mul24(d, n[1]) + m[1], t2 = __mul24(d, n[2]) + m[2];
+      const int d = (int)mul_u24(f >> s, shift_mul(s)); // <= 255 * 256
+      const int t0 = mad_i24(d, n[0], m[0]), t1 = mad_i24(d, n[1], m[1]), t2 = mad_i24(d, n[2], m[2]);
       tRG = __builtin_amdgcn_perm((uint32_t)t1, (uint32_t)t0, 0x06050201u); // ((t1 >> 8) & 0xFFFF) << 16 | ((t0 >> 8) & 0xFFFF)
       tB = t2 >> 8;
     }
@@ -273,15 +281,44 @@ namespace limg_hip
       dB = dB < t.pxB ? dB : t.pxB;
       const ushort2_t eu = __builtin_bit_cast(ushort2_t, e);
       const ushort2_t sq = eu * eu; // d^2 <= 65025 fits 16 bits; (-d)^2 mod 2^16 == d^2
-      const uint32_t sqB = (uint32_t)__mul24(dB, dB);
+      const uint32_t sqB = (uint32_t)mul_i24(dB, dB);
       const bool low_red = sq.x < 0x4000;
       const uint32_t wRG = low_red ? 0x00040002u : 0x00040003u;
-      uint32_t err = __builtin_amdgcn_udot2(sq, __builtin_bit_cast(ushort2_t, wRG), __umul24(sqB, low_red ? 3u : 2u), false);
+      uint32_t err = __builtin_amdgcn_udot2(sq, __builtin_bit_cast(ushort2_t, wRG), mul_u24(sqB, low_red ? 3u : 2u), false);
       if (!FULL) err = active ? err : 0u;
       if (__builtin_amdgcn_ballot_w64(err > maxPixel32) != 0ull) return false;
       const uint32_t be = wave_sum(err);
       blockError = be;
       return be < blockLimit; // be * 16 < maxBlock * n, see phase E
+    }
+
+    // a10 + a11 as a table-driven automaton: one trial loop, the next two candidate states are fetched (scalar loads) while
+    // the current trial computes, and the outcome selects between them.
+    // scalar 8-byte load issued now, consumed after `sload_wait` (the compiler would otherwise sink the load to its use and
+    // expose the scalar-cache latency on every trial)
+    __device__ __forceinline__ uint64_t sload2(const uint2 *base, uint32_t byteOffset)
+    {
+      uint64_t v;
+      asm volatile("s_load_dwordx2 %0, %1, %2" : "=&s"(v) : "s"(base), "s"(byteOffset) : "memory");
+      return v;
+    }
+    __device__ __forceinline__ void sload_wait(uint64_t &a, uint64_t &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)::"memory"); }
+
+    template <bool FULL>
+    __device__ __forceinline__ void search_fast_automaton(TrialState &t, const bool active, const uint32_t maxPixel32, const uint32_t blockLimit, uint32_t shift[3])
+    {
+      const uint2 *tab = d_search_tab;
+      uint32_t ex = (uint32_t)sgpr((int)tab[0].x), ey = (uint32_t)sgpr((int)tab[0].y);
+      while (!(ex >> 31))
+      {
+        uint64_t ep = sload2(tab, (ey & 0xFFFFu) << 3), ef = sload2(tab, (ey >> 16) << 3);
+        uint32_t be;
+        const bool ok = trial_packed<FULL>(t, ex & 15u, (ex >> 4) & 15u, (ex >> 8) & 15u, active, maxPixel32, blockLimit, be);
+        sload_wait(ep, ef);
+        const uint64_t e = ok ? ep : ef;
+        ex = (uint32_t)e; ey = (uint32_t)(e >> 32);
+      }
+      shift[0] = ex & 15u; shift[1] = (ex >> 4) & 15u; shift[2] = (ex >> 8) & 15u;
     }
 
     // a10-a12 search driver; everything in here is wave-uniform
@@ -414,13 +451,130 @@ namespace limg_hip
     // =====================================================================================================================
     // kernel 1: fit + factors + shift search
     // =====================================================================================================================
+
+    // Per-block state in LDS.  The first 120 bytes are the float-stage state; once the record has been produced they are
+    // dead and the same bytes carry what phase E needs (`BlkE` view).
+    struct BlkF
+    {
+      float avg[4], dirA[4], dirB[4], dirC[4], est0[4]; // 80
+      float mm[6];                                      // 104: minA maxA minB maxB minC maxC
+      float inv_count, invA, invB, invC;                // 120
+      uint32_t flags, n;                                // 128
+      int16_t rec[24];                                  // 176
+      float pad[4];                                     // 192
+    };
+    struct BlkE
+    {
+      float nrm[3][4]; // 48: float normals (max - min) of A, B, C
+      float off[3][4]; // 96: float dirA_min, dirB_offset, dirC_offset
+      float invN[3];   // 108
+    };
+    static_assert(sizeof(BlkE) <= 120, "BlkE must fit the dead float-stage fields");
+    static_assert(sizeof(BlkF) == 192, "BlkF layout");
+
+    // exact min / max over the wave of two values at once (no NaN present); results wave-uniform.
+    // Hand-written DPP: the two chains interleave so each needs only one wait state between dependent steps.
+    __device__ __forceinline__ void wave_min_max(float &mn, float &mx)
+    {
+      asm volatile(
+          "s_nop 1\n\t"
+          "v_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+          "v_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 0\n\t"
+          "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+          "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 0\n\t"
+          "v_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+          "v_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 0\n\t"
+          "v_min_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+          "v_max_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 0\n\t"
+          "v_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+          "v_max_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+          "s_nop 0\n\t"
+          "v_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+          "v_max_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+          "s_nop 1"
+          : "+v"(mn), "+v"(mx));
+      mn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mn), 63));
+      mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mx), 63));
+    }
+
+    __device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+    __device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+    __device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+    __device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+    // sign-normalised unit vector, lean form of `unit_contribution` (same arithmetic; min/max by v_min3/v_max3 -- their
+    // only differences from MINPS/MAXPS are NaN handling and the sign of a zero result, neither of which can reach the
+    // `|min| > max` comparison outcome; the NaN-producing degenerate cases never get here, see kZero* flags).
+    template <int CH>
+    __device__ __forceinline__ void unit2(const unsigned short *tab, const float d[4], bool active, float out[4])
+    {
+      const float e3 = FLT_EPSILON * 3, e2 = FLT_EPSILON * 2, e1 = FLT_EPSILON;
+      const float mn = vmin3(d[0] - e3, d[2] - e1, vmin(d[1] - e2, d[3] - 0.0f));
+      const float mx = vmax3(d[0] + e3, d[2] + e1, vmax(d[1] + e2, d[3] + 0.0f));
+      const uint32_t anybits = (__float_as_uint(d[0]) | __float_as_uint(d[1]) | __float_as_uint(d[2]) | __float_as_uint(d[3])) << 1;
+      const bool use = (anybits != 0u) && active;
+      float len2 = dpps<CH>(d, d);
+      // RSQRTPS table lookup; for skipped lanes len2 == 0 => index 0x400, exponent garbage: result discarded below
+      const uint32_t b = __float_as_uint(len2);
+      const uint32_t idx2 = ((b >> 12) & 0xFFEu) ^ 0x800u; // byte offset into the u16 table
+      const uint32_t tv = *reinterpret_cast<const unsigned short *>(reinterpret_cast<const unsigned char *>(tab) + idx2);
+      const uint32_t ex = (380u - (b >> 23)) >> 1; // 126 - floor((e - 127) / 2)
+      float inv = __uint_as_float((ex << 23) | (tv << 11));
+      inv = (-mn > mx) ? -inv : inv; // |min| > max  (min >= 0 can never satisfy either form)
+      inv = use ? inv : 0.0f;
+#pragma unroll
+      for (int c = 0; c < 4; c++) out[c] = d[c] * inv;
+    }
+
+    enum : int { kDirA = 0, kDirB = 1, kDirC = 2 };
+    constexpr uint32_t kBig = 16u; // some |record value| > kRecordLimit => generic 32-bit trial
+
+    // Pixel-order accumulation (as `serial_sums`) followed, lane-parallel over the wave's 8 blocks, by everything the next
+    // phase needs of the new direction: 1 / (dir . dir) with the DPPS order (correctly rounded division, once per 8 blocks)
+    // and the all-zero flag.
+    template <int CH, int WHICH>
+    __device__ __forceinline__ void serial_sums2(const float *V, BlkF *blk, int lane)
+    {
+      wave_lds_fence();
+      if (lane < 32)
+      {
+        const int b = lane >> 2, c = lane & 3;
+        const float *src = V + b * kVDw + c;
+        float s = 0.0f;
+#pragma unroll 16
+        for (int i = 0; i < 64; i++) s = s + src[i * 4];
+        const float dir = s * blk[b].inv_count;
+        float *dst = WHICH == kDirA ? blk[b].dirA : (WHICH == kDirB ? blk[b].dirB : blk[b].dirC);
+        dst[c] = dir;
+        // (p0 + p1) + (p2 + p3) inside each quad of lanes; float add is commutative so the xor butterflies give exactly that
+        float p = (CH == 3 && c == 3) ? 0.0f : dir * dir;
+        p = p + __int_as_float(dpp<0xB1, 0xF>(0, __float_as_int(p)));
+        p = p + __int_as_float(dpp<0x4E, 0xF>(0, __float_as_int(p)));
+        uint32_t z = (dir == 0.0f) ? 1u : 0u;
+        z &= (uint32_t)dpp<0xB1, 0xF>(0, (int)z);
+        z &= (uint32_t)dpp<0x4E, 0xF>(0, (int)z);
+        const float inv = 1.0f / p;
+        if (c == 0)
+        {
+          if (WHICH == kDirA) { blk[b].invA = inv; if (z) blk[b].flags |= kZeroA | kZeroB | kZeroC; }
+          else if (WHICH == kDirB) { blk[b].invB = inv; if (z) blk[b].flags |= kZeroB | kZeroC; }
+          else { blk[b].invC = inv; if (z) blk[b].flags |= kZeroC; }
+        }
+      }
+      wave_lds_fence();
+    }
+
     template <int CH>
     __global__ __launch_bounds__(kThreads) void k_fit_search(const EncodeParams p)
     {
       __shared__ __attribute__((aligned(16))) unsigned short s_rsq[2048];
       __shared__ __attribute__((aligned(16))) uint32_t s_strip[8 * kRowDw];
       __shared__ __attribute__((aligned(16))) float s_V[kWaves * kBlocksPerWave * kVDw];
-      __shared__ __attribute__((aligned(16))) Blk s_blk[kStripBlocks];
+      __shared__ __attribute__((aligned(16))) BlkF s_blk[kStripBlocks];
       __shared__ uint32_t s_calls[kWaves];
 
       const int tid = (int)threadIdx.x;
@@ -457,44 +611,47 @@ namespace limg_hip
       __syncthreads();
 
       float *V = s_V + wave * kBlocksPerWave * kVDw;
-      Blk *blk = s_blk + wave * kBlocksPerWave;
+      BlkF *blk = s_blk + wave * kBlocksPerWave;
 
-      // per-block geometry helpers (wave-uniform)
+      // per-block geometry (wave-uniform)
       auto geom = [&](int b, uint32_t &rx, uint32_t &n) -> bool
       {
-        const uint32_t sb = wave * kBlocksPerWave + b;
-        const uint32_t bx = strip * kStripBlocks + sb;
+        const uint32_t bx = strip * kStripBlocks + wave * kBlocksPerWave + b;
         if (bx >= p.blocksX) { rx = 0; n = 0; return false; }
         rx = min(p.sizeX - bx * kBlock, (uint32_t)kBlock);
         n = rx * ry;
         return true;
       };
-      auto load_px = [&](int b, uint32_t rx, uint32_t n, float pf[4]) -> uint32_t
+
+      // Per-block values that stay in registers across the phases (all loops over b are fully unrolled).
+      uint32_t px8[kBlocksPerWave];
+      float est8[kBlocksPerWave][4];
+
+      // ---- phase A: sums, average, first direction pass (a4, a5/a6 pass 1) ------------------------------------------
+#pragma unroll
+      for (int b = 0; b < kBlocksPerWave; b++)
       {
+        uint32_t rx, n;
+        px8[b] = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) est8[b][c] = 0.0f;
+        if (!geom(b, rx, n))
+        {
+          if (lane == 0) { blk[b].flags = 0; blk[b].n = 0; blk[b].inv_count = 0.0f; }
+          continue;
+        }
         const uint32_t sb = wave * kBlocksPerWave + b;
         uint32_t lx, ly;
         if (rx == 8) { lx = lane & 7; ly = lane >> 3; }
         else { const uint32_t l = (uint32_t)lane < n ? (uint32_t)lane : 0u; ly = l / rx; lx = l - ly * rx; }
         uint32_t px = s_strip[ly * kRowDw + sb * kBlock + lx];
         px = (uint32_t)lane < n ? px : 0u;
-        px_to_float(px, pf);
-        return px;
-      };
-
-      // ---- phase A: sums, average, first direction pass (a4, a5/a6 pass 1) ------------------------------------------
-      for (int b = 0; b < kBlocksPerWave; b++)
-      {
-        uint32_t rx, n;
-        const bool valid = geom(b, rx, n);
-        if (!valid)
-        {
-          if (lane == 0) { blk[b].flags = 0; blk[b].n = 0; blk[b].inv_count = 0.0f; }
-          continue;
-        }
+        px8[b] = px;
         float pf[4];
-        const uint32_t px = load_px(b, rx, n, pf);
+        px_to_float(px, pf);
         const uint32_t s02 = wave_sum(px & 0x00FF00FFu), s13 = wave_sum((px >> 8) & 0x00FF00FFu);
-        const float inv_count = 1.0f / (float)n;
+        float inv_count = 0.015625f;
+        if (n != 64) inv_count = 1.0f / (float)n;
         float avg[4];
         avg[0] = (float)(int)(s02 & 0xFFFF) * inv_count;
         avg[1] = (float)(int)(s13 & 0xFFFF) * inv_count;
@@ -504,118 +661,108 @@ namespace limg_hip
 #pragma unroll
         for (int c = 0; c < 4; c++) d[c] = pf[c] - avg[c];
         if (CH == 3) d[3] = 0.0f;
-        unit_contribution<CH>(s_rsq, d, (uint32_t)lane < n, v);
+        unit2<CH>(s_rsq, d, (uint32_t)lane < n, v);
         store_v(V + b * kVDw, lane, v);
         if (lane == 0)
         {
-          blk[b].avg[0] = avg[0]; blk[b].avg[1] = avg[1]; blk[b].avg[2] = avg[2]; blk[b].avg[3] = avg[3];
-          blk[b].inv_count = inv_count; blk[b].n = n; blk[b].rx = rx; blk[b].flags = kValid;
-#pragma unroll
-          for (int k = 0; k < 6; k++) blk[b].mm[k] = 0.0f;
-#pragma unroll
-          for (int c = 0; c < 4; c++) { blk[b].dirB[c] = 0.0f; blk[b].dirC[c] = 0.0f; blk[b].est0[c] = 0.0f; }
+          *reinterpret_cast<float4 *>(blk[b].avg) = make_float4(avg[0], avg[1], avg[2], avg[3]);
+          *reinterpret_cast<float4 *>(blk[b].dirB) = make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4 *>(blk[b].dirC) = make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4 *>(blk[b].est0) = make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4 *>(blk[b].mm) = make_float4(0.f, 0.f, 0.f, 0.f);
+          blk[b].mm[4] = 0.0f; blk[b].mm[5] = 0.0f;
+          blk[b].inv_count = inv_count; blk[b].n = n; blk[b].flags = kValid;
         }
       }
-      serial_sums(V, blk, 0, lane);
+      serial_sums2<CH, kDirA>(V, blk, lane);
 
       // ---- phase B: factor A extrema, residual -> second direction (pass 2) --------------------------------------------
+#pragma unroll
       for (int b = 0; b < kBlocksPerWave; b++)
       {
         uint32_t rx, n;
         if (!geom(b, rx, n)) continue;
-        float dirA[4], avg[4], pf[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) { dirA[c] = sgprf(blk[b].dirA[c]); avg[c] = sgprf(blk[b].avg[c]); }
-        const bool zeroA = (dirA[0] == 0.0f && dirA[1] == 0.0f && dirA[2] == 0.0f && dirA[3] == 0.0f);
-        if (zeroA)
-        {
-          if (lane == 0) blk[b].flags |= kZeroA | kZeroB | kZeroC;
-          continue;
-        }
-        load_px(b, rx, n, pf);
+        if ((uint32_t)sgpr((int)blk[b].flags) & kZeroA) continue;
+        const float4 dA4 = *reinterpret_cast<const float4 *>(blk[b].dirA), av4 = *reinterpret_cast<const float4 *>(blk[b].avg);
+        const float dirA[4] = { dA4.x, dA4.y, dA4.z, dA4.w }, avg[4] = { av4.x, av4.y, av4.z, av4.w };
+        const float invA = blk[b].invA;
+        float pf[4], l[4], e[4], v[4];
+        px_to_float(px8[b], pf);
         const bool active = (uint32_t)lane < n;
-        const float invA = 1.0f / dpps<CH>(dirA, dirA);
-        float l[4], e[4], v[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) l[c] = pf[c] - avg[c];
         const float fA = dpps<CH>(l, dirA) * invA;
-        const float mn = __builtin_fminf(0.0f, wave_minmax<false>(active ? fA : 0.0f));
-        const float mx = __builtin_fmaxf(0.0f, wave_minmax<true>(active ? fA : 0.0f));
+        float mn = active ? fA : 0.0f, mx = mn; // min / max start at 0 upstream (src/limg_factorization.h:633-634)
+        wave_min_max(mn, mx);
+        mn = vmin(mn, 0.0f); mx = vmax(mx, 0.0f);
 #pragma unroll
-        for (int c = 0; c < 4; c++) e[c] = pf[c] - (avg[c] + fA * dirA[c]);
+        for (int c = 0; c < 4; c++) { est8[b][c] = avg[c] + fA * dirA[c]; e[c] = pf[c] - est8[b][c]; }
         if (CH == 3) e[3] = 0.0f;
-        unit_contribution<CH>(s_rsq, e, active, v);
+        unit2<CH>(s_rsq, e, active, v);
         store_v(V + b * kVDw, lane, v);
         if (lane == 0) { blk[b].mm[0] = mn; blk[b].mm[1] = mx; }
       }
-      serial_sums(V, blk, 1, lane);
+      serial_sums2<CH, kDirB>(V, blk, lane);
 
       // ---- phase C: factor B (and, 3 ch, C) extrema; 4 ch: residual -> third direction (pass 3) ---------------------
+#pragma unroll
       for (int b = 0; b < kBlocksPerWave; b++)
       {
         uint32_t rx, n;
         if (!geom(b, rx, n)) continue;
-        const uint32_t flags = (uint32_t)sgpr((int)blk[b].flags);
-        if (flags & kZeroA) continue;
-        float dirA[4], dirB[4], avg[4], pf[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) { dirA[c] = sgprf(blk[b].dirA[c]); dirB[c] = sgprf(blk[b].dirB[c]); avg[c] = sgprf(blk[b].avg[c]); }
-        const bool zeroB = (dirB[0] == 0.0f && dirB[1] == 0.0f && dirB[2] == 0.0f && dirB[3] == 0.0f);
-        if (zeroB)
-        { // 1/0 = inf => every fB is NaN upstream => B and (through the NaN estimate) C collapse to 0
-          if (lane == 0) blk[b].flags |= kZeroB | kZeroC;
-          continue;
-        }
-        load_px(b, rx, n, pf);
+        if ((uint32_t)sgpr((int)blk[b].flags) & kZeroB) continue; // 1/0 = inf => every fB is NaN upstream => B and C collapse to 0
+        const float4 dB4 = *reinterpret_cast<const float4 *>(blk[b].dirB);
+        const float dirB[4] = { dB4.x, dB4.y, dB4.z, dB4.w };
+        const float invB = blk[b].invB;
+        float pf[4], l[4];
+        px_to_float(px8[b], pf);
         const bool active = (uint32_t)lane < n;
-        const float invA = 1.0f / dpps<CH>(dirA, dirA);
-        const float invB = 1.0f / dpps<CH>(dirB, dirB);
-        float l[4], est[4];
 #pragma unroll
-        for (int c = 0; c < 4; c++) l[c] = pf[c] - avg[c];
-        const float fA = dpps<CH>(l, dirA) * invA;
-#pragma unroll
-        for (int c = 0; c < 4; c++) { est[c] = avg[c] + fA * dirA[c]; l[c] = pf[c] - est[c]; }
+        for (int c = 0; c < 4; c++) l[c] = pf[c] - est8[b][c];
         const float fB = dpps<CH>(l, dirB) * invB;
-        const float mnB = wave_minmax<false>(active ? fB : FLT_MAX);
-        const float mxB = wave_minmax<true>(active ? fB : -FLT_MAX);
+        float mnB = active ? fB : FLT_MAX, mxB = active ? fB : -FLT_MAX;
         if (CH == 4)
         {
+          wave_min_max(mnB, mxB);
           float e[4], v[4];
 #pragma unroll
-          for (int c = 0; c < 4; c++) { est[c] = est[c] + fB * dirB[c]; e[c] = pf[c] - est[c]; }
-          unit_contribution<CH>(s_rsq, e, active, v);
+          for (int c = 0; c < 4; c++) { est8[b][c] = est8[b][c] + fB * dirB[c]; e[c] = pf[c] - est8[b][c]; }
+          unit2<CH>(s_rsq, e, active, v);
           store_v(V + b * kVDw, lane, v);
           if (lane == 0)
           {
             blk[b].mm[2] = mnB; blk[b].mm[3] = mxB;
-            blk[b].est0[0] = est[0]; blk[b].est0[1] = est[1]; blk[b].est0[2] = est[2]; blk[b].est0[3] = est[3];
+            *reinterpret_cast<float4 *>(blk[b].est0) = make_float4(est8[b][0], est8[b][1], est8[b][2], est8[b][3]);
           }
         }
         else
         {
           // dirC = dirA x dirB (src/limg_factorization.h:498-507)
+          const float4 dA4 = *reinterpret_cast<const float4 *>(blk[b].dirA);
           float dirC[4];
-          dirC[0] = dirA[1] * dirB[2] - dirA[2] * dirB[1];
-          dirC[1] = dirA[2] * dirB[0] - dirA[0] * dirB[2];
-          dirC[2] = dirA[0] * dirB[1] - dirA[1] * dirB[0];
+          dirC[0] = dA4.y * dirB[2] - dA4.z * dirB[1];
+          dirC[1] = dA4.z * dirB[0] - dA4.x * dirB[2];
+          dirC[2] = dA4.x * dirB[1] - dA4.y * dirB[0];
           dirC[3] = 0.0f;
-          const bool zeroC = (dirC[0] == 0.0f && dirC[1] == 0.0f && dirC[2] == 0.0f);
+          const bool zeroC = sgpr((dirC[0] == 0.0f && dirC[1] == 0.0f && dirC[2] == 0.0f) ? 1 : 0) != 0;
           float mnC = 0.0f, mxC = 0.0f;
           if (!zeroC)
           {
             const float invC = 1.0f / dpps<CH>(dirC, dirC);
             float e[4];
 #pragma unroll
-            for (int c = 0; c < 4; c++) e[c] = pf[c] - (est[c] + fB * dirB[c]);
+            for (int c = 0; c < 4; c++) e[c] = pf[c] - (est8[b][c] + fB * dirB[c]);
             const float fC = dpps<CH>(e, dirC) * invC;
-            mnC = wave_minmax<false>(active ? fC : FLT_MAX);
-            mxC = wave_minmax<true>(active ? fC : -FLT_MAX);
+            mnC = active ? fC : FLT_MAX; mxC = active ? fC : -FLT_MAX;
+            wave_min_max(mnB, mxB);
+            wave_min_max(mnC, mxC);
           }
+          else
+            wave_min_max(mnB, mxB);
           if (lane == 0)
           {
             blk[b].mm[2] = mnB; blk[b].mm[3] = mxB; blk[b].mm[4] = mnC; blk[b].mm[5] = mxC;
-            blk[b].dirC[0] = dirC[0]; blk[b].dirC[1] = dirC[1]; blk[b].dirC[2] = dirC[2]; blk[b].dirC[3] = 0.0f;
+            *reinterpret_cast<float4 *>(blk[b].dirC) = make_float4(dirC[0], dirC[1], dirC[2], 0.0f);
             if (zeroC) blk[b].flags |= kZeroC;
           }
         }
@@ -623,71 +770,104 @@ namespace limg_hip
       if (CH == 4)
       {
         // blocks that skipped phase C left stale pass-2 contributions in V; their dirC is never used (flags)
-        serial_sums(V, blk, 2, lane);
+        serial_sums2<CH, kDirC>(V, blk, lane);
         // ---- phase D: factor C extrema (pass 4).  Upstream never advances its estimate pointer in this loop
         //      (src/limg_factorization.h:748-758), so every pixel is measured against pixel 0's A+B estimate.
+#pragma unroll
         for (int b = 0; b < kBlocksPerWave; b++)
         {
           uint32_t rx, n;
           if (!geom(b, rx, n)) continue;
-          const uint32_t flags = (uint32_t)sgpr((int)blk[b].flags);
-          if (flags & (kZeroA | kZeroB)) continue;
-          float dirC[4], est0[4], pf[4];
-#pragma unroll
-          for (int c = 0; c < 4; c++) { dirC[c] = sgprf(blk[b].dirC[c]); est0[c] = sgprf(blk[b].est0[c]); }
-          const bool zeroC = (dirC[0] == 0.0f && dirC[1] == 0.0f && dirC[2] == 0.0f && dirC[3] == 0.0f);
-          if (zeroC)
-          {
-            if (lane == 0) blk[b].flags |= kZeroC;
-            continue;
-          }
-          load_px(b, rx, n, pf);
+          if ((uint32_t)sgpr((int)blk[b].flags) & kZeroC) continue;
+          const float4 dC4 = *reinterpret_cast<const float4 *>(blk[b].dirC), e04 = *reinterpret_cast<const float4 *>(blk[b].est0);
+          const float dirC[4] = { dC4.x, dC4.y, dC4.z, dC4.w }, est0[4] = { e04.x, e04.y, e04.z, e04.w };
+          const float invC = blk[b].invC;
+          float pf[4], l[4];
+          px_to_float(px8[b], pf);
           const bool active = (uint32_t)lane < n;
-          const float invC = 1.0f / dpps<CH>(dirC, dirC);
-          float l[4];
 #pragma unroll
           for (int c = 0; c < 4; c++) l[c] = pf[c] - est0[c];
           const float fC = dpps<CH>(l, dirC) * invC;
-          const float mnC = wave_minmax<false>(active ? fC : FLT_MAX);
-          const float mxC = wave_minmax<true>(active ? fC : -FLT_MAX);
+          float mnC = active ? fC : FLT_MAX, mxC = active ? fC : -FLT_MAX;
+          wave_min_max(mnC, mxC);
           if (lane == 0) { blk[b].mm[4] = mnC; blk[b].mm[5] = mxC; }
         }
       }
       wave_lds_fence();
 
-      // ---- records (src/limg_factorization.h:764-790): 8 blocks x 24 values, one value per lane ---------------------
-#pragma unroll
-      for (int r = 0; r < 3; r++)
+      // ---- records (src/limg_factorization.h:764-790): 8 lanes per block, 3 values per lane --------------------------
       {
-        const int idx = r * 64 + lane;
-        const int b = idx / 24, kc = idx - b * 24, k = kc >> 2, c = kc & 3;
+        const int b = lane >> 3, j = lane & 7;
         const uint32_t flags = blk[b].flags;
-        const float *dir = k < 2 ? blk[b].dirA : (k < 4 ? blk[b].dirB : blk[b].dirC);
-        float m = blk[b].mm[k];
-        float dv = dir[c];
-        const bool dead = (k >= 4 && (flags & kZeroC)) || (k >= 2 && (flags & kZeroB)) || (flags & kZeroA);
-        if (dead) { m = 0.0f; dv = 0.0f; }
-        float val = m * dv;
-        if (k < 2) val = blk[b].avg[c] + val;
-        int q = cvt_rne(val);
-        if ((CH == 3 && c == 3) || !(flags & kValid)) q = 0;
-        blk[b].rec[kc] = (int16_t)q;
+        uint32_t big = 0;
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+        {
+          const int kc = j + 8 * r, k = kc >> 2, c = kc & 3; // k = 2 r + (j >> 2): A for r == 0, B for r == 1, C for r == 2
+          const float *dir = r == 0 ? blk[b].dirA : (r == 1 ? blk[b].dirB : blk[b].dirC);
+          float m = blk[b].mm[k], dv = dir[c];
+          const bool dead = (r == 2 && (flags & kZeroC)) || (r >= 1 && (flags & kZeroB)) || (flags & kZeroA);
+          if (dead) { m = 0.0f; dv = 0.0f; }
+          float val = m * dv;
+          if (r == 0) val = blk[b].avg[c] + val;
+          int q = cvt_rne(val);
+          if ((CH == 3 && c == 3) || !(flags & kValid)) q = 0;
+          big |= (q > kRecordLimit || q < -kRecordLimit) ? 1u : 0u;
+          blk[b].rec[kc] = (int16_t)q;
+        }
+        big |= (uint32_t)dpp<0xB1, 0xF>(0, (int)big);
+        big |= (uint32_t)dpp<0x4E, 0xF>(0, (int)big);
+        big |= (uint32_t)dpp<0x141, 0xF>(0, (int)big);
+        if (j == 0 && big) blk[b].flags = flags | kBig;
       }
       wave_lds_fence();
-      // colour-error state (src/limg_internal.h:426-452): 1 / |n|^2 per factor, serial limg_dot order
-      if (lane < 24)
+      // record -> global (16 dwords per block: avg, then the 24 int16)
+      if (p.records)
       {
-        const int b = lane / 3, f = lane - b * 3;
-        float s = 0.0f;
-        bool nz = false;
 #pragma unroll
-        for (int c = 0; c < CH; c++)
+        for (int r = 0; r < 2; r++)
         {
-          const float nrm = (float)((int)blk[b].rec[f * 8 + 4 + c] - (int)blk[b].rec[f * 8 + c]);
-          nz |= nrm != 0.0f;
-          s = s + nrm * nrm;
+          const int b = r * 4 + (lane >> 4), w = lane & 15;
+          const uint32_t bx = strip * kStripBlocks + wave * kBlocksPerWave + b;
+          if (bx < p.blocksX)
+          {
+            const uint32_t val = w < 4 ? __float_as_uint(blk[b].avg[w]) : reinterpret_cast<const uint32_t *>(blk[b].rec)[w - 4];
+            reinterpret_cast<uint32_t *>(p.records + (size_t)by * p.blocksX + bx)[w] = val;
+          }
         }
-        blk[b].invN[f] = nz ? 1.0f / s : 0.0f;
+      }
+      // phase-E view (overlays the dead float-stage fields): float normals / offsets and 1 / |n|^2 in the serial limg_dot
+      // order (src/limg_internal.h:426-452).  One lane per (block, factor, channel): 96 of 128 lane slots.
+      {
+        float nrm[2], off[2], invn[2];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+        {
+          const int idx = min(r * 64 + lane, 95);
+          const int b = idx / 12, fc = idx - b * 12, f = fc >> 2, c = fc & 3;
+          const int lo = blk[b].rec[f * 8 + c], hi = blk[b].rec[f * 8 + 4 + c];
+          nrm[r] = (float)(hi - lo); off[r] = (float)lo;
+          const float sq = nrm[r] * nrm[r];
+          const float s0 = __int_as_float(dpp<0x00, 0xF>(0, __float_as_int(sq))), s1 = __int_as_float(dpp<0x55, 0xF>(0, __float_as_int(sq)));
+          const float s2 = __int_as_float(dpp<0xAA, 0xF>(0, __float_as_int(sq))), s3 = __int_as_float(dpp<0xFF, 0xF>(0, __float_as_int(sq)));
+          float s = ((0.0f + s0) + s1) + s2;
+          if (CH == 4) s = s + s3;
+          const bool nz = (s0 != 0.0f) || (s1 != 0.0f) || (s2 != 0.0f) || (CH == 4 && s3 != 0.0f);
+          invn[r] = nz ? 1.0f / s : 0.0f;
+        }
+        wave_lds_fence(); // every lane has read what it needs of the float-stage fields before the overlay is written
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+        {
+          const int idx = r * 64 + lane;
+          if (idx < 96)
+          {
+            const int b = idx / 12, fc = idx - b * 12, f = fc >> 2, c = fc & 3;
+            BlkE *e = reinterpret_cast<BlkE *>(&blk[b]);
+            e->nrm[f][c] = nrm[r]; e->off[f][c] = off[r];
+            if (c == 0) e->invN[f] = invn[r];
+          }
+        }
       }
       __syncthreads(); // all waves are done with V: wave 0's V region becomes the factor-byte staging area
 
@@ -695,41 +875,43 @@ namespace limg_hip
       uint32_t waveCalls = 0;
 
       // ---- phase E: per-pixel factors (a8) + shift search (a10-a12) ----------------------------------------------------
+#pragma unroll 1
       for (int b = 0; b < kBlocksPerWave; b++)
       {
         uint32_t rx, n;
         if (!geom(b, rx, n)) continue;
         const uint32_t sb = wave * kBlocksPerWave + b;
         const uint32_t bx = strip * kStripBlocks + sb;
-        float pf[4];
-        const uint32_t px = load_px(b, rx, n, pf);
+        uint32_t lx, ly;
+        if (rx == 8) { lx = lane & 7; ly = lane >> 3; }
+        else { const uint32_t l = (uint32_t)lane < n ? (uint32_t)lane : 0u; ly = l / rx; lx = l - ly * rx; }
+        uint32_t px = s_strip[ly * kRowDw + sb * kBlock + lx];
         const bool active = (uint32_t)lane < n;
-
-        int rec[24];
-#pragma unroll
-        for (int i = 0; i < 24; i++) rec[i] = sgpr((int)blk[b].rec[i]);
-        const float invA = sgprf(blk[b].invN[0]), invB = sgprf(blk[b].invN[1]), invC = sgprf(blk[b].invN[2]);
+        px = active ? px : 0u;
+        float pf[4];
+        px_to_float(px, pf);
+        const BlkE *be = reinterpret_cast<const BlkE *>(&blk[b]);
 
         uint32_t fA, fB, fC;
         {
-          float nA[4], nB[4], nC[4], mnA[4], ofB[4], ofC[4], t[4], est[4];
-#pragma unroll
-          for (int c = 0; c < 4; c++)
-          {
-            nA[c] = (float)(rec[4 + c] - rec[c]); nB[c] = (float)(rec[12 + c] - rec[8 + c]); nC[c] = (float)(rec[20 + c] - rec[16 + c]);
-            mnA[c] = (float)rec[c]; ofB[c] = (float)rec[8 + c]; ofC[c] = (float)rec[16 + c];
-          }
+          float t[4], est[4];
+          const float4 nA4 = *reinterpret_cast<const float4 *>(be->nrm[0]), oA4 = *reinterpret_cast<const float4 *>(be->off[0]);
+          const float nA[4] = { nA4.x, nA4.y, nA4.z, nA4.w }, mnA[4] = { oA4.x, oA4.y, oA4.z, oA4.w };
 #pragma unroll
           for (int c = 0; c < 4; c++) t[c] = pf[c] - mnA[c];
-          const float fa = dpps<CH>(t, nA) * invA;
+          const float fa = dpps<CH>(t, nA) * be->invN[0];
           int q = cvt_rne(255.0f * fa); q = q < 255 ? q : 255; q = q > 0 ? q : 0; fA = (uint32_t)q;
+          const float4 nB4 = *reinterpret_cast<const float4 *>(be->nrm[1]), oB4 = *reinterpret_cast<const float4 *>(be->off[1]);
+          const float nB[4] = { nB4.x, nB4.y, nB4.z, nB4.w }, ofB[4] = { oB4.x, oB4.y, oB4.z, oB4.w };
 #pragma unroll
           for (int c = 0; c < 4; c++) { est[c] = mnA[c] + nA[c] * fa; t[c] = (pf[c] - est[c]) - ofB[c]; }
-          const float fb = dpps<CH>(t, nB) * invB;
+          const float fb = dpps<CH>(t, nB) * be->invN[1];
           q = cvt_rne(255.0f * fb); q = q < 255 ? q : 255; q = q > 0 ? q : 0; fB = (uint32_t)q;
+          const float4 nC4 = *reinterpret_cast<const float4 *>(be->nrm[2]), oC4 = *reinterpret_cast<const float4 *>(be->off[2]);
+          const float nC[4] = { nC4.x, nC4.y, nC4.z, nC4.w }, ofC[4] = { oC4.x, oC4.y, oC4.z, oC4.w };
 #pragma unroll
           for (int c = 0; c < 4; c++) { est[c] = est[c] + nB[c] * fb; t[c] = (pf[c] - est[c]) - ofC[c]; }
-          const float fc = dpps<CH>(t, nC) * invC;
+          const float fc = dpps<CH>(t, nC) * be->invN[2];
           q = cvt_rne(255.0f * fc); q = q < 255 ? q : 255; q = q > 0 ? q : 0; fC = (uint32_t)q;
         }
 
@@ -744,9 +926,13 @@ namespace limg_hip
           // be * 16 < maxBlock * n  <=>  be < ceil(maxBlock * n / 16); clamped to 32 bits (be itself never gets near 2^32)
           const uint64_t lim64 = (maxBlockN + 15ull) >> 4;
           const uint32_t blockLimit = (uint32_t)sgpr((int)(lim64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)lim64));
-          int big = 0;
+          const bool big = ((uint32_t)sgpr((int)blk[b].flags) & kBig) != 0;
+          // integer record view (RGB lanes); kept in VGPRs: they are operands of v_mad_i32_i24
+          int rlo[3][3], rhi[3][3];
 #pragma unroll
-          for (int i = 0; i < 24; i++) big |= (rec[i] > kRecordLimit || rec[i] < -kRecordLimit) ? 1 : 0;
+          for (int f = 0; f < 3; f++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) { rlo[f][c] = blk[b].rec[f * 8 + c]; rhi[f][c] = blk[b].rec[f * 8 + 4 + c]; }
           if (!big)
           {
             TrialState t;
@@ -760,22 +946,28 @@ namespace limg_hip
             for (int c = 0; c < 3; c++)
             {
               const int bias = c == 0 ? (kTermBias << 8) : 0;
-              t.nA[c] = rec[4 + c] - rec[c]; t.nB[c] = rec[12 + c] - rec[8 + c]; t.nC[c] = rec[20 + c] - rec[16 + c];
-              t.mA[c] = (rec[c] << 8) + 128 + bias; t.mB[c] = (rec[8 + c] << 8) + 128 + bias; t.mC[c] = (rec[16 + c] << 8) + 128 + bias;
+              t.nA[c] = rhi[0][c] - rlo[0][c]; t.nB[c] = rhi[1][c] - rlo[1][c]; t.nC[c] = rhi[2][c] - rlo[2][c];
+              t.mA[c] = (rlo[0][c] << 8) + 128 + bias; t.mB[c] = (rlo[1][c] << 8) + 128 + bias; t.mC[c] = (rlo[2][c] << 8) + 128 + bias;
             }
             t.cA = t.cB = t.cC = 0xFFu;
             t.tA_RG = t.tB_RG = t.tC_RG = 0; t.tA_B = t.tB_B = t.tC_B = 0;
             if (n == 64)
             {
-              auto T = [&](uint32_t a, uint32_t bb, uint32_t c, uint32_t &be) -> bool { return trial_packed<true>(t, a, bb, c, true, p.maxPixel32, blockLimit, be); };
-              if (p.fast) search_fast(T, shift);
-              else search_accurate(T, shift);
+              if (p.fast) search_fast_automaton<true>(t, true, p.maxPixel32, blockLimit, shift);
+              else
+              {
+                auto T = [&](uint32_t a, uint32_t bb, uint32_t c, uint32_t &be2) -> bool { return trial_packed<true>(t, a, bb, c, true, p.maxPixel32, blockLimit, be2); };
+                search_accurate(T, shift);
+              }
             }
             else
             {
-              auto T = [&](uint32_t a, uint32_t bb, uint32_t c, uint32_t &be) -> bool { return trial_packed<false>(t, a, bb, c, active, p.maxPixel32, blockLimit, be); };
-              if (p.fast) search_fast(T, shift);
-              else search_accurate(T, shift);
+              if (p.fast) search_fast_automaton<false>(t, active, p.maxPixel32, blockLimit, shift);
+              else
+              {
+                auto T = [&](uint32_t a, uint32_t bb, uint32_t c, uint32_t &be2) -> bool { return trial_packed<false>(t, a, bb, c, active, p.maxPixel32, blockLimit, be2); };
+                search_accurate(T, shift);
+              }
             }
           }
           else
@@ -784,10 +976,10 @@ namespace limg_hip
 #pragma unroll
             for (int c = 0; c < 3; c++)
             {
-              r.nA[c] = rec[4 + c] - rec[c]; r.nB[c] = rec[12 + c] - rec[8 + c]; r.nC[c] = rec[20 + c] - rec[16 + c];
-              r.mA[c] = (int)(((uint32_t)rec[c] << 8) + 128u); r.mB[c] = (int)(((uint32_t)rec[8 + c] << 8) + 128u); r.mC[c] = (int)(((uint32_t)rec[16 + c] << 8) + 128u);
+              r.nA[c] = sgpr(rhi[0][c] - rlo[0][c]); r.nB[c] = sgpr(rhi[1][c] - rlo[1][c]); r.nC[c] = sgpr(rhi[2][c] - rlo[2][c]);
+              r.mA[c] = sgpr((int)(((uint32_t)rlo[0][c] << 8) + 128u)); r.mB[c] = sgpr((int)(((uint32_t)rlo[1][c] << 8) + 128u)); r.mC[c] = sgpr((int)(((uint32_t)rlo[2][c] << 8) + 128u));
             }
-            auto T = [&](uint32_t a, uint32_t bb, uint32_t c, uint32_t &be) -> bool { return trial(px, fA, fB, fC, r, a, bb, c, active, p.maxPixel32, maxBlockN, be); };
+            auto T = [&](uint32_t a, uint32_t bb, uint32_t c, uint32_t &be2) -> bool { return trial(px, fA, fB, fC, r, a, bb, c, active, p.maxPixel32, maxBlockN, be2); };
             if (p.fast) search_fast(T, shift);
             else search_accurate(T, shift);
           }
@@ -799,18 +991,8 @@ namespace limg_hip
 
         const size_t bi = (size_t)by * p.blocksX + bx;
         if (lane == 0) p.shifts[bi] = shift[0] | (shift[1] << 8) | (shift[2] << 16) | (calls << 24);
-        if (p.records && lane < 16)
-        {
-          uint32_t w;
-          if (lane < 4) w = __float_as_uint(blk[b].avg[lane]);
-          else w = reinterpret_cast<const uint32_t *>(blk[b].rec)[lane - 4];
-          reinterpret_cast<uint32_t *>(p.records + bi)[lane] = w;
-        }
         if (p.storePlanes && active)
         {
-          uint32_t lx, ly;
-          if (rx == 8) { lx = lane & 7; ly = lane >> 3; }
-          else { ly = (uint32_t)lane / rx; lx = (uint32_t)lane - ly * rx; }
           const uint32_t o = ly * 256 + sb * kBlock + lx;
           stage[o] = (uint8_t)fA; stage[2048 + o] = (uint8_t)fB; stage[4096 + o] = (uint8_t)fC;
         }

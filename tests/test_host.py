@@ -109,3 +109,49 @@ def test_partition_rule(lib, size_y, pool):
             yr = ((size_y // 8) // tc) * 8
         want = (tc, yr // 8) if yr else (1, 0)
     assert (cc.value, rr.value) == want
+
+
+def test_search_automaton_replays_reference_searches():
+    """The generated decision table (tools/make_search_table.py) driven by the real reference's trial outcomes
+    (tests/golden/blocks.npz: all 729 shift triples per block) ends at the real reference's search result."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_search_table as mst
+    words = mst.encode(mst.build())
+    hdr = open(os.path.join(ROOT, "limg_amd", "csrc", "limg_search_table.h")).read()
+    assert "LIMG_SEARCH_STATES %d" % len(words) in hdr
+    assert all("{0x%08xu, 0x%08xu}" % w in hdr for w in words[:50] + words[-50:])
+    z = gu.blocks()
+    for bi in range(int(z["count"])):
+        for ch in (4, 3):
+            p = "b%02d_%d_" % (bi, ch)
+            t = z[p + "trials"]
+            shift, n = mst.walk(words, lambda a, b, c: bool(t[a, b, c, 0]))
+            assert list(shift) == z[p + "search_100_1"].tolist(), p
+
+
+def test_search_automaton_equals_oracle_on_random_outcomes(oracle):
+    """Random pass/fail oracles: the table and a literal re-run of the generator agree (exhaustive merge is sound)."""
+    import random
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_search_table as mst
+    words = mst.encode(mst.build())
+    rnd = random.Random(5)
+    for _ in range(2000):
+        pr = rnd.random()
+        memo = {}
+
+        def outcome(a, b, c):
+            if (a, b, c) not in memo:
+                memo[(a, b, c)] = rnd.random() < pr
+            return memo[(a, b, c)]
+        got, _n = mst.walk(words, outcome)
+        g = mst.search_fast()
+        try:
+            t = next(g)
+            while True:
+                t = g.send(outcome(*t))
+        except StopIteration as e:
+            want = e.value
+        assert got == want
