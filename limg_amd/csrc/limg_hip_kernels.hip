@@ -1072,65 +1072,117 @@ namespace limg_hip
     }
 
     // =====================================================================================================================
-    // kernel 3: dither (a13), plane stores (a15), decode (a16)
+    // phase F / kernel 3: dither (a13), plane stores (a15), decode (a16) for one work strip
     // =====================================================================================================================
-    template <int CH>
-    __global__ __launch_bounds__(kThreads) void k_dither_store(const EncodeParams p)
+
+    // LDS areas of phase F.  In the fused kernel they overlay the (then dead) parked-contribution area of k_fit_search.
+    struct StripLds
     {
-      __shared__ __attribute__((aligned(16))) uint8_t s_fac[3 * 8 * 256];       // pre-dither factor bytes of the strip
-      __shared__ __attribute__((aligned(16))) uint32_t s_dec[kWaves][8 * 64];   // decoded pixels, per wave [row][64]
-      __shared__ __attribute__((aligned(16))) uint8_t s_out[kWaves][3][8 * 64]; // output factor bytes, per wave [plane][row][64]
-      __shared__ uint32_t s_cst[7][kStripBlocks];                               // per-block constants of the 7 uniform planes
-      __shared__ uint32_t s_shift[kStripBlocks];
-      __shared__ uint32_t s_first[kStripBlocks];                                // first dither-call index of each block
+      uint8_t *fac;    // [3][8][256]  pre-dither factor bytes of the strip (plane-row layout)
+      uint32_t *dec;   // [4 waves][8 rows][64]  decoded pixels
+      uint8_t *out;    // [4 waves][3][8 rows][64]  output factor bytes
+      uint32_t *cst;   // [7][32]  per-block constants of the 7 block-uniform planes
+      int32_t *nm;     // [32 blocks][2][3][4]  effective integer normals / additive constants of the decode
+      uint32_t *shift; // [32]  shift words
+      uint32_t *first; // [32]  first dither-call index of each block
+      const int16_t *rec; // record of block sb at rec + sb * recStride
+      int recStride;
+    };
+    constexpr int kPhaseFBytes = 6144 + 8192 + 6144 + 896 + 3072 + 128 + 128;
 
-      const int tid = (int)threadIdx.x;
-      const int lane = tid & 63, wave = tid >> 6;
-      const uint32_t strip = blockIdx.x % p.stripsX, by = blockIdx.x / p.stripsX;
-      const uint32_t x0 = strip * (kStripBlocks * kBlock), y0 = by * kBlock;
-      const uint32_t stripW = min(p.sizeX - x0, (uint32_t)(kStripBlocks * kBlock));
-      const uint32_t ry = min(p.sizeY - y0, (uint32_t)kBlock);
-      const uint32_t nBlocks = min(p.blocksX - strip * kStripBlocks, (uint32_t)kStripBlocks);
-      const uint8_t *planesIn[3] = { p.info.pFactorsA, p.info.pFactorsB, p.info.pFactorsC };
+    __device__ __forceinline__ StripLds carve_phase_f(uint8_t *base, const int16_t *rec, int recStride)
+    {
+      StripLds L;
+      L.fac = base;
+      L.dec = reinterpret_cast<uint32_t *>(base + 6144);
+      L.out = base + 6144 + 8192;
+      L.cst = reinterpret_cast<uint32_t *>(base + 6144 + 8192 + 6144);
+      L.nm = reinterpret_cast<int32_t *>(base + 6144 + 8192 + 6144 + 896);
+      L.shift = reinterpret_cast<uint32_t *>(base + 6144 + 8192 + 6144 + 896 + 3072);
+      L.first = L.shift + 32;
+      L.rec = rec; L.recStride = recStride;
+      return L;
+    }
 
-      if ((p.sizeX & 15u) == 0)
+    // Per-wave preparation from records + shifts (lane-parallel over the wave's 8 blocks): the 7 block-uniform plane values
+    // (src/limg.cpp:2006-2036) and the effective decode constants (src/limg_decode.h:139-196 / :40-101).
+    template <int CH>
+    __device__ __forceinline__ void phase_f_prepare(const StripLds &L, int lane, int wave)
+    {
+      if (lane < 56)
       {
-        for (int i = tid; i < 384; i += kThreads)
+        const int b = lane / 7, k = lane - b * 7, sb = wave * kBlocksPerWave + b;
+        const int16_t *rec = L.rec + sb * L.recStride;
+        uint32_t v;
+        if (k == 0)
         {
-          const int pl = i >> 7, row = (i & 127) >> 4, col = (i & 15) * 16;
-          if ((uint32_t)row < ry && (uint32_t)col < stripW)
-            *reinterpret_cast<uint4 *>(s_fac + pl * 2048 + row * 256 + col) = *reinterpret_cast<const uint4 *>(planesIn[pl] + (size_t)(y0 + row) * p.sizeX + x0 + col);
+          const uint32_t w = L.shift[sb];
+          const uint32_t pat[3] = { (w & 0xFF), ((w >> 8) & 0xFF), ((w >> 16) & 0xFF) };
+          // bit_to_pattern {0,0x22,...,0xEE,0xFF}: 0x22 * s, except s == 8 -> 0xFF
+          const uint32_t pa = pat[0] == 8 ? 0xFFu : pat[0] * 0x22u, pb = pat[1] == 8 ? 0xFFu : pat[1] * 0x22u, pc = pat[2] == 8 ? 0xFFu : pat[2] * 0x22u;
+          v = 0xFF000000u | (pa << 16) | (pb << 8) | pc;
         }
-      }
-      else
-      {
-        for (int i = tid; i < 3 * 2048; i += kThreads)
+        else
         {
-          const int pl = i >> 11, row = (i & 2047) >> 8, col = i & 255;
-          if ((uint32_t)row < ry && (uint32_t)col < stripW) s_fac[i] = planesIn[pl][(size_t)(y0 + row) * p.sizeX + x0 + col];
-        }
-      }
-      if (wave == 0)
-      {
-        // shifts + exclusive prefix of the calls of the strip's blocks (32 lanes)
-        uint32_t w = 0;
-        if ((uint32_t)lane < nBlocks) w = p.shifts[(size_t)by * p.blocksX + strip * kStripBlocks + lane];
-        const uint32_t calls = w >> 24;
-        uint32_t incl = calls;
+          v = 0;
 #pragma unroll
-        for (int off = 1; off < 32; off <<= 1)
-        {
-          const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
-          if (lane >= off) incl += up;
+          for (int c = 0; c < CH; c++)
+          {
+            int q = rec[(k - 1) * 4 + c] + (k >= 3 ? 0x80 : 0);
+            q = q < 0 ? 0 : (q > 255 ? 255 : q);
+            v |= (uint32_t)q << (8 * c);
+          }
+          if (CH == 3) v |= 0xFF000000u;
         }
-        if (lane < kStripBlocks)
+        L.cst[k * kStripBlocks + sb] = v;
+      }
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+      {
+        const int idx = r * 64 + lane;
+        if (idx < 96)
         {
-          s_shift[lane] = w;
-          s_first[lane] = p.stripBase[(size_t)by * p.stripsX + strip] + incl - calls;
+          const int b = idx / 12, fc = idx - b * 12, f = fc >> 2, c = fc & 3, sb = wave * kBlocksPerWave + b;
+          const int16_t *rec = L.rec + sb * L.recStride;
+          const uint32_t sh = (L.shift[sb] >> (8 * f)) & 0xFF;
+          int n = rec[f * 8 + 4 + c] - rec[f * 8 + c], m = rec[f * 8 + c];
+          if (c < 3)
+          {
+            if (sh > 7) { n = 0; if (f > 0) m = 0; }
+          }
+          else if (CH == 3) { n = 0; m = 0xFFFF; }
+          int *dst = L.nm + sb * 24;
+          dst[f * 4 + c] = n;
+          dst[12 + f * 4 + c] = (int)(((uint32_t)m << 8) + 128u);
         }
       }
-      __syncthreads();
+    }
 
+    // the 7 block-uniform planes: 256 contiguous bytes (8 blocks x 8 px) per store instruction, straight from registers
+    __device__ __forceinline__ void phase_f_store_const(const EncodeParams &p, const StripLds &L, uint32_t x0, uint32_t y0, uint32_t ry, int lane, int wave)
+    {
+      const uint32_t wx0 = x0 + wave * 64;
+      if (wx0 >= p.sizeX) return;
+      const uint32_t ww = min(p.sizeX - wx0, 64u);
+      uint32_t *planes[7] = { p.info.pShiftABCX, p.info.pColAMin, p.info.pColAMax, p.info.pColBMin, p.info.pColBMax, p.info.pColCMin, p.info.pColCMax };
+      uint32_t cst[7];
+#pragma unroll
+      for (int k = 0; k < 7; k++) cst[k] = L.cst[k * kStripBlocks + wave * kBlocksPerWave + (lane >> 3)];
+      if ((uint32_t)lane < ww)
+        for (uint32_t row = 0; row < ry; row++)
+        {
+          const size_t g = (size_t)(y0 + row) * p.sizeX + wx0 + lane;
+#pragma unroll
+          for (int k = 0; k < 7; k++) planes[k][g] = cst[k];
+        }
+    }
+
+    // dither + decode of the wave's 8 blocks into the per-wave staging areas, then the per-pixel planes' stores
+    template <int CH>
+    __device__ __forceinline__ void phase_f_pixels(const EncodeParams &p, const StripLds &L, uint32_t strip, uint32_t x0, uint32_t y0, uint32_t ry, int lane, int wave)
+    {
+      uint32_t *dec = L.dec + wave * 512;
+      uint8_t *out = L.out + wave * 1536;
       for (int b = 0; b < kBlocksPerWave; b++)
       {
         const uint32_t sb = wave * kBlocksPerWave + b;
@@ -1142,15 +1194,15 @@ namespace limg_hip
         if (rx == 8) { lx = lane & 7; ly = lane >> 3; }
         else { const uint32_t l = active ? (uint32_t)lane : 0u; ly = l / rx; lx = l - ly * rx; }
         const uint32_t o = ly * 256 + sb * kBlock + lx;
-        const uint32_t w = (uint32_t)sgpr((int)s_shift[sb]);
+        const uint32_t w = (uint32_t)sgpr((int)L.shift[sb]);
         const uint32_t shift[3] = { w & 0xFF, (w >> 8) & 0xFF, (w >> 16) & 0xFF };
-        uint32_t call = (uint32_t)sgpr((int)s_first[sb]);
+        uint32_t call = (uint32_t)sgpr((int)L.first[sb]);
 
         uint32_t f[3];
 #pragma unroll
         for (int k = 0; k < 3; k++)
         {
-          uint32_t v = s_fac[k * 2048 + o];
+          uint32_t v = L.fac[k * 2048 + o];
           const uint32_t s = shift[k];
           if (s != 0 && s != 8)
           { // src/limg.cpp:824-879: (lane16 & ditherSize) - ditherOffset, add, clamp, shift
@@ -1163,111 +1215,127 @@ namespace limg_hip
           f[k] = v;
         }
 
-        const limg_hip_block_record *rec = p.records + (size_t)by * p.blocksX + bx;
-        int r16[24];
-        {
-          const uint32_t *rw = reinterpret_cast<const uint32_t *>(rec) + 4;
-#pragma unroll
-          for (int i = 0; i < 12; i++)
-          {
-            const uint32_t d = (uint32_t)sgpr((int)rw[i]);
-            r16[2 * i] = (int)(int16_t)(d & 0xFFFF); r16[2 * i + 1] = (int)(int16_t)(d >> 16);
-          }
-        }
-        // decode, src/limg_decode.h:137-236 / :36-135
-        const uint32_t dA = f[0] * shift_mul(shift[0]), dB = f[1] * shift_mul(shift[1]), dC = f[2] * shift_mul(shift[2]);
+        // decode: dec_k = byte * mul_k, est_c = sum_k (dec_k * n_k[c] + m_k[c]) >> 8, clamp.  24-bit multiplies are exact here:
+        // dec <= 255 * 256 and |n| <= 65535 (difference of two int16), and v_mad_i32_i24 keeps the low 32 bits like PMULLD.
+        const int *nm = L.nm + sb * 24;
         uint32_t decoded = 0;
+        const int dA = (int)(f[0] * shift_mul(shift[0])), dB = (int)(f[1] * shift_mul(shift[1])), dC = (int)(f[2] * shift_mul(shift[2]));
+        const int4 nA = *reinterpret_cast<const int4 *>(nm), nB = *reinterpret_cast<const int4 *>(nm + 4), nC = *reinterpret_cast<const int4 *>(nm + 8);
+        const int4 mA = *reinterpret_cast<const int4 *>(nm + 12), mB = *reinterpret_cast<const int4 *>(nm + 16), mC = *reinterpret_cast<const int4 *>(nm + 20);
+        const int nAa[4] = { nA.x, nA.y, nA.z, nA.w }, nBa[4] = { nB.x, nB.y, nB.z, nB.w }, nCa[4] = { nC.x, nC.y, nC.z, nC.w };
+        const int mAa[4] = { mA.x, mA.y, mA.z, mA.w }, mBa[4] = { mB.x, mB.y, mB.z, mB.w }, mCa[4] = { mC.x, mC.y, mC.z, mC.w };
 #pragma unroll
         for (int c = 0; c < 4; c++)
         {
-          int nA = r16[4 + c] - r16[c], nB = r16[12 + c] - r16[8 + c], nC = r16[20 + c] - r16[16 + c];
-          int mA = r16[c], mB = r16[8 + c], mC = r16[16 + c];
-          if (c < 3)
-          {
-            if (shift[0] > 7) nA = 0;
-            if (shift[1] > 7) { nB = 0; mB = 0; }
-            if (shift[2] > 7) { nC = 0; mC = 0; }
-          }
-          else if (CH == 3) { nA = nB = nC = 0; mA = mB = mC = 0xFFFF; }
-          int est = ((int)(dA * (uint32_t)nA + (((uint32_t)mA << 8) + 128u)) >> 8) + ((int)(dB * (uint32_t)nB + (((uint32_t)mB << 8) + 128u)) >> 8) +
-                    ((int)(dC * (uint32_t)nC + (((uint32_t)mC << 8) + 128u)) >> 8);
+          int est = (mad_i24(dA, nAa[c], mAa[c]) >> 8) + (mad_i24(dB, nBa[c], mBa[c]) >> 8) + (mad_i24(dC, nCa[c], mCa[c]) >> 8);
           est = est < 0 ? 0 : (est > 255 ? 255 : est);
           decoded |= (uint32_t)est << (8 * c);
         }
         if (active)
         {
           const uint32_t wo = ly * 64 + b * kBlock + lx;
-          s_dec[wave][wo] = decoded;
+          dec[wo] = decoded;
 #pragma unroll
-          for (int k = 0; k < 3; k++) s_out[wave][k][wo] = (uint8_t)(f[k] << shift[k]); // shift 8 => 0 (src/limg.cpp:2054-2062)
-        }
-        if (lane == 0)
-        {
-          const uint32_t pat[9] = { 0, 0x22, 0x44, 0x66, 0x88, 0xAA, 0xCC, 0xEE, 0xFF };
-          s_cst[0][sb] = 0xFF000000u | (pat[shift[0]] << 16) | (pat[shift[1]] << 8) | pat[shift[2]];
-        }
-        if (lane < 6)
-        { // colour planes, src/limg.cpp:2018-2036
-          uint32_t col = 0;
-#pragma unroll
-          for (int c = 0; c < CH; c++)
-          {
-            int v = r16[lane * 4 + c] + (lane >= 2 ? 0x80 : 0);
-            v = v < 0 ? 0 : (v > 255 ? 255 : v);
-            col |= (uint32_t)v << (8 * c);
-          }
-          if (CH == 3) col |= 0xFF000000u;
-          s_cst[1 + lane][sb] = col;
+          for (int k = 0; k < 3; k++) out[k * 512 + wo] = (uint8_t)(f[k] << shift[k]); // shift 8 => 0 (src/limg.cpp:2054-2062)
         }
       }
       wave_lds_fence();
 
-      // ---- stores.  Each wave owns a 64-px wide column of the strip ----------------------------------------------------
       const uint32_t wx0 = x0 + wave * 64;
-      if (wx0 < p.sizeX)
-      {
-        const uint32_t ww = min(p.sizeX - wx0, 64u);
-        uint32_t *planes32[8] = { p.info.pDecoded, p.info.pShiftABCX, p.info.pColAMin, p.info.pColAMax, p.info.pColBMin, p.info.pColBMax, p.info.pColCMin, p.info.pColCMax };
-        uint8_t *planes8[3] = { p.info.pFactorsA, p.info.pFactorsB, p.info.pFactorsC };
-        const bool in = (uint32_t)lane < ww;
-        uint32_t cst[7];
+      if (wx0 >= p.sizeX) return;
+      const uint32_t ww = min(p.sizeX - wx0, 64u);
+      uint8_t *planes8[3] = { p.info.pFactorsA, p.info.pFactorsB, p.info.pFactorsC };
+      if ((uint32_t)lane < ww)
+        for (uint32_t row = 0; row < ry; row++) p.info.pDecoded[(size_t)(y0 + row) * p.sizeX + wx0 + lane] = dec[row * 64 + lane];
+      if ((p.sizeX & 3u) == 0)
+      { // 4 bytes per lane: lane -> (row = lane >> 4, 4-px chunk = lane & 15), two passes cover 8 rows
 #pragma unroll
-        for (int k = 0; k < 7; k++) cst[k] = s_cst[k][wave * kBlocksPerWave + (lane >> 3)];
-        for (uint32_t row = 0; row < ry; row++)
+        for (int pass = 0; pass < 2; pass++)
         {
-          const size_t g = (size_t)(y0 + row) * p.sizeX + wx0 + lane;
-          if (in)
+          const uint32_t row = pass * 4 + (lane >> 4), ch = (lane & 15) * 4;
+          if (row < ry && ch < ww)
           {
-            planes32[0][g] = s_dec[wave][row * 64 + lane];
+            const size_t g = (size_t)(y0 + row) * p.sizeX + wx0 + ch;
 #pragma unroll
-            for (int k = 0; k < 7; k++) planes32[1 + k][g] = cst[k];
+            for (int k = 0; k < 3; k++) *reinterpret_cast<uint32_t *>(planes8[k] + g) = *reinterpret_cast<const uint32_t *>(&out[k * 512 + row * 64 + ch]);
           }
-        }
-        if ((p.sizeX & 3u) == 0)
-        { // 4 bytes per lane: lane -> (row = lane >> 4, 4-px chunk = lane & 15), two passes cover 8 rows
-#pragma unroll
-          for (int pass = 0; pass < 2; pass++)
-          {
-            const uint32_t row = pass * 4 + (lane >> 4), ch = (lane & 15) * 4;
-            if (row < ry && ch < ww)
-            {
-              const size_t g = (size_t)(y0 + row) * p.sizeX + wx0 + ch;
-#pragma unroll
-              for (int k = 0; k < 3; k++) *reinterpret_cast<uint32_t *>(planes8[k] + g) = *reinterpret_cast<const uint32_t *>(&s_out[wave][k][row * 64 + ch]);
-            }
-          }
-        }
-        else
-        {
-          for (uint32_t row = 0; row < ry; row++)
-            if (in)
-            {
-              const size_t g = (size_t)(y0 + row) * p.sizeX + wx0 + lane;
-#pragma unroll
-              for (int k = 0; k < 3; k++) planes8[k][g] = s_out[wave][k][row * 64 + lane];
-            }
         }
       }
+      else
+      {
+        for (uint32_t row = 0; row < ry; row++)
+          if ((uint32_t)lane < ww)
+          {
+            const size_t g = (size_t)(y0 + row) * p.sizeX + wx0 + lane;
+#pragma unroll
+            for (int k = 0; k < 3; k++) planes8[k][g] = out[k * 512 + row * 64 + lane];
+          }
+      }
+    }
+
+    // exclusive prefix of the dither-call counts of the strip's 32 blocks (wave 0), on top of the strip's base
+    __device__ __forceinline__ void phase_f_first_calls(const StripLds &L, uint32_t base, int lane)
+    {
+      const uint32_t w = lane < kStripBlocks ? L.shift[lane] : 0u;
+      const uint32_t calls = w >> 24;
+      uint32_t incl = calls;
+#pragma unroll
+      for (int off = 1; off < 32; off <<= 1)
+      {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+        if (lane >= off) incl += up;
+      }
+      if (lane < kStripBlocks) L.first[lane] = base + incl - calls;
+    }
+
+    template <int CH>
+    __global__ __launch_bounds__(kThreads) void k_dither_store(const EncodeParams p)
+    {
+      __shared__ __attribute__((aligned(16))) uint8_t s_f[kPhaseFBytes];
+      __shared__ __attribute__((aligned(16))) int16_t s_rec[kStripBlocks][24];
+
+      const int tid = (int)threadIdx.x;
+      const int lane = tid & 63, wave = tid >> 6;
+      const uint32_t strip = blockIdx.x % p.stripsX, by = blockIdx.x / p.stripsX;
+      const uint32_t x0 = strip * (kStripBlocks * kBlock), y0 = by * kBlock;
+      const uint32_t stripW = min(p.sizeX - x0, (uint32_t)(kStripBlocks * kBlock));
+      const uint32_t ry = min(p.sizeY - y0, (uint32_t)kBlock);
+      const uint32_t nBlocks = min(p.blocksX - strip * kStripBlocks, (uint32_t)kStripBlocks);
+      const uint8_t *planesIn[3] = { p.info.pFactorsA, p.info.pFactorsB, p.info.pFactorsC };
+      const StripLds L = carve_phase_f(s_f, &s_rec[0][0], 24);
+
+      if ((p.sizeX & 15u) == 0)
+      {
+        for (int i = tid; i < 384; i += kThreads)
+        {
+          const int pl = i >> 7, row = (i & 127) >> 4, col = (i & 15) * 16;
+          if ((uint32_t)row < ry && (uint32_t)col < stripW)
+            *reinterpret_cast<uint4 *>(L.fac + pl * 2048 + row * 256 + col) = *reinterpret_cast<const uint4 *>(planesIn[pl] + (size_t)(y0 + row) * p.sizeX + x0 + col);
+        }
+      }
+      else
+      {
+        for (int i = tid; i < 3 * 2048; i += kThreads)
+        {
+          const int pl = i >> 11, row = (i & 2047) >> 8, col = i & 255;
+          if ((uint32_t)row < ry && (uint32_t)col < stripW) L.fac[i] = planesIn[pl][(size_t)(y0 + row) * p.sizeX + x0 + col];
+        }
+      }
+      // records (12 dwords of int16 per block) and shift words
+      for (int i = tid; i < kStripBlocks * 12; i += kThreads)
+      {
+        const int sb = i / 12, w = i - sb * 12;
+        uint32_t v = 0;
+        if ((uint32_t)sb < nBlocks) v = reinterpret_cast<const uint32_t *>(p.records + (size_t)by * p.blocksX + strip * kStripBlocks + sb)[4 + w];
+        reinterpret_cast<uint32_t *>(&s_rec[sb][0])[w] = v;
+      }
+      if (tid < kStripBlocks) L.shift[tid] = (uint32_t)tid < nBlocks ? p.shifts[(size_t)by * p.blocksX + strip * kStripBlocks + tid] : 0u;
+      __syncthreads();
+      if (wave == 0) phase_f_first_calls(L, p.stripBase[(size_t)by * p.stripsX + strip], lane);
+      phase_f_prepare<CH>(L, lane, wave);
+      __syncthreads();
+      phase_f_store_const(p, L, x0, y0, ry, lane, wave);
+      phase_f_pixels<CH>(p, L, strip, x0, y0, ry, lane, wave);
     }
   } // namespace
 
