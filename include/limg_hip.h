@@ -59,7 +59,8 @@ typedef struct limg_hip_compact_out
 typedef struct limg_hip_options
 {
   int32_t forced_shift[3]; /* all three in 0..8: bypass the shift search (a10-a12) with this triple; otherwise {-1,-1,-1} */
-  int32_t reserved[5];
+  int32_t force_split_kernels; /* non-0: use the three-launch path (fit+search, scan, dither+store) even where the fused kernel applies */
+  int32_t reserved[4];
 } limg_hip_options;
 
 typedef struct limg_hip_context limg_hip_context;
@@ -99,6 +100,10 @@ double limg_hip_compare_device(limg_hip_context *pCtx, const uint32_t *pImageA, 
  * (y0, fullWidth) let a rank generate only its row strip of a larger image. */
 limg_hip_result limg_hip_synth_random_gradient_device(uint32_t *pOut, size_t width, size_t height, uint64_t seed, int opaque, size_t y0, void *stream);
 limg_hip_result limg_hip_synth_photo_noise_device(uint32_t *pOut, size_t width, size_t height, uint64_t seed, size_t y0, void *stream);
+
+/* Waits for the device and returns limg_hip_error_Generic if the fused kernel's bounded look-back spin ever timed out
+ * (protocol safety net; the host-pointer entry points call it themselves). */
+limg_hip_result limg_hip_check_device_status(limg_hip_context *pCtx);
 
 /* Per-kernel timing for the bench (HIP events recorded on the stream each profiled encode is launched on).
  * limg_hip_profile_end writes 3 floats per profiled encode: k_fit_search, k_strip_scan (or the host chain walk of ragged

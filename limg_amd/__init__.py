@@ -21,7 +21,7 @@ ABI_SYMBOLS = (
     "limg_hip_init", "limg_hip_shutdown", "limg_hip_default_options", "limg_hip_set_options", "limg_hip_encode3d", "limg_hip_encode3d_perf",
     "limg_hip_encode3d_device", "limg_hip_compare", "limg_hip_compare_device", "limg_hip_synth_random_gradient_device",
     "limg_hip_synth_photo_noise_device", "limg_hip_context_device_bytes", "limg_hip_version", "limg_hip_profile_begin", "limg_hip_profile_end",
-    "limg_hip_host_noise_table", "limg_hip_host_chain_call", "limg_hip_host_partition",
+    "limg_hip_host_noise_table", "limg_hip_host_chain_call", "limg_hip_host_partition", "limg_hip_check_device_status",
 )
 
 RECORD_DTYPE = np.dtype([("avg", "<f4", 4), ("dirA_min", "<i2", 4), ("dirA_max", "<i2", 4), ("dirB_offset", "<i2", 4),
@@ -41,7 +41,7 @@ class CompactOut(C.Structure):
 
 
 class Options(C.Structure):
-    _fields_ = [("forced_shift", C.c_int32 * 3), ("reserved", C.c_int32 * 5)]
+    _fields_ = [("forced_shift", C.c_int32 * 3), ("force_split_kernels", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 def load_library(path=None):
@@ -81,6 +81,8 @@ def load_library(path=None):
     L.limg_hip_profile_begin.argtypes = [C.c_void_p]
     L.limg_hip_profile_end.restype = C.c_int
     L.limg_hip_profile_end.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.limg_hip_check_device_status.restype = C.c_int
+    L.limg_hip_check_device_status.argtypes = [C.c_void_p]
     L.limg_hip_host_noise_table.restype = C.c_int
     L.limg_hip_host_noise_table.argtypes = [C.c_void_p, C.c_size_t]
     L.limg_hip_host_chain_call.restype = C.c_uint64
@@ -121,13 +123,18 @@ class LimgHip:
         except Exception:
             pass
 
-    def set_forced_shift(self, shift=None):
+    def set_options(self, forced_shift=None, force_split=False, dbg=0):
         o = Options()
         self.lib.limg_hip_default_options(C.byref(o))
-        if shift is not None:
+        if forced_shift is not None:
             for i in range(3):
-                o.forced_shift[i] = int(shift[i])
+                o.forced_shift[i] = int(forced_shift[i])
+        o.force_split_kernels = int(force_split)
+        o.reserved[0] = int(dbg)
         _check(self.lib.limg_hip_set_options(self.ctx, C.byref(o)), "limg_hip_set_options")
+
+    def set_forced_shift(self, shift=None):
+        self.set_options(forced_shift=shift)
 
     # ---- host pointers (drop-in for limg_encode3d_test / _perf / limg_compare) ---------------------------------------------
     def encode3d(self, img, has_alpha, error_factor=100, pool_threads=0, fast=True):
@@ -191,6 +198,9 @@ class LimgHip:
         else:
             raise ValueError(kind)
         return out
+
+    def check(self):
+        _check(self.lib.limg_hip_check_device_status(self.ctx), "limg_hip_check_device_status")
 
     def profile_begin(self):
         _check(self.lib.limg_hip_profile_begin(self.ctx), "limg_hip_profile_begin")

@@ -53,9 +53,13 @@ struct limg_hip_context
   size_t noiseCount = 0;                         // entries generated so far
   uint64_t noiseNext = kDitherSeed;              // chain value after the last generated entry
   DevBuf noiseDyn;                               // data-dependent chains (images with partial blocks)
+  DevBuf park;                                   // persistent kernel: 2 x 8 KiB per workgroup
+  DevBuf lookback;                               // fused path: ticket + timeout flag (16 B) then one 8-byte descriptor per work strip
   DevBuf in, planes;                             // staging for the host-pointer entry points
   DevBuf cmp;                                    // 8-byte accumulator of limg_hip_compare
   // optional per-kernel timing (bench): 4 events per encode, recorded on the caller's stream, read back in one go
+  int persistentWorkgroups = 768; // 3 per CU (LDS-limited), set from the device's CU count at init
+  bool forceSplit = false; // options: run the three-kernel path even where the fused kernel applies (A/B, tests)
   bool profiling = false;
   std::vector<hipEvent_t> events;
   size_t eventsUsed = 0;
@@ -176,6 +180,25 @@ namespace
       p.noise = (const uint8_t *)c->noise.p;
     }
 
+    const bool fused = dInfo != nullptr && !ragged && !c->forceSplit;
+    if (fused)
+    {
+      // one launch does everything: zero the look-back words, go
+      if ((r = c->lookback.ensure(16 + strips * 8)) != limg_hip_success) return r;
+      HIP_TRY(hipMemsetAsync(c->lookback.p, 0, 16 + strips * 8, stream));
+      p.ticket = (uint32_t *)c->lookback.p;
+      p.desc = (unsigned long long *)((uint8_t *)c->lookback.p + 16);
+      p.dbg = c->opt.reserved[0];
+      p.compactOut = compact != nullptr;
+      if ((r = c->park.ensure((size_t)c->persistentWorkgroups * 2 * 8192)) != limg_hip_success) return r;
+      p.park = (uint8_t *)c->park.p;
+      mark(c, stream);
+      launch_encode_persistent(p, channels, c->persistentWorkgroups, stream);
+      mark(c, stream); mark(c, stream); mark(c, stream);
+      HIP_TRY(hipGetLastError());
+      return limg_hip_success;
+    }
+
     mark(c, stream);
     launch_fit_search(p, channels, stream);
     mark(c, stream);
@@ -255,6 +278,8 @@ extern "C"
     limg_hip_context *c = new (std::nothrow) limg_hip_context();
     if (!c) return limg_hip_error_MemoryAllocationFailure;
     c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->persistentWorkgroups = 3 * prop.multiProcessorCount;
     limg_hip_default_options(&c->opt);
     *ppCtx = c;
     return limg_hip_success;
@@ -266,7 +291,7 @@ extern "C"
     limg_hip_context *c = *ppCtx;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = { &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->in, &c->planes, &c->cmp };
+    DevBuf *bufs[] = { &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->lookback, &c->park, &c->in, &c->planes, &c->cmp };
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     delete c;
@@ -277,6 +302,27 @@ extern "C"
   {
     if (!c || !o) return limg_hip_error_ArgumentNull;
     c->opt = *o;
+    c->forceSplit = o->force_split_kernels != 0;
+    return limg_hip_success;
+  }
+
+  // Blocks until the device is idle and reports a look-back timeout of the fused kernel (never observed; the spin is bounded so
+  // that a protocol bug could not hang the GPU) as limg_hip_error_Generic.
+  limg_hip_result limg_hip_check_device_status(limg_hip_context *c)
+  {
+    if (!c) return limg_hip_error_ArgumentNull;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (c->lookback.p)
+    {
+      uint32_t words[2] = { 0, 0 };
+      HIP_TRY(hipMemcpy(words, c->lookback.p, 8, hipMemcpyDeviceToHost));
+      if (words[1] != 0)
+      {
+        fprintf(stderr, "limg_hip: look-back timeout in the fused encode kernel\n");
+        return limg_hip_error_Generic;
+      }
+    }
     return limg_hip_success;
   }
 
@@ -332,7 +378,7 @@ extern "C"
   size_t limg_hip_context_device_bytes(const limg_hip_context *c)
   {
     if (!c) return 0;
-    return c->records.cap + c->shifts.cap + c->stripCalls.cap + c->stripBase.cap + c->noise.cap + c->noiseDyn.cap + c->in.cap + c->planes.cap + c->cmp.cap;
+    return c->records.cap + c->shifts.cap + c->stripCalls.cap + c->stripBase.cap + c->noise.cap + c->noiseDyn.cap + c->lookback.cap + c->park.cap + c->in.cap + c->planes.cap + c->cmp.cap;
   }
 
   limg_hip_result limg_hip_encode3d_device(limg_hip_context *c, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, const limg_hip_encode3d_info *pInfo,
@@ -366,7 +412,7 @@ extern "C"
       off = (off + 255) & ~(size_t)255;
     }
     if ((r = encode_device(c, (const uint32_t *)c->in.p, sizeX, sizeY, hasAlpha, &d, nullptr, errorFactor, poolThreads, fastBitCrushing, nullptr)) != limg_hip_success) return r;
-    HIP_TRY(hipDeviceSynchronize());
+    if ((r = limg_hip_check_device_status(c)) != limg_hip_success) return r;
     for (int i = 0; i < 11; i++) HIP_TRY(hipMemcpy(hp[i], dp[i], i < 8 ? px * 4 : px, hipMemcpyDeviceToHost));
     return limg_hip_success;
   }

@@ -34,9 +34,16 @@ namespace limg_hip
     int32_t storePlanes;   // 0: _perf behaviour
     // dither noise: byte p of call k = low byte of the 16-bit lane the reference ANDs with ditherSize for pixel p
     const uint8_t *noise;
+    // fused single-kernel path: per-strip look-back descriptors (status << 32 | value), work ticket, error word
+    unsigned long long *desc;
+    uint32_t *ticket;   // [0] = next strip id, [1] = look-back timeout flag
+    uint8_t *park;      // persistent kernel: per workgroup two 8 KiB slots holding a strip's parked results between its E and F steps
+    int32_t compactOut; // persistent kernel: also write records / shift words to the raster-order arrays
+    int32_t dbg;        // timing experiments only (limg_hip_options.reserved[0]): 1 = no look-back, 2 = no pixel phase, 4 = no const stores
   };
 
   void launch_fit_search(const EncodeParams &p, int channels, hipStream_t s);
+  void launch_encode_persistent(const EncodeParams &p, int channels, int workgroups, hipStream_t s);
   void launch_strip_scan(const EncodeParams &p, hipStream_t s);
   void launch_dither_store(const EncodeParams &p, int channels, hipStream_t s);
 

@@ -449,6 +449,223 @@ namespace limg_hip
     }
 
     // =====================================================================================================================
+    // phase F / kernel 3: dither (a13), plane stores (a15), decode (a16) for one work strip
+    // =====================================================================================================================
+
+    // LDS areas of phase F.  In the fused kernel they overlay the (then dead) parked-contribution area of k_fit_search.
+    struct StripLds
+    {
+      uint8_t *fac;    // [3][8][256]  pre-dither factor bytes of the strip (plane-row layout)
+      uint32_t *dec;   // [4 waves][8 rows][64]  decoded pixels
+      uint8_t *out;    // [4 waves][3][8 rows][64]  output factor bytes
+      uint32_t *cst;   // [7][32]  per-block constants of the 7 block-uniform planes
+      int32_t *nm;     // [32 blocks][2][3][4]  effective integer normals / additive constants of the decode
+      uint32_t *shift; // [32]  shift words
+      uint32_t *first; // [32]  first dither-call index of each block
+      const int16_t *rec; // record of block sb at rec + sb * recStride
+      int recStride;
+    };
+    constexpr int kPhaseFBytes = 6144 + 8192 + 6144 + 896 + 3072 + 128 + 128;
+
+    __device__ __forceinline__ StripLds carve_phase_f(uint8_t *base, const int16_t *rec, int recStride)
+    {
+      StripLds L;
+      L.fac = base;
+      L.dec = reinterpret_cast<uint32_t *>(base + 6144);
+      L.out = base + 6144 + 8192;
+      L.cst = reinterpret_cast<uint32_t *>(base + 6144 + 8192 + 6144);
+      L.nm = reinterpret_cast<int32_t *>(base + 6144 + 8192 + 6144 + 896);
+      L.shift = reinterpret_cast<uint32_t *>(base + 6144 + 8192 + 6144 + 896 + 3072);
+      L.first = L.shift + 32;
+      L.rec = rec; L.recStride = recStride;
+      return L;
+    }
+
+    // Per-wave preparation from records + shifts (lane-parallel over the wave's 8 blocks): the 7 block-uniform plane values
+    // (src/limg.cpp:2006-2036) and the effective decode constants (src/limg_decode.h:139-196 / :40-101).
+    template <int CH>
+    __device__ __forceinline__ void phase_f_prepare(const StripLds &L, int lane, int wave)
+    {
+      if (lane < 56)
+      {
+        const int b = lane / 7, k = lane - b * 7, sb = wave * kBlocksPerWave + b;
+        const int16_t *rec = L.rec + sb * L.recStride;
+        uint32_t v;
+        if (k == 0)
+        {
+          const uint32_t w = L.shift[sb];
+          const uint32_t pat[3] = { (w & 0xFF), ((w >> 8) & 0xFF), ((w >> 16) & 0xFF) };
+          // bit_to_pattern {0,0x22,...,0xEE,0xFF}: 0x22 * s, except s == 8 -> 0xFF
+          const uint32_t pa = pat[0] == 8 ? 0xFFu : pat[0] * 0x22u, pb = pat[1] == 8 ? 0xFFu : pat[1] * 0x22u, pc = pat[2] == 8 ? 0xFFu : pat[2] * 0x22u;
+          v = 0xFF000000u | (pa << 16) | (pb << 8) | pc;
+        }
+        else
+        {
+          v = 0;
+#pragma unroll
+          for (int c = 0; c < CH; c++)
+          {
+            int q = rec[(k - 1) * 4 + c] + (k >= 3 ? 0x80 : 0);
+            q = q < 0 ? 0 : (q > 255 ? 255 : q);
+            v |= (uint32_t)q << (8 * c);
+          }
+          if (CH == 3) v |= 0xFF000000u;
+        }
+        L.cst[k * kStripBlocks + sb] = v;
+      }
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+      {
+        const int idx = r * 64 + lane;
+        if (idx < 96)
+        {
+          const int b = idx / 12, fc = idx - b * 12, f = fc >> 2, c = fc & 3, sb = wave * kBlocksPerWave + b;
+          const int16_t *rec = L.rec + sb * L.recStride;
+          const uint32_t sh = (L.shift[sb] >> (8 * f)) & 0xFF;
+          int n = rec[f * 8 + 4 + c] - rec[f * 8 + c], m = rec[f * 8 + c];
+          if (c < 3)
+          {
+            if (sh > 7) { n = 0; if (f > 0) m = 0; }
+          }
+          else if (CH == 3) { n = 0; m = 0xFFFF; }
+          int *dst = L.nm + sb * 24;
+          dst[f * 4 + c] = n;
+          dst[12 + f * 4 + c] = (int)(((uint32_t)m << 8) + 128u);
+        }
+      }
+    }
+
+    // the 7 block-uniform planes: 256 contiguous bytes (8 blocks x 8 px) per store instruction, straight from registers
+    __device__ __forceinline__ void phase_f_store_const(const EncodeParams &p, const StripLds &L, uint32_t x0, uint32_t y0, uint32_t ry, int lane, int wave)
+    {
+      const uint32_t wx0 = x0 + wave * 64;
+      if (wx0 >= p.sizeX) return;
+      const uint32_t ww = min(p.sizeX - wx0, 64u);
+      uint32_t *planes[7] = { p.info.pShiftABCX, p.info.pColAMin, p.info.pColAMax, p.info.pColBMin, p.info.pColBMax, p.info.pColCMin, p.info.pColCMax };
+      uint32_t cst[7];
+#pragma unroll
+      for (int k = 0; k < 7; k++) cst[k] = L.cst[k * kStripBlocks + wave * kBlocksPerWave + (lane >> 3)];
+      if ((uint32_t)lane < ww)
+        for (uint32_t row = 0; row < ry; row++)
+        {
+          const size_t g = (size_t)(y0 + row) * p.sizeX + wx0 + lane;
+#pragma unroll
+          for (int k = 0; k < 7; k++) planes[k][g] = cst[k];
+        }
+    }
+
+    // dither + decode of the wave's 8 blocks into the per-wave staging areas, then the per-pixel planes' stores
+    template <int CH>
+    __device__ __forceinline__ void phase_f_pixels(const EncodeParams &p, const StripLds &L, uint32_t strip, uint32_t x0, uint32_t y0, uint32_t ry, int lane, int wave)
+    {
+      uint32_t *dec = L.dec + wave * 512;
+      uint8_t *out = L.out + wave * 1536;
+      for (int b = 0; b < kBlocksPerWave; b++)
+      {
+        const uint32_t sb = wave * kBlocksPerWave + b;
+        const uint32_t bx = strip * kStripBlocks + sb;
+        if (bx >= p.blocksX) continue;
+        const uint32_t rx = min(p.sizeX - bx * kBlock, (uint32_t)kBlock), n = rx * ry;
+        const bool active = (uint32_t)lane < n;
+        uint32_t lx, ly;
+        if (rx == 8) { lx = lane & 7; ly = lane >> 3; }
+        else { const uint32_t l = active ? (uint32_t)lane : 0u; ly = l / rx; lx = l - ly * rx; }
+        const uint32_t o = ly * 256 + sb * kBlock + lx;
+        const uint32_t w = (uint32_t)sgpr((int)L.shift[sb]);
+        const uint32_t shift[3] = { w & 0xFF, (w >> 8) & 0xFF, (w >> 16) & 0xFF };
+        uint32_t call = (uint32_t)sgpr((int)L.first[sb]);
+
+        uint32_t f[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+        {
+          uint32_t v = L.fac[k * 2048 + o];
+          const uint32_t s = shift[k];
+          if (s != 0 && s != 8)
+          { // src/limg.cpp:824-879: (lane16 & ditherSize) - ditherOffset, add, clamp, shift
+            const uint32_t nz = p.noise[(size_t)call * 64 + (active ? lane : 0)];
+            int t = (int)v + ((int)(nz & ((1u << s) - 1u)) - (int)(1u << (s - 1)));
+            t = t < 0 ? 0 : (t > 255 ? 255 : t);
+            v = (uint32_t)t >> s;
+            call++;
+          }
+          f[k] = v;
+        }
+
+        // decode: dec_k = byte * mul_k, est_c = sum_k (dec_k * n_k[c] + m_k[c]) >> 8, clamp.  24-bit multiplies are exact here:
+        // dec <= 255 * 256 and |n| <= 65535 (difference of two int16), and v_mad_i32_i24 keeps the low 32 bits like PMULLD.
+        const int *nm = L.nm + sb * 24;
+        uint32_t decoded = 0;
+        const int dA = (int)(f[0] * shift_mul(shift[0])), dB = (int)(f[1] * shift_mul(shift[1])), dC = (int)(f[2] * shift_mul(shift[2]));
+        const int4 nA = *reinterpret_cast<const int4 *>(nm), nB = *reinterpret_cast<const int4 *>(nm + 4), nC = *reinterpret_cast<const int4 *>(nm + 8);
+        const int4 mA = *reinterpret_cast<const int4 *>(nm + 12), mB = *reinterpret_cast<const int4 *>(nm + 16), mC = *reinterpret_cast<const int4 *>(nm + 20);
+        const int nAa[4] = { nA.x, nA.y, nA.z, nA.w }, nBa[4] = { nB.x, nB.y, nB.z, nB.w }, nCa[4] = { nC.x, nC.y, nC.z, nC.w };
+        const int mAa[4] = { mA.x, mA.y, mA.z, mA.w }, mBa[4] = { mB.x, mB.y, mB.z, mB.w }, mCa[4] = { mC.x, mC.y, mC.z, mC.w };
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+        {
+          int est = (mad_i24(dA, nAa[c], mAa[c]) >> 8) + (mad_i24(dB, nBa[c], mBa[c]) >> 8) + (mad_i24(dC, nCa[c], mCa[c]) >> 8);
+          est = est < 0 ? 0 : (est > 255 ? 255 : est);
+          decoded |= (uint32_t)est << (8 * c);
+        }
+        if (active)
+        {
+          const uint32_t wo = ly * 64 + b * kBlock + lx;
+          dec[wo] = decoded;
+#pragma unroll
+          for (int k = 0; k < 3; k++) out[k * 512 + wo] = (uint8_t)(f[k] << shift[k]); // shift 8 => 0 (src/limg.cpp:2054-2062)
+        }
+      }
+      wave_lds_fence();
+
+      const uint32_t wx0 = x0 + wave * 64;
+      if (wx0 >= p.sizeX) return;
+      const uint32_t ww = min(p.sizeX - wx0, 64u);
+      uint8_t *planes8[3] = { p.info.pFactorsA, p.info.pFactorsB, p.info.pFactorsC };
+      if ((uint32_t)lane < ww)
+        for (uint32_t row = 0; row < ry; row++) p.info.pDecoded[(size_t)(y0 + row) * p.sizeX + wx0 + lane] = dec[row * 64 + lane];
+      if ((p.sizeX & 3u) == 0)
+      { // 4 bytes per lane: lane -> (row = lane >> 4, 4-px chunk = lane & 15), two passes cover 8 rows
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++)
+        {
+          const uint32_t row = pass * 4 + (lane >> 4), ch = (lane & 15) * 4;
+          if (row < ry && ch < ww)
+          {
+            const size_t g = (size_t)(y0 + row) * p.sizeX + wx0 + ch;
+#pragma unroll
+            for (int k = 0; k < 3; k++) *reinterpret_cast<uint32_t *>(planes8[k] + g) = *reinterpret_cast<const uint32_t *>(&out[k * 512 + row * 64 + ch]);
+          }
+        }
+      }
+      else
+      {
+        for (uint32_t row = 0; row < ry; row++)
+          if ((uint32_t)lane < ww)
+          {
+            const size_t g = (size_t)(y0 + row) * p.sizeX + wx0 + lane;
+#pragma unroll
+            for (int k = 0; k < 3; k++) planes8[k][g] = out[k * 512 + row * 64 + lane];
+          }
+      }
+    }
+
+    // exclusive prefix of the dither-call counts of the strip's 32 blocks (wave 0), on top of the strip's base
+    __device__ __forceinline__ void phase_f_first_calls(const StripLds &L, uint32_t base, int lane)
+    {
+      const uint32_t w = lane < kStripBlocks ? L.shift[lane] : 0u;
+      const uint32_t calls = w >> 24;
+      uint32_t incl = calls;
+#pragma unroll
+      for (int off = 1; off < 32; off <<= 1)
+      {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+        if (lane >= off) incl += up;
+      }
+      if (lane < kStripBlocks) L.first[lane] = base + incl - calls;
+    }
+
+    // =====================================================================================================================
     // kernel 1: fit + factors + shift search
     // =====================================================================================================================
 
@@ -568,25 +785,98 @@ namespace limg_hip
       wave_lds_fence();
     }
 
-    template <int CH>
-    __global__ __launch_bounds__(kThreads) void k_fit_search(const EncodeParams p)
+    // ---- decoupled look-back over the per-strip dither-call counts (fused path) ------------------------------------------
+    // One 8-byte descriptor per work strip: value in the low word, status in the high word (0 = nothing yet, 1 = this strip's
+    // own count, 2 = inclusive count of the chain up to and including this strip).  Written and read with relaxed agent-scope
+    // 8-byte atomics only: value and status travel in one granule, so no other ordering is needed.  Strip ids are handed out
+    // by a ticket, so every predecessor of a running workgroup has itself started (and never waits on a successor): the
+    // look-back always terminates.  The spin is bounded all the same; a timeout raises ticket[1] and the kernel finishes.
+    constexpr uint32_t kDescAggregate = 1u, kDescInclusive = 2u;
+
+    __device__ __forceinline__ void desc_store(unsigned long long *d, uint32_t status, uint32_t value)
     {
-      __shared__ __attribute__((aligned(16))) unsigned short s_rsq[2048];
-      __shared__ __attribute__((aligned(16))) uint32_t s_strip[8 * kRowDw];
-      __shared__ __attribute__((aligned(16))) float s_V[kWaves * kBlocksPerWave * kVDw];
-      __shared__ __attribute__((aligned(16))) BlkF s_blk[kStripBlocks];
-      __shared__ uint32_t s_calls[kWaves];
+      __hip_atomic_store(d, ((unsigned long long)status << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ unsigned long long desc_load(unsigned long long *d)
+    {
+      return __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    // called by all 64 lanes of one wave; returns the number of dither calls of the chain before strip `id`
+    __device__ __forceinline__ uint32_t lookback_base(const EncodeParams &p, uint32_t id, uint32_t headId, uint32_t agg, int lane)
+    {
+      if (id == headId) return 0u;
+      uint32_t base = 0;
+      int hi = (int)id - 1; // nearest predecessor not yet accounted for
+      for (;;)
+      {
+        const int j = hi - lane; // lane 0 looks at the nearest one
+        const bool inrange = j >= (int)headId;
+        unsigned long long d = ((unsigned long long)kDescInclusive << 32); // before the chain head: inclusive 0
+        uint32_t spins = 0;
+        for (;;)
+        {
+          if (inrange) d = desc_load(p.desc + j);
+          const uint64_t incl = __builtin_amdgcn_ballot_w64((uint32_t)(d >> 32) == kDescInclusive);
+          const uint64_t none = __builtin_amdgcn_ballot_w64((uint32_t)(d >> 32) == 0u);
+          // every strip nearer than the nearest inclusive one must have published at least its own count
+          const uint64_t nearer = incl ? ((incl & (0ull - incl)) - 1ull) : ~0ull;
+          if ((none & nearer) == 0ull)
+          {
+            const uint32_t v = (uint32_t)d;
+            if (incl)
+            {
+              const int fl = __builtin_ctzll(incl);
+              base += wave_sum(lane <= fl ? v : 0u);
+              return base;
+            }
+            base += wave_sum(v);
+            break;
+          }
+          if (++spins > (1u << 22))
+          {
+            if (lane == 0) atomicExch(p.ticket + 1, 1u);
+            return base;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        hi -= 64;
+      }
+    }
+
+    // LDS of an E task (fit + search of one work strip); the F task's areas overlay `V`.
+    constexpr int kLdsRsq = 0, kLdsStrip = 4096, kLdsV = kLdsStrip + 8 * kRowDw * 4, kLdsVBytes = kWaves * kBlocksPerWave * kVDw * 4;
+    constexpr int kLdsBlk = kLdsV + kLdsVBytes, kLdsCalls = kLdsBlk + kStripBlocks * 192, kLdsTotal = kLdsCalls + 16;
+    static_assert(kLdsTotal == 51984, "3 workgroups per CU");
+
+    __device__ __forceinline__ void load_rsqrt_table(uint8_t *lds, int tid)
+    {
+      for (int i = tid; i < 2048 / 8; i += kThreads)
+        reinterpret_cast<uint4 *>(lds + kLdsRsq)[i] = reinterpret_cast<const uint4 *>(d_rsqrt_x86_tab)[i];
+    }
+
+    // PERSIST == false: split path, the strip's call count goes to p.stripCalls for k_strip_scan.
+    // PERSIST == true : persistent kernel, the count is published as an "aggregate" look-back descriptor.
+    // parked results of one strip (persistent kernel): pre-dither factor bytes, records (int16 part), shift words
+    constexpr int kParkFac = 0, kParkRec = 6144, kParkShift = 6144 + 1536, kParkBytes = 8192;
+
+    template <int CH, bool PERSIST>
+    __device__ __forceinline__ void fit_search_strip(const EncodeParams &p, const uint32_t id, uint8_t *lds, uint8_t *park)
+    {
+      unsigned short *s_rsq = reinterpret_cast<unsigned short *>(lds + kLdsRsq);
+      uint32_t *s_strip = reinterpret_cast<uint32_t *>(lds + kLdsStrip);
+      float *s_V = reinterpret_cast<float *>(lds + kLdsV);
+      BlkF *s_blk = reinterpret_cast<BlkF *>(lds + kLdsBlk);
+      uint32_t *s_calls = reinterpret_cast<uint32_t *>(lds + kLdsCalls);
 
       const int tid = (int)threadIdx.x;
       const int lane = tid & 63, wave = tid >> 6;
-      const uint32_t strip = blockIdx.x % p.stripsX, by = blockIdx.x / p.stripsX;
+      const uint32_t strip = id % p.stripsX, by = id / p.stripsX;
       const uint32_t x0 = strip * (kStripBlocks * kBlock), y0 = by * kBlock;
       const uint32_t stripW = min(p.sizeX - x0, (uint32_t)(kStripBlocks * kBlock)); // pixels
       const uint32_t ry = min(p.sizeY - y0, (uint32_t)kBlock);
 
-      // ---- stage: rsqrt table + the strip's pixel rows into LDS ------------------------------------------------------
-      for (int i = tid; i < 2048 / 8; i += kThreads)
-        reinterpret_cast<uint4 *>(s_rsq)[i] = reinterpret_cast<const uint4 *>(d_rsqrt_x86_tab)[i];
+      // ---- stage: the strip's pixel rows into LDS (the rsqrt table is loaded by the caller) ----------------------------
       if ((p.sizeX & 3u) == 0)
       {
 #pragma unroll
@@ -821,19 +1111,16 @@ namespace limg_hip
         if (j == 0 && big) blk[b].flags = flags | kBig;
       }
       wave_lds_fence();
-      // record -> global (16 dwords per block: avg, then the 24 int16)
-      if (p.records)
+      // record -> global (16 dwords per block: avg, then the 24 int16); persistent kernel: the int16 part is parked
       {
 #pragma unroll
         for (int r = 0; r < 2; r++)
         {
           const int b = r * 4 + (lane >> 4), w = lane & 15;
-          const uint32_t bx = strip * kStripBlocks + wave * kBlocksPerWave + b;
-          if (bx < p.blocksX)
-          {
-            const uint32_t val = w < 4 ? __float_as_uint(blk[b].avg[w]) : reinterpret_cast<const uint32_t *>(blk[b].rec)[w - 4];
-            reinterpret_cast<uint32_t *>(p.records + (size_t)by * p.blocksX + bx)[w] = val;
-          }
+          const uint32_t sb = wave * kBlocksPerWave + b, bx = strip * kStripBlocks + sb;
+          const uint32_t val = w < 4 ? __float_as_uint(blk[b].avg[w]) : reinterpret_cast<const uint32_t *>(blk[b].rec)[w - 4];
+          if (bx < p.blocksX && (!PERSIST || p.compactOut)) reinterpret_cast<uint32_t *>(p.records + (size_t)by * p.blocksX + bx)[w] = val;
+          if (PERSIST && w >= 4) reinterpret_cast<uint32_t *>(park + kParkRec)[sb * 12 + (w - 4)] = val;
         }
       }
       // phase-E view (overlays the dead float-stage fields): float normals / offsets and 1 / |n|^2 in the serial limg_dot
@@ -873,6 +1160,7 @@ namespace limg_hip
 
       uint8_t *stage = reinterpret_cast<uint8_t *>(s_V); // [3 planes][8 rows][256 px]
       uint32_t waveCalls = 0;
+      if (PERSIST && lane < kBlocksPerWave) reinterpret_cast<uint32_t *>(park + kParkShift)[wave * kBlocksPerWave + lane] = 0u; // blocks past the right edge
 
       // ---- phase E: per-pixel factors (a8) + shift search (a10-a12) ----------------------------------------------------
 #pragma unroll 1
@@ -990,7 +1278,12 @@ namespace limg_hip
         waveCalls += calls;
 
         const size_t bi = (size_t)by * p.blocksX + bx;
-        if (lane == 0) p.shifts[bi] = shift[0] | (shift[1] << 8) | (shift[2] << 16) | (calls << 24);
+        const uint32_t word = shift[0] | (shift[1] << 8) | (shift[2] << 16) | (calls << 24);
+        if (lane == 0)
+        {
+          if (!PERSIST || p.compactOut) p.shifts[bi] = word;
+          if (PERSIST) reinterpret_cast<uint32_t *>(park + kParkShift)[sb] = word;
+        }
         if (p.storePlanes && active)
         {
           const uint32_t o = ly * 256 + sb * kBlock + lx;
@@ -999,7 +1292,33 @@ namespace limg_hip
       }
       if (lane == 0) s_calls[wave] = waveCalls;
       __syncthreads();
-      if (tid == 0) p.stripCalls[(size_t)by * p.stripsX + strip] = s_calls[0] + s_calls[1] + s_calls[2] + s_calls[3];
+      if (tid == 0)
+      {
+        const uint32_t agg = s_calls[0] + s_calls[1] + s_calls[2] + s_calls[3];
+        if (PERSIST)
+        { // publish the count; if the predecessor's inclusive count is already there, publish ours as inclusive right away
+          uint32_t headId = 0;
+          if (p.chainCount > 1 && p.chainRows != 0)
+          {
+            uint32_t c = by / p.chainRows;
+            c = c < p.chainCount - 1 ? c : p.chainCount - 1;
+            headId = c * p.chainRows * p.stripsX;
+          }
+          if (id == headId) desc_store(p.desc + id, kDescInclusive, agg);
+          else
+          {
+            const unsigned long long d = desc_load(p.desc + id - 1);
+            if ((uint32_t)(d >> 32) == kDescInclusive) desc_store(p.desc + id, kDescInclusive, (uint32_t)d + agg);
+            else desc_store(p.desc + id, kDescAggregate, agg);
+          }
+        }
+        else p.stripCalls[id] = agg;
+      }
+      if (PERSIST)
+      { // park the pre-dither factor bytes (private, L2-resident scratch; same workgroup reads them back)
+        for (int i = tid; i < 384; i += kThreads) reinterpret_cast<uint4 *>(park + kParkFac)[i] = reinterpret_cast<const uint4 *>(stage)[i];
+        return;
+      }
 
       // ---- pre-dither factor bytes -> the caller's factor planes (rewritten in place by k_dither_store) -------------
       if (p.storePlanes)
@@ -1072,270 +1391,167 @@ namespace limg_hip
     }
 
     // =====================================================================================================================
-    // phase F / kernel 3: dither (a13), plane stores (a15), decode (a16) for one work strip
+    // kernel 3 (split path): phase F as its own launch
     // =====================================================================================================================
+    // F task: dither + stores + decode of one work strip from the parked per-block results.
+    // PERSIST == false: the strip's chain position comes from k_strip_scan (p.stripBase);
+    // PERSIST == true : from the look-back over the descriptors, and the strip's inclusive count is published first thing.
+    static_assert(kPhaseFBytes + kStripBlocks * 48 <= kLdsVBytes, "the F task's LDS must fit the E task's parked-contribution area");
 
-    // LDS areas of phase F.  In the fused kernel they overlay the (then dead) parked-contribution area of k_fit_search.
-    struct StripLds
+    template <int CH, bool PERSIST>
+    __device__ __forceinline__ void dither_store_strip(const EncodeParams &p, const uint32_t id, uint8_t *fbase, const uint8_t *park)
     {
-      uint8_t *fac;    // [3][8][256]  pre-dither factor bytes of the strip (plane-row layout)
-      uint32_t *dec;   // [4 waves][8 rows][64]  decoded pixels
-      uint8_t *out;    // [4 waves][3][8 rows][64]  output factor bytes
-      uint32_t *cst;   // [7][32]  per-block constants of the 7 block-uniform planes
-      int32_t *nm;     // [32 blocks][2][3][4]  effective integer normals / additive constants of the decode
-      uint32_t *shift; // [32]  shift words
-      uint32_t *first; // [32]  first dither-call index of each block
-      const int16_t *rec; // record of block sb at rec + sb * recStride
-      int recStride;
-    };
-    constexpr int kPhaseFBytes = 6144 + 8192 + 6144 + 896 + 3072 + 128 + 128;
-
-    __device__ __forceinline__ StripLds carve_phase_f(uint8_t *base, const int16_t *rec, int recStride)
-    {
-      StripLds L;
-      L.fac = base;
-      L.dec = reinterpret_cast<uint32_t *>(base + 6144);
-      L.out = base + 6144 + 8192;
-      L.cst = reinterpret_cast<uint32_t *>(base + 6144 + 8192 + 6144);
-      L.nm = reinterpret_cast<int32_t *>(base + 6144 + 8192 + 6144 + 896);
-      L.shift = reinterpret_cast<uint32_t *>(base + 6144 + 8192 + 6144 + 896 + 3072);
-      L.first = L.shift + 32;
-      L.rec = rec; L.recStride = recStride;
-      return L;
-    }
-
-    // Per-wave preparation from records + shifts (lane-parallel over the wave's 8 blocks): the 7 block-uniform plane values
-    // (src/limg.cpp:2006-2036) and the effective decode constants (src/limg_decode.h:139-196 / :40-101).
-    template <int CH>
-    __device__ __forceinline__ void phase_f_prepare(const StripLds &L, int lane, int wave)
-    {
-      if (lane < 56)
-      {
-        const int b = lane / 7, k = lane - b * 7, sb = wave * kBlocksPerWave + b;
-        const int16_t *rec = L.rec + sb * L.recStride;
-        uint32_t v;
-        if (k == 0)
-        {
-          const uint32_t w = L.shift[sb];
-          const uint32_t pat[3] = { (w & 0xFF), ((w >> 8) & 0xFF), ((w >> 16) & 0xFF) };
-          // bit_to_pattern {0,0x22,...,0xEE,0xFF}: 0x22 * s, except s == 8 -> 0xFF
-          const uint32_t pa = pat[0] == 8 ? 0xFFu : pat[0] * 0x22u, pb = pat[1] == 8 ? 0xFFu : pat[1] * 0x22u, pc = pat[2] == 8 ? 0xFFu : pat[2] * 0x22u;
-          v = 0xFF000000u | (pa << 16) | (pb << 8) | pc;
-        }
-        else
-        {
-          v = 0;
-#pragma unroll
-          for (int c = 0; c < CH; c++)
-          {
-            int q = rec[(k - 1) * 4 + c] + (k >= 3 ? 0x80 : 0);
-            q = q < 0 ? 0 : (q > 255 ? 255 : q);
-            v |= (uint32_t)q << (8 * c);
-          }
-          if (CH == 3) v |= 0xFF000000u;
-        }
-        L.cst[k * kStripBlocks + sb] = v;
-      }
-#pragma unroll
-      for (int r = 0; r < 2; r++)
-      {
-        const int idx = r * 64 + lane;
-        if (idx < 96)
-        {
-          const int b = idx / 12, fc = idx - b * 12, f = fc >> 2, c = fc & 3, sb = wave * kBlocksPerWave + b;
-          const int16_t *rec = L.rec + sb * L.recStride;
-          const uint32_t sh = (L.shift[sb] >> (8 * f)) & 0xFF;
-          int n = rec[f * 8 + 4 + c] - rec[f * 8 + c], m = rec[f * 8 + c];
-          if (c < 3)
-          {
-            if (sh > 7) { n = 0; if (f > 0) m = 0; }
-          }
-          else if (CH == 3) { n = 0; m = 0xFFFF; }
-          int *dst = L.nm + sb * 24;
-          dst[f * 4 + c] = n;
-          dst[12 + f * 4 + c] = (int)(((uint32_t)m << 8) + 128u);
-        }
-      }
-    }
-
-    // the 7 block-uniform planes: 256 contiguous bytes (8 blocks x 8 px) per store instruction, straight from registers
-    __device__ __forceinline__ void phase_f_store_const(const EncodeParams &p, const StripLds &L, uint32_t x0, uint32_t y0, uint32_t ry, int lane, int wave)
-    {
-      const uint32_t wx0 = x0 + wave * 64;
-      if (wx0 >= p.sizeX) return;
-      const uint32_t ww = min(p.sizeX - wx0, 64u);
-      uint32_t *planes[7] = { p.info.pShiftABCX, p.info.pColAMin, p.info.pColAMax, p.info.pColBMin, p.info.pColBMax, p.info.pColCMin, p.info.pColCMax };
-      uint32_t cst[7];
-#pragma unroll
-      for (int k = 0; k < 7; k++) cst[k] = L.cst[k * kStripBlocks + wave * kBlocksPerWave + (lane >> 3)];
-      if ((uint32_t)lane < ww)
-        for (uint32_t row = 0; row < ry; row++)
-        {
-          const size_t g = (size_t)(y0 + row) * p.sizeX + wx0 + lane;
-#pragma unroll
-          for (int k = 0; k < 7; k++) planes[k][g] = cst[k];
-        }
-    }
-
-    // dither + decode of the wave's 8 blocks into the per-wave staging areas, then the per-pixel planes' stores
-    template <int CH>
-    __device__ __forceinline__ void phase_f_pixels(const EncodeParams &p, const StripLds &L, uint32_t strip, uint32_t x0, uint32_t y0, uint32_t ry, int lane, int wave)
-    {
-      uint32_t *dec = L.dec + wave * 512;
-      uint8_t *out = L.out + wave * 1536;
-      for (int b = 0; b < kBlocksPerWave; b++)
-      {
-        const uint32_t sb = wave * kBlocksPerWave + b;
-        const uint32_t bx = strip * kStripBlocks + sb;
-        if (bx >= p.blocksX) continue;
-        const uint32_t rx = min(p.sizeX - bx * kBlock, (uint32_t)kBlock), n = rx * ry;
-        const bool active = (uint32_t)lane < n;
-        uint32_t lx, ly;
-        if (rx == 8) { lx = lane & 7; ly = lane >> 3; }
-        else { const uint32_t l = active ? (uint32_t)lane : 0u; ly = l / rx; lx = l - ly * rx; }
-        const uint32_t o = ly * 256 + sb * kBlock + lx;
-        const uint32_t w = (uint32_t)sgpr((int)L.shift[sb]);
-        const uint32_t shift[3] = { w & 0xFF, (w >> 8) & 0xFF, (w >> 16) & 0xFF };
-        uint32_t call = (uint32_t)sgpr((int)L.first[sb]);
-
-        uint32_t f[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-        {
-          uint32_t v = L.fac[k * 2048 + o];
-          const uint32_t s = shift[k];
-          if (s != 0 && s != 8)
-          { // src/limg.cpp:824-879: (lane16 & ditherSize) - ditherOffset, add, clamp, shift
-            const uint32_t nz = p.noise[(size_t)call * 64 + (active ? lane : 0)];
-            int t = (int)v + ((int)(nz & ((1u << s) - 1u)) - (int)(1u << (s - 1)));
-            t = t < 0 ? 0 : (t > 255 ? 255 : t);
-            v = (uint32_t)t >> s;
-            call++;
-          }
-          f[k] = v;
-        }
-
-        // decode: dec_k = byte * mul_k, est_c = sum_k (dec_k * n_k[c] + m_k[c]) >> 8, clamp.  24-bit multiplies are exact here:
-        // dec <= 255 * 256 and |n| <= 65535 (difference of two int16), and v_mad_i32_i24 keeps the low 32 bits like PMULLD.
-        const int *nm = L.nm + sb * 24;
-        uint32_t decoded = 0;
-        const int dA = (int)(f[0] * shift_mul(shift[0])), dB = (int)(f[1] * shift_mul(shift[1])), dC = (int)(f[2] * shift_mul(shift[2]));
-        const int4 nA = *reinterpret_cast<const int4 *>(nm), nB = *reinterpret_cast<const int4 *>(nm + 4), nC = *reinterpret_cast<const int4 *>(nm + 8);
-        const int4 mA = *reinterpret_cast<const int4 *>(nm + 12), mB = *reinterpret_cast<const int4 *>(nm + 16), mC = *reinterpret_cast<const int4 *>(nm + 20);
-        const int nAa[4] = { nA.x, nA.y, nA.z, nA.w }, nBa[4] = { nB.x, nB.y, nB.z, nB.w }, nCa[4] = { nC.x, nC.y, nC.z, nC.w };
-        const int mAa[4] = { mA.x, mA.y, mA.z, mA.w }, mBa[4] = { mB.x, mB.y, mB.z, mB.w }, mCa[4] = { mC.x, mC.y, mC.z, mC.w };
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-        {
-          int est = (mad_i24(dA, nAa[c], mAa[c]) >> 8) + (mad_i24(dB, nBa[c], mBa[c]) >> 8) + (mad_i24(dC, nCa[c], mCa[c]) >> 8);
-          est = est < 0 ? 0 : (est > 255 ? 255 : est);
-          decoded |= (uint32_t)est << (8 * c);
-        }
-        if (active)
-        {
-          const uint32_t wo = ly * 64 + b * kBlock + lx;
-          dec[wo] = decoded;
-#pragma unroll
-          for (int k = 0; k < 3; k++) out[k * 512 + wo] = (uint8_t)(f[k] << shift[k]); // shift 8 => 0 (src/limg.cpp:2054-2062)
-        }
-      }
-      wave_lds_fence();
-
-      const uint32_t wx0 = x0 + wave * 64;
-      if (wx0 >= p.sizeX) return;
-      const uint32_t ww = min(p.sizeX - wx0, 64u);
-      uint8_t *planes8[3] = { p.info.pFactorsA, p.info.pFactorsB, p.info.pFactorsC };
-      if ((uint32_t)lane < ww)
-        for (uint32_t row = 0; row < ry; row++) p.info.pDecoded[(size_t)(y0 + row) * p.sizeX + wx0 + lane] = dec[row * 64 + lane];
-      if ((p.sizeX & 3u) == 0)
-      { // 4 bytes per lane: lane -> (row = lane >> 4, 4-px chunk = lane & 15), two passes cover 8 rows
-#pragma unroll
-        for (int pass = 0; pass < 2; pass++)
-        {
-          const uint32_t row = pass * 4 + (lane >> 4), ch = (lane & 15) * 4;
-          if (row < ry && ch < ww)
-          {
-            const size_t g = (size_t)(y0 + row) * p.sizeX + wx0 + ch;
-#pragma unroll
-            for (int k = 0; k < 3; k++) *reinterpret_cast<uint32_t *>(planes8[k] + g) = *reinterpret_cast<const uint32_t *>(&out[k * 512 + row * 64 + ch]);
-          }
-        }
-      }
-      else
-      {
-        for (uint32_t row = 0; row < ry; row++)
-          if ((uint32_t)lane < ww)
-          {
-            const size_t g = (size_t)(y0 + row) * p.sizeX + wx0 + lane;
-#pragma unroll
-            for (int k = 0; k < 3; k++) planes8[k][g] = out[k * 512 + row * 64 + lane];
-          }
-      }
-    }
-
-    // exclusive prefix of the dither-call counts of the strip's 32 blocks (wave 0), on top of the strip's base
-    __device__ __forceinline__ void phase_f_first_calls(const StripLds &L, uint32_t base, int lane)
-    {
-      const uint32_t w = lane < kStripBlocks ? L.shift[lane] : 0u;
-      const uint32_t calls = w >> 24;
-      uint32_t incl = calls;
-#pragma unroll
-      for (int off = 1; off < 32; off <<= 1)
-      {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
-        if (lane >= off) incl += up;
-      }
-      if (lane < kStripBlocks) L.first[lane] = base + incl - calls;
-    }
-
-    template <int CH>
-    __global__ __launch_bounds__(kThreads) void k_dither_store(const EncodeParams p)
-    {
-      __shared__ __attribute__((aligned(16))) uint8_t s_f[kPhaseFBytes];
-      __shared__ __attribute__((aligned(16))) int16_t s_rec[kStripBlocks][24];
-
+      int16_t *s_rec = reinterpret_cast<int16_t *>(fbase + kPhaseFBytes); // [32][24]
       const int tid = (int)threadIdx.x;
       const int lane = tid & 63, wave = tid >> 6;
-      const uint32_t strip = blockIdx.x % p.stripsX, by = blockIdx.x / p.stripsX;
+      const uint32_t strip = id % p.stripsX, by = id / p.stripsX;
       const uint32_t x0 = strip * (kStripBlocks * kBlock), y0 = by * kBlock;
       const uint32_t stripW = min(p.sizeX - x0, (uint32_t)(kStripBlocks * kBlock));
       const uint32_t ry = min(p.sizeY - y0, (uint32_t)kBlock);
       const uint32_t nBlocks = min(p.blocksX - strip * kStripBlocks, (uint32_t)kStripBlocks);
       const uint8_t *planesIn[3] = { p.info.pFactorsA, p.info.pFactorsB, p.info.pFactorsC };
-      const StripLds L = carve_phase_f(s_f, &s_rec[0][0], 24);
+      const StripLds L = carve_phase_f(fbase, s_rec, 24);
 
-      if ((p.sizeX & 15u) == 0)
+      if (PERSIST)
       {
-        for (int i = tid; i < 384; i += kThreads)
-        {
-          const int pl = i >> 7, row = (i & 127) >> 4, col = (i & 15) * 16;
-          if ((uint32_t)row < ry && (uint32_t)col < stripW)
-            *reinterpret_cast<uint4 *>(L.fac + pl * 2048 + row * 256 + col) = *reinterpret_cast<const uint4 *>(planesIn[pl] + (size_t)(y0 + row) * p.sizeX + x0 + col);
-        }
+        for (int i = tid; i < 384; i += kThreads) reinterpret_cast<uint4 *>(L.fac)[i] = reinterpret_cast<const uint4 *>(park + kParkFac)[i];
+        for (int i = tid; i < kStripBlocks * 12; i += kThreads) reinterpret_cast<uint32_t *>(s_rec)[i] = reinterpret_cast<const uint32_t *>(park + kParkRec)[i];
+        if (tid < kStripBlocks) L.shift[tid] = reinterpret_cast<const uint32_t *>(park + kParkShift)[tid];
       }
       else
       {
-        for (int i = tid; i < 3 * 2048; i += kThreads)
+        if ((p.sizeX & 15u) == 0)
         {
-          const int pl = i >> 11, row = (i & 2047) >> 8, col = i & 255;
-          if ((uint32_t)row < ry && (uint32_t)col < stripW) L.fac[i] = planesIn[pl][(size_t)(y0 + row) * p.sizeX + x0 + col];
+          for (int i = tid; i < 384; i += kThreads)
+          {
+            const int pl = i >> 7, row = (i & 127) >> 4, col = (i & 15) * 16;
+            if ((uint32_t)row < ry && (uint32_t)col < stripW)
+              *reinterpret_cast<uint4 *>(L.fac + pl * 2048 + row * 256 + col) = *reinterpret_cast<const uint4 *>(planesIn[pl] + (size_t)(y0 + row) * p.sizeX + x0 + col);
+          }
         }
+        else
+        {
+          for (int i = tid; i < 3 * 2048; i += kThreads)
+          {
+            const int pl = i >> 11, row = (i & 2047) >> 8, col = i & 255;
+            if ((uint32_t)row < ry && (uint32_t)col < stripW) L.fac[i] = planesIn[pl][(size_t)(y0 + row) * p.sizeX + x0 + col];
+          }
+        }
+        // records (12 dwords of int16 per block) and shift words
+        for (int i = tid; i < kStripBlocks * 12; i += kThreads)
+        {
+          const int sb = i / 12, w = i - sb * 12;
+          uint32_t v = 0;
+          if ((uint32_t)sb < nBlocks) v = reinterpret_cast<const uint32_t *>(p.records + (size_t)by * p.blocksX + strip * kStripBlocks + sb)[4 + w];
+          reinterpret_cast<uint32_t *>(s_rec + sb * 24)[w] = v;
+        }
+        if (tid < kStripBlocks) L.shift[tid] = (uint32_t)tid < nBlocks ? p.shifts[(size_t)by * p.blocksX + strip * kStripBlocks + tid] : 0u;
       }
-      // records (12 dwords of int16 per block) and shift words
-      for (int i = tid; i < kStripBlocks * 12; i += kThreads)
-      {
-        const int sb = i / 12, w = i - sb * 12;
-        uint32_t v = 0;
-        if ((uint32_t)sb < nBlocks) v = reinterpret_cast<const uint32_t *>(p.records + (size_t)by * p.blocksX + strip * kStripBlocks + sb)[4 + w];
-        reinterpret_cast<uint32_t *>(&s_rec[sb][0])[w] = v;
-      }
-      if (tid < kStripBlocks) L.shift[tid] = (uint32_t)tid < nBlocks ? p.shifts[(size_t)by * p.blocksX + strip * kStripBlocks + tid] : 0u;
       __syncthreads();
-      if (wave == 0) phase_f_first_calls(L, p.stripBase[(size_t)by * p.stripsX + strip], lane);
       phase_f_prepare<CH>(L, lane, wave);
+      wave_lds_fence();
+      phase_f_store_const(p, L, x0, y0, ry, lane, wave); // base-independent: 28 of the 35 output bytes per pixel
+      if (wave == 0)
+      {
+        uint32_t base;
+        if (PERSIST)
+        {
+          uint32_t headId = 0;
+          if (p.chainCount > 1 && p.chainRows != 0)
+          {
+            uint32_t c = by / p.chainRows;
+            c = c < p.chainCount - 1 ? c : p.chainCount - 1;
+            headId = c * p.chainRows * p.stripsX;
+          }
+          const uint32_t w = lane < kStripBlocks ? L.shift[lane] : 0u;
+          const uint32_t agg = wave_sum(w >> 24);
+          const unsigned long long own = desc_load(p.desc + id);
+          if ((uint32_t)(own >> 32) == kDescInclusive) base = (uint32_t)sgpr((int)((uint32_t)own - agg));
+          else
+          {
+            base = lookback_base(p, id, headId, agg, lane);
+            if (lane == 0) desc_store(p.desc + id, kDescInclusive, base + agg);
+          }
+        }
+        else
+          base = p.stripBase[id];
+        phase_f_first_calls(L, base, lane);
+      }
       __syncthreads();
-      phase_f_store_const(p, L, x0, y0, ry, lane, wave);
       phase_f_pixels<CH>(p, L, strip, x0, y0, ry, lane, wave);
+    }
+
+    // ---- kernels ---------------------------------------------------------------------------------------------------------
+    template <int CH>
+    __global__ __launch_bounds__(kThreads) void k_fit_search(const EncodeParams p)
+    {
+      __shared__ __attribute__((aligned(16))) uint8_t s_lds[kLdsTotal];
+      load_rsqrt_table(s_lds, (int)threadIdx.x);
+      fit_search_strip<CH, false>(p, blockIdx.x, s_lds, nullptr);
+    }
+
+    template <int CH>
+    __global__ __launch_bounds__(kThreads) void k_dither_store(const EncodeParams p)
+    {
+      __shared__ __attribute__((aligned(16))) uint8_t s_lds[kPhaseFBytes + kStripBlocks * 48];
+      dither_store_strip<CH, false>(p, blockIdx.x, s_lds, nullptr);
+    }
+
+    // The two steps are compiled as real functions for the persistent kernel: inlined into one loop body the register allocator
+    // blends their live ranges (194 VGPRs => 2 waves/SIMD); as calls each keeps its own footprint (<= 3 waves/SIMD, no spills).
+    // They re-read the kernel arguments from the kernarg segment (scalar loads) instead of receiving a pointer to a stack copy.
+    typedef const EncodeParams __attribute__((address_space(4))) *KernargPtr;
+    template <int CH>
+    __device__ __attribute__((noinline)) void step_e(KernargPtr kp, uint32_t id, uint8_t *lds, uint8_t *park)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+      const EncodeParams p = *kp;
+      fit_search_strip<CH, true>(p, id, lds, park);
+#endif
+    }
+    template <int CH>
+    __device__ __attribute__((noinline)) void step_f(KernargPtr kp, uint32_t id, uint8_t *fbase, const uint8_t *park)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+      const EncodeParams p = *kp;
+      dither_store_strip<CH, true>(p, id, fbase, park);
+#endif
+    }
+
+    // Persistent single-launch encode: 3 workgroups per CU loop over the work strips (ticket order).  Each iteration runs the
+    // VALU-bound E step (fit + search) of a new strip and then the HBM-bound F step (dither, decode, all plane stores) of the
+    // strip the SAME workgroup fitted one iteration earlier, whose parked results sit in a private, L2-resident 8 KiB slot.
+    // The one-iteration lag means that by the time an F step asks for its strip's position in the dither chain, every
+    // earlier strip has long published its call count, so the look-back does not wait; and since the workgroups of a CU
+    // drift apart, E and F steps of different workgroups overlap on every CU.
+    // Progress: a look-back only waits for strips with smaller tickets; those were drawn earlier, and an E step never waits.
+    template <int CH>
+    __global__ __launch_bounds__(kThreads, 3) void k_encode_persistent(const EncodeParams p)
+    {
+      __shared__ __attribute__((aligned(16))) uint8_t s_lds[kLdsTotal];
+      __shared__ uint32_t s_ticket;
+      const int tid = (int)threadIdx.x;
+      const KernargPtr kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+      load_rsqrt_table(s_lds, tid);
+      const uint32_t S = p.stripsX * p.blocksY;
+      uint8_t *park = p.park + (size_t)blockIdx.x * 2 * kParkBytes;
+      uint32_t prev = 0xFFFFFFFFu, slot = 0;
+      for (;;)
+      {
+        __syncthreads(); // the previous step's LDS use is over (and the rsqrt table is in place)
+        if (tid == 0) s_ticket = atomicAdd(p.ticket, 1u);
+        __syncthreads();
+        const uint32_t t = s_ticket;
+        if (t < S) step_e<CH>(kp, t, s_lds, park + slot * kParkBytes);
+        if (prev != 0xFFFFFFFFu)
+        {
+          __syncthreads();
+          step_f<CH>(kp, prev, s_lds + kLdsV, park + (slot ^ 1u) * kParkBytes);
+        }
+        if (t >= S) break;
+        prev = t;
+        slot ^= 1u;
+      }
     }
   } // namespace
 
@@ -1344,6 +1560,14 @@ namespace limg_hip
     const dim3 grid(p.stripsX * p.blocksY), block(kThreads);
     if (channels == 4) hipLaunchKernelGGL(k_fit_search<4>, grid, block, 0, s, p);
     else hipLaunchKernelGGL(k_fit_search<3>, grid, block, 0, s, p);
+  }
+
+  void launch_encode_persistent(const EncodeParams &p, int channels, int workgroups, hipStream_t s)
+  {
+    const uint32_t strips = p.stripsX * p.blocksY;
+    const dim3 grid(strips < (uint32_t)workgroups ? strips : (uint32_t)workgroups), block(kThreads);
+    if (channels == 4) hipLaunchKernelGGL(k_encode_persistent<4>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(k_encode_persistent<3>, grid, block, 0, s, p);
   }
 
   void launch_strip_scan(const EncodeParams &p, hipStream_t s) { hipLaunchKernelGGL(k_strip_scan, dim3(1), dim3(1024), 0, s, p); }

@@ -13,11 +13,16 @@ from oracle.bind import PLANES, REC_DTYPE
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def gpu():
+@pytest.fixture(scope="module", params=["fused", "split"])
+def gpu(request):
+    """`fused` = the single-kernel path (decoupled look-back for the dither chain) where it applies;
+    `split` = the three-launch path (fit+search, scan, dither+store) that ragged images always take."""
     import limg_amd
     g = limg_amd.LimgHip(0)  # raises if the HIP library or the device is missing: no fallback
+    g.set_options(force_split=(request.param == "split"))
+    g.mode = request.param
     yield g
+    g.check()
     g.close()
 
 
@@ -89,11 +94,11 @@ def test_forced_shift_sweep(gpu, oracle, bits):
     """BASELINE.json configs[2] 'bit-crush sweep': the search bypassed with shift = 8 - bits on all three factors."""
     s = 8 - bits
     img = oracle.photo_noise(256, 32, 19)
-    gpu.set_forced_shift((s, s, s))
+    gpu.set_options(forced_shift=(s, s, s), force_split=(gpu.mode == "split"))
     try:
         got = gpu.encode3d(img, True)
     finally:
-        gpu.set_forced_shift(None)
+        gpu.set_options(force_split=(gpu.mode == "split"))
     _assert_planes(got, oracle.encode3d(img, True, forced_shift=(s, s, s)), bits)
 
 
