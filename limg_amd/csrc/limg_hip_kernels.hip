@@ -560,6 +560,28 @@ namespace limg_hip
     {
       uint32_t *dec = L.dec + wave * 512;
       uint8_t *out = L.out + wave * 1536;
+      // All noise bytes of the wave's 8 blocks are requested up front (up to 24 independent 64-byte loads in flight): fetched
+      // block by block, each block would expose a full memory round trip.
+      uint32_t nz8[kBlocksPerWave][3];
+#pragma unroll
+      for (int b = 0; b < kBlocksPerWave; b++)
+      {
+        const uint32_t sb = wave * kBlocksPerWave + b;
+        const uint32_t w = (uint32_t)sgpr((int)L.shift[sb]);
+        uint32_t call = (uint32_t)sgpr((int)L.first[sb]);
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+        {
+          const uint32_t s = (w >> (8 * k)) & 0xFF;
+          nz8[b][k] = 0;
+          if (s != 0 && s != 8)
+          {
+            nz8[b][k] = p.noise[(size_t)call * 64 + lane];
+            call++;
+          }
+        }
+      }
+#pragma unroll
       for (int b = 0; b < kBlocksPerWave; b++)
       {
         const uint32_t sb = wave * kBlocksPerWave + b;
@@ -573,7 +595,6 @@ namespace limg_hip
         const uint32_t o = ly * 256 + sb * kBlock + lx;
         const uint32_t w = (uint32_t)sgpr((int)L.shift[sb]);
         const uint32_t shift[3] = { w & 0xFF, (w >> 8) & 0xFF, (w >> 16) & 0xFF };
-        uint32_t call = (uint32_t)sgpr((int)L.first[sb]);
 
         uint32_t f[3];
 #pragma unroll
@@ -583,11 +604,9 @@ namespace limg_hip
           const uint32_t s = shift[k];
           if (s != 0 && s != 8)
           { // src/limg.cpp:824-879: (lane16 & ditherSize) - ditherOffset, add, clamp, shift
-            const uint32_t nz = p.noise[(size_t)call * 64 + (active ? lane : 0)];
-            int t = (int)v + ((int)(nz & ((1u << s) - 1u)) - (int)(1u << (s - 1)));
+            int t = (int)v + ((int)(nz8[b][k] & ((1u << s) - 1u)) - (int)(1u << (s - 1)));
             t = t < 0 ? 0 : (t > 255 ? 255 : t);
             v = (uint32_t)t >> s;
-            call++;
           }
           f[k] = v;
         }
