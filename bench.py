@@ -10,9 +10,9 @@ the metric is quoted on "8K RGBA"), errorFactor 100, fast bit crushing, single d
 so N GPUs encode N images with no data-path collective ("weak" scaling); the only torch.distributed traffic is the
 barrier and the max-over-ranks of the elapsed time.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the whole encode (its three kernel launches together) against the HBM
-roofline with the algorithmic 39 B/px of SURVEY.md 8(d): achieved = 39 B * pixels / (sum of the three kernels' average
-durations, HIP events on the launch stream inside the timed region); per-kernel times are in `roofline.kernels_ms`.
+Prints ONE JSON line (rank 0).  `roofline` prices the encode kernel (one persistent launch per image; `--split` = the
+three-launch fallback path) against the HBM roofline with the algorithmic 39 B/px of SURVEY.md 8(d):
+achieved = 39 B * pixels / average kernel duration (HIP events on the launch stream inside the timed region).
 `cpu_baseline` times the real reference (oracle/_ref, kind "reference") -- or, where that build is absent, the CPU
 oracle (kind "port") -- on a bounded band of the same image on this host's cores (rank 0, N = 1 only).
 """
@@ -34,37 +34,36 @@ def cpu_baseline(width, seed, budget_s=25.0):
     import numpy as np
     from oracle.bind import Oracle, Ref, ref_available
     orc = Oracle()
-    rows = 1024
+    rows = 2048
     band = orc.photo_noise(width, rows, seed)  # the first `rows` rows of the bench image (the generator is row-local)
-    cores = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except Exception:
-        pass
-    out = {}
+        avail = os.cpu_count() or 1
+    # the GPU box gives one GPU a CPU share of 16 cores; the reference makes 4 strips per pool thread
+    pool = max(1, min(avail, 16))
     if ref_available():
         ref = Ref()
         kind = "reference"
 
-        def run(pool):
+        def run(p):
             t = time.perf_counter()
-            ref.encode3d(band, True, error_factor=100, pool_threads=pool)
+            ref.encode3d(band, True, error_factor=100, pool_threads=p)
             return time.perf_counter() - t
     else:
         kind = "port"
 
-        def run(pool):
+        def run(p):
             t = time.perf_counter()
-            orc.encode3d(band, True, error_factor=100, pool_threads=pool, worker_threads=max(pool, 1))
+            orc.encode3d(band, True, error_factor=100, pool_threads=p, worker_threads=max(p, 1))
             return time.perf_counter() - t
     t1 = run(0)                      # single thread, single dither chain (== pThreadPool nullptr)
-    reps = max(1, min(5, int((budget_s * 0.4) / max(t1, 1e-3))))
-    tn = min(run(cores) for _ in range(reps))  # pool of `cores` threads (cores*4 strips), the reference's own threaded mode
+    reps = max(2, min(6, int((budget_s - t1) / max(t1 / pool * 2, 1e-3))))
+    tn = min(run(pool) for _ in range(reps))  # the reference's own threaded mode: pool of `pool` threads = pool*4 row strips
     px = width * rows
-    out = {"value": round(px / tn / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": kind,
-           "sample": "first %d rows (%dx%d, %.1f Mpx) of the bench image, limg_encode3d_test-equivalent (all planes + decode), "
-                     "thread pool of %d; single-thread: %.2f Mpixels/s" % (rows, width, rows, px / 1e6, cores, px / t1 / 1e6)}
-    return out
+    return {"value": round(px / tn / 1e6, 2), "unit": "Mpixels/s", "cores": pool, "kind": kind,
+            "sample": "first %d rows (%dx%d, %.1f Mpx) of the bench image, limg_encode3d_test-equivalent (all planes + decode), thread pool of %d "
+                      "(best of %d); single-thread: %.2f Mpixels/s" % (rows, width, rows, px / 1e6, pool, reps, px / t1 / 1e6)}
 
 
 def main():
@@ -151,8 +150,10 @@ def main():
                        "images_per_step": n_gpus, "parallelism": "independent image per GPU, no data-path collective", "psnr_db": round(psnr, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": None, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PX * px,
-                         "kernels_ms": {"k_fit_search": round(float(kavg[0]), 4), "k_strip_scan": round(float(kavg[1]), 4), "k_dither_store": round(float(kavg[2]), 4)},
-                         "note": "whole encode = 3 launches; achieved = 39 B/px * pixels / sum of the three average kernel durations (HIP events)"},
+                         "kernels_ms": ({"k_fit_search": round(float(kavg[0]), 4), "k_strip_scan": round(float(kavg[1]), 4), "k_dither_store": round(float(kavg[2]), 4)}
+                                        if args.split else {"k_encode_persistent": round(float(kavg[0]), 4)}),
+                         "note": ("whole encode = 3 launches; achieved = 39 B/px * pixels / sum of the three average kernel durations (HIP events)" if args.split else
+                                  "whole encode = one persistent launch; achieved = 39 B/px * pixels / its average duration (HIP events on the launch stream)")},
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:

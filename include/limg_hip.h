@@ -59,8 +59,9 @@ typedef struct limg_hip_compact_out
 typedef struct limg_hip_options
 {
   int32_t forced_shift[3]; /* all three in 0..8: bypass the shift search (a10-a12) with this triple; otherwise {-1,-1,-1} */
-  int32_t force_split_kernels; /* non-0: use the three-launch path (fit+search, scan, dither+store) even where the fused kernel applies */
-  int32_t reserved[4];
+  int32_t force_split_kernels; /* non-0: use the three-launch path (fit+search, scan, dither+store) even where the persistent kernel applies */
+  int32_t dither_pcg;          /* non-0: the reference's PCG dither (src/limg.cpp:799-822, what it runs on hosts without AES-NI) instead of the AES one */
+  int32_t reserved[3];
 } limg_hip_options;
 
 typedef struct limg_hip_context limg_hip_context;
@@ -116,6 +117,7 @@ int limg_hip_profile_end(limg_hip_context *pCtx, float *pMs, int maxEncodes);
  *                              (src/limg.cpp:1893); byte p of call k is what the AES dither ANDs with ditherSize for pixel p.
  *  limg_hip_host_chain_call  : one dither call's state walk over `pixelCount` (<= 64) pixels: returns the next chain value
  *                              (src/limg.cpp:824-879), optionally writing the noise bytes (64-byte buffer).
+ *                              forceSoftwareAes bit 0: do not use AES-NI; bit 1: PCG dither instead of AES.
  *  limg_hip_host_partition   : src/limg.cpp:2114-2134 in block rows: chain c < count-1 owns rows [c*rows, (c+1)*rows), the last the rest. */
 limg_hip_result limg_hip_host_noise_table(uint8_t *pOut, size_t calls);
 uint64_t limg_hip_host_chain_call(uint64_t chainValue, size_t pixelCount, uint8_t *pNoise64, int forceSoftwareAes);

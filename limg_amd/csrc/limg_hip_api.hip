@@ -11,8 +11,8 @@
 
 namespace limg_hip
 {
-  uint64_t chain_call(uint64_t h, unsigned n, uint8_t *noise64, bool forceSoft);
-  uint64_t fill_noise_table(uint64_t h, uint8_t *noise, size_t count);
+  uint64_t chain_call(uint64_t h, unsigned n, uint8_t *noise64, bool forceSoft, bool pcg);
+  uint64_t fill_noise_table(uint64_t h, uint8_t *noise, size_t count, bool pcg);
 }
 
 using namespace limg_hip;
@@ -50,6 +50,7 @@ struct limg_hip_context
   limg_hip_options opt;
   DevBuf records, shifts, stripCalls, stripBase; // per-block / per-strip scratch
   DevBuf noise;                                  // static dither noise table (full-block chains)
+  bool noisePcg = false;                         // which generator the table was built with
   size_t noiseCount = 0;                         // entries generated so far
   uint64_t noiseNext = kDitherSeed;              // chain value after the last generated entry
   DevBuf noiseDyn;                               // data-dependent chains (images with partial blocks)
@@ -71,17 +72,20 @@ namespace
 
   limg_hip_result grow_noise_table(limg_hip_context *c, size_t entries, hipStream_t stream)
   {
+    const bool pcg = c->opt.dither_pcg != 0;
+    if (pcg != c->noisePcg) c->noiseCount = 0;
     if (entries <= c->noiseCount) return limg_hip_success;
     const size_t want = ((entries + kNoiseChunk - 1) / kNoiseChunk) * kNoiseChunk;
     // (re)generate on the host; one-time cost per context and image size class
     std::vector<uint8_t> host(want * 64);
     uint64_t h = kDitherSeed;
-    h = fill_noise_table(h, host.data(), want);
+    h = fill_noise_table(h, host.data(), want, pcg);
     HIP_TRY(hipStreamSynchronize(stream));
     const limg_hip_result r = c->noise.ensure(want * 64);
     if (r != limg_hip_success) return r;
     HIP_TRY(hipMemcpy(c->noise.p, host.data(), want * 64, hipMemcpyHostToDevice));
     c->noiseCount = want;
+    c->noisePcg = pcg;
     c->noiseNext = h;
     return limg_hip_success;
   }
@@ -234,7 +238,7 @@ namespace
           if (bx % kStripBlocks == 0) hBase[(size_t)by * p.stripsX + bx / kStripBlocks] = (uint32_t)call;
           const unsigned rx = (unsigned)((sizeX - (size_t)bx * kBlock) < kBlock ? (sizeX - (size_t)bx * kBlock) : kBlock);
           const uint32_t calls = hShifts[(size_t)by * p.blocksX + bx] >> 24;
-          for (uint32_t k = 0; k < calls; k++, call++) h = chain_call(h, rx * ry, hNoise.data() + call * 64, false);
+          for (uint32_t k = 0; k < calls; k++, call++) h = chain_call(h, rx * ry, hNoise.data() + call * 64, false, c->opt.dither_pcg != 0);
         }
       }
       if ((r = c->noiseDyn.ensure(hNoise.size())) != limg_hip_success) return r;
@@ -356,14 +360,14 @@ extern "C"
   limg_hip_result limg_hip_host_noise_table(uint8_t *pOut, size_t calls)
   {
     if (!pOut) return limg_hip_error_ArgumentNull;
-    fill_noise_table(kDitherSeed, pOut, calls);
+    fill_noise_table(kDitherSeed, pOut, calls, false);
     return limg_hip_success;
   }
 
   uint64_t limg_hip_host_chain_call(uint64_t chainValue, size_t pixelCount, uint8_t *pNoise64, int forceSoftwareAes)
   {
     if (pixelCount > 64) return 0;
-    return chain_call(chainValue, (unsigned)pixelCount, pNoise64, forceSoftwareAes != 0);
+    return chain_call(chainValue, (unsigned)pixelCount, pNoise64, (forceSoftwareAes & 1) != 0, (forceSoftwareAes & 2) != 0);
   }
 
   limg_hip_result limg_hip_host_partition(size_t sizeY, int poolThreads, uint32_t *pChainCount, uint32_t *pChainBlockRows)

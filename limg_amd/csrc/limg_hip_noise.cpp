@@ -120,9 +120,10 @@ namespace limg_hip
   }
 
   // One dither call over `n` pixels starting from chain value `h`: writes n noise bytes (padded to 64), returns G_n(h).
-  uint64_t chain_call(uint64_t h, unsigned n, uint8_t *noise64, bool forceSoft)
+  // pcg == true: the reference's fallback for hosts without AES-NI (src/limg.cpp:799-822): every pixel is a PCG step.
+  uint64_t chain_call(uint64_t h, unsigned n, uint8_t *noise64, bool forceSoft, bool pcg)
   {
-    const unsigned rounds = n >= 8 ? n / 8 : 0;
+    const unsigned rounds = (!pcg && n >= 8) ? n / 8 : 0;
     if (rounds)
     {
 #if defined(__x86_64__)
@@ -141,9 +142,9 @@ namespace limg_hip
 
   // Static table for chains made of full 8x8 blocks only: entries [first, first + count) given the chain value at `first`.
   // Returns the chain value after the last generated entry (so the table can be grown later).
-  uint64_t fill_noise_table(uint64_t h, uint8_t *noise, size_t count)
+  uint64_t fill_noise_table(uint64_t h, uint8_t *noise, size_t count, bool pcg)
   {
-    for (size_t k = 0; k < count; k++) h = chain_call(h, 64, noise + k * 64, false);
+    for (size_t k = 0; k < count; k++) h = chain_call(h, 64, noise + k * 64, false, pcg);
     return h;
   }
 }

@@ -56,20 +56,27 @@ def test_stagewise_small(gpu, oracle):
 def test_golden_cases(gpu):
     idx, z = gu.cases()
     for i, m in enumerate(idx):
-        if m["dither"] != 0:
-            continue  # PCG dither is a CPU-side variant, not on the GPU path yet
-        got = gpu.encode3d(z["c%02d_in" % i], m["alpha"], error_factor=m["ef"], pool_threads=m["pool"], fast=m["fast"])
+        gpu.set_options(force_split=(gpu.mode == "split"), dither_pcg=(m["dither"] != 0))
+        try:
+            got = gpu.encode3d(z["c%02d_in" % i], m["alpha"], error_factor=m["ef"], pool_threads=m["pool"], fast=m["fast"])
+        finally:
+            gpu.set_options(force_split=(gpu.mode == "split"))
         want = {k: z["c%02d_%s" % (i, k)] for k in PLANES}
         _assert_planes(got, want, (i, m))
 
 
-@pytest.mark.parametrize("name", ["original_rgb", "original_as_rgba", "rg1024", "rga1024", "pn1024", "pn1024_ef25", "pn1024_pool2", "original_rgb_ef0"])
+@pytest.mark.parametrize("name", ["original_rgb", "original_as_rgba", "rg1024", "rga1024", "pn1024", "pn1024_ef25", "pn1024_pool2", "pn1024_pcg", "original_rgb_ef0"])
 def test_full_image_hashes(gpu, oracle, name):
     """Plane hashes of the real reference on original.png (config #1) and on 1024x1024 of each synthetic generator."""
     e = gu.hashes()[name]
     img = gu.big_input(name, oracle)
     kw = dict(e["kw"])
-    got = gpu.encode3d(img, e["alpha"], **kw)
+    pcg = kw.pop("dither_mode", 0) != 0
+    gpu.set_options(force_split=(gpu.mode == "split"), dither_pcg=pcg)
+    try:
+        got = gpu.encode3d(img, e["alpha"], **kw)
+    finally:
+        gpu.set_options(force_split=(gpu.mode == "split"))
     for k in PLANES:
         assert oracle.fnv(got[k]) == e[k], (name, k)
     psnr, mse = gpu.compare(img, got["pDecoded"], e["alpha"])
@@ -112,6 +119,19 @@ def test_strip_restart_chains(gpu, oracle, pool):
 def test_accurate_mode(gpu, oracle, alpha):
     img = oracle.photo_noise(256, 24, 29)
     _assert_planes(gpu.encode3d(img, alpha, fast=False), oracle.encode3d(img, alpha, fast=False), alpha)
+
+
+@pytest.mark.parametrize("w,h", [(256, 64), (61, 27)])
+def test_pcg_dither(gpu, oracle, w, h):
+    """a14: the reference's non-AES dither (PCG) -- full blocks through the noise table, ragged through the chain walk."""
+    from oracle.bind import DITHER_PCG
+    img = oracle.photo_noise(w, h, 31)
+    gpu.set_options(force_split=(gpu.mode == "split"), dither_pcg=True)
+    try:
+        got = gpu.encode3d(img, True)
+    finally:
+        gpu.set_options(force_split=(gpu.mode == "split"))
+    _assert_planes(got, oracle.encode3d(img, True, dither_mode=DITHER_PCG), (w, h))
 
 
 def test_degenerate_blocks(gpu, oracle):

@@ -155,3 +155,20 @@ def test_search_automaton_equals_oracle_on_random_outcomes(oracle):
         except StopIteration as e:
             want = e.value
         assert got == want
+
+
+def test_pcg_chain_walk(lib, oracle):
+    from oracle.bind import DITHER_PCG
+    c = gu.chain()
+    for n in (64, 16, 7):
+        h = 0xCA7F00D15BADF00D
+        for want in c["pcg_%d" % n]:
+            buf = np.zeros(64, dtype=np.uint8)
+            h = lib.limg_hip_host_chain_call(h, n, buf.ctypes.data_as(C.c_void_p), 2)
+            assert "%016x" % h == want
+    f = (np.arange(64) * 4 + 1).astype(np.uint8)
+    for s in range(1, 8):
+        buf = np.zeros(64, dtype=np.uint8)
+        lib.limg_hip_host_chain_call(0xCA7F00D15BADF00D, 64, buf.ctypes.data_as(C.c_void_p), 2)
+        t = f.astype(np.int32) + ((buf.astype(np.int32) & ((1 << s) - 1)) - (1 << (s - 1)))
+        assert (np.clip(t, 0, 255) >> s).tolist() == c["dither_bytes"]["pcg_s%d" % s]
