@@ -59,7 +59,7 @@ struct limg_hip_context
   DevBuf in, planes;                             // staging for the host-pointer entry points
   DevBuf cmp;                                    // 8-byte accumulator of limg_hip_compare
   // optional per-kernel timing (bench): 4 events per encode, recorded on the caller's stream, read back in one go
-  int persistentWorkgroups = 768; // 3 per CU (LDS-limited), set from the device's CU count at init
+  int persistentWorkgroups = 1024; // 4 per CU (LDS-limited), set from the device's CU count at init
   bool forceSplit = false; // options: run the three-kernel path even where the fused kernel applies (A/B, tests)
   bool profiling = false;
   std::vector<hipEvent_t> events;
@@ -283,7 +283,7 @@ extern "C"
     if (!c) return limg_hip_error_MemoryAllocationFailure;
     c->device = device;
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->persistentWorkgroups = 3 * prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->persistentWorkgroups = 4 * prop.multiProcessorCount;
     limg_hip_default_options(&c->opt);
     *ppCtx = c;
     return limg_hip_success;

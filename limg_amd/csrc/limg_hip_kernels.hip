@@ -767,6 +767,7 @@ namespace limg_hip
     }
 
     enum : int { kDirA = 0, kDirB = 1, kDirC = 2 };
+    constexpr int kBatch = 4; // blocks per wave whose pass contributions are parked at a time
     constexpr uint32_t kBig = 16u; // some |record value| > kRecordLimit => generic 32-bit trial
 
     // Pixel-order accumulation (as `serial_sums`) followed, lane-parallel over the wave's 8 blocks, by everything the next
@@ -776,7 +777,7 @@ namespace limg_hip
     __device__ __forceinline__ void serial_sums2(const float *V, BlkF *blk, int lane)
     {
       wave_lds_fence();
-      if (lane < 32)
+      if (lane < 4 * kBatch)
       {
         const int b = lane >> 2, c = lane & 3;
         const float *src = V + b * kVDw + c;
@@ -864,9 +865,9 @@ namespace limg_hip
     }
 
     // LDS of an E task (fit + search of one work strip); the F task's areas overlay `V`.
-    constexpr int kLdsRsq = 0, kLdsStrip = 4096, kLdsV = kLdsStrip + 8 * kRowDw * 4, kLdsVBytes = kWaves * kBlocksPerWave * kVDw * 4;
+    constexpr int kLdsRsq = 0, kLdsStrip = 4096, kLdsV = kLdsStrip + 8 * kRowDw * 4, kLdsVBytes = kWaves * kBatch * kVDw * 4;
     constexpr int kLdsBlk = kLdsV + kLdsVBytes, kLdsCalls = kLdsBlk + kStripBlocks * 192, kLdsTotal = kLdsCalls + 16;
-    static_assert(kLdsTotal == 51984, "3 workgroups per CU");
+    static_assert(kLdsTotal <= 40960 - 16, "at least 4 workgroups per CU");
 
     __device__ __forceinline__ void load_rsqrt_table(uint8_t *lds, int tid)
     {
@@ -919,7 +920,7 @@ namespace limg_hip
       }
       __syncthreads();
 
-      float *V = s_V + wave * kBlocksPerWave * kVDw;
+      float *V = s_V + wave * kBatch * kVDw;
       BlkF *blk = s_blk + wave * kBlocksPerWave;
 
       // per-block geometry (wave-uniform)
@@ -932,18 +933,25 @@ namespace limg_hip
         return true;
       };
 
-      // Per-block values that stay in registers across the phases (all loops over b are fully unrolled).
-      uint32_t px8[kBlocksPerWave];
-      float est8[kBlocksPerWave][4];
+      // The float stage runs in batches of kBatch blocks per wave: the parked contributions of one batch are what limits the
+      // workgroups per CU (LDS), and 4 blocks x 4 waves keep it at 4 workgroups per CU.
+      // Per-block values of the batch stay in registers across the phases (the loops over i are fully unrolled).
+#pragma unroll 1
+      for (int h = 0; h < kBlocksPerWave / kBatch; h++)
+      {
+      uint32_t px8[kBatch];
+      float est8[kBatch][4];
+      BlkF *const blkh = blk + h * kBatch;
 
       // ---- phase A: sums, average, first direction pass (a4, a5/a6 pass 1) ------------------------------------------
 #pragma unroll
-      for (int b = 0; b < kBlocksPerWave; b++)
+      for (int i = 0; i < kBatch; i++)
       {
+        const int b = h * kBatch + i;
         uint32_t rx, n;
-        px8[b] = 0;
+        px8[i] = 0;
 #pragma unroll
-        for (int c = 0; c < 4; c++) est8[b][c] = 0.0f;
+        for (int c = 0; c < 4; c++) est8[i][c] = 0.0f;
         if (!geom(b, rx, n))
         {
           if (lane == 0) { blk[b].flags = 0; blk[b].n = 0; blk[b].inv_count = 0.0f; }
@@ -955,7 +963,7 @@ namespace limg_hip
         else { const uint32_t l = (uint32_t)lane < n ? (uint32_t)lane : 0u; ly = l / rx; lx = l - ly * rx; }
         uint32_t px = s_strip[ly * kRowDw + sb * kBlock + lx];
         px = (uint32_t)lane < n ? px : 0u;
-        px8[b] = px;
+        px8[i] = px;
         float pf[4];
         px_to_float(px, pf);
         const uint32_t s02 = wave_sum(px & 0x00FF00FFu), s13 = wave_sum((px >> 8) & 0x00FF00FFu);
@@ -971,7 +979,7 @@ namespace limg_hip
         for (int c = 0; c < 4; c++) d[c] = pf[c] - avg[c];
         if (CH == 3) d[3] = 0.0f;
         unit2<CH>(s_rsq, d, (uint32_t)lane < n, v);
-        store_v(V + b * kVDw, lane, v);
+        store_v(V + i * kVDw, lane, v);
         if (lane == 0)
         {
           *reinterpret_cast<float4 *>(blk[b].avg) = make_float4(avg[0], avg[1], avg[2], avg[3]);
@@ -983,12 +991,13 @@ namespace limg_hip
           blk[b].inv_count = inv_count; blk[b].n = n; blk[b].flags = kValid;
         }
       }
-      serial_sums2<CH, kDirA>(V, blk, lane);
+      serial_sums2<CH, kDirA>(V, blkh, lane);
 
       // ---- phase B: factor A extrema, residual -> second direction (pass 2) --------------------------------------------
 #pragma unroll
-      for (int b = 0; b < kBlocksPerWave; b++)
+      for (int i = 0; i < kBatch; i++)
       {
+        const int b = h * kBatch + i;
         uint32_t rx, n;
         if (!geom(b, rx, n)) continue;
         if ((uint32_t)sgpr((int)blk[b].flags) & kZeroA) continue;
@@ -996,7 +1005,7 @@ namespace limg_hip
         const float dirA[4] = { dA4.x, dA4.y, dA4.z, dA4.w }, avg[4] = { av4.x, av4.y, av4.z, av4.w };
         const float invA = blk[b].invA;
         float pf[4], l[4], e[4], v[4];
-        px_to_float(px8[b], pf);
+        px_to_float(px8[i], pf);
         const bool active = (uint32_t)lane < n;
 #pragma unroll
         for (int c = 0; c < 4; c++) l[c] = pf[c] - avg[c];
@@ -1005,18 +1014,19 @@ namespace limg_hip
         wave_min_max(mn, mx);
         mn = vmin(mn, 0.0f); mx = vmax(mx, 0.0f);
 #pragma unroll
-        for (int c = 0; c < 4; c++) { est8[b][c] = avg[c] + fA * dirA[c]; e[c] = pf[c] - est8[b][c]; }
+        for (int c = 0; c < 4; c++) { est8[i][c] = avg[c] + fA * dirA[c]; e[c] = pf[c] - est8[i][c]; }
         if (CH == 3) e[3] = 0.0f;
         unit2<CH>(s_rsq, e, active, v);
-        store_v(V + b * kVDw, lane, v);
+        store_v(V + i * kVDw, lane, v);
         if (lane == 0) { blk[b].mm[0] = mn; blk[b].mm[1] = mx; }
       }
-      serial_sums2<CH, kDirB>(V, blk, lane);
+      serial_sums2<CH, kDirB>(V, blkh, lane);
 
       // ---- phase C: factor B (and, 3 ch, C) extrema; 4 ch: residual -> third direction (pass 3) ---------------------
 #pragma unroll
-      for (int b = 0; b < kBlocksPerWave; b++)
+      for (int i = 0; i < kBatch; i++)
       {
+        const int b = h * kBatch + i;
         uint32_t rx, n;
         if (!geom(b, rx, n)) continue;
         if ((uint32_t)sgpr((int)blk[b].flags) & kZeroB) continue; // 1/0 = inf => every fB is NaN upstream => B and C collapse to 0
@@ -1024,10 +1034,10 @@ namespace limg_hip
         const float dirB[4] = { dB4.x, dB4.y, dB4.z, dB4.w };
         const float invB = blk[b].invB;
         float pf[4], l[4];
-        px_to_float(px8[b], pf);
+        px_to_float(px8[i], pf);
         const bool active = (uint32_t)lane < n;
 #pragma unroll
-        for (int c = 0; c < 4; c++) l[c] = pf[c] - est8[b][c];
+        for (int c = 0; c < 4; c++) l[c] = pf[c] - est8[i][c];
         const float fB = dpps<CH>(l, dirB) * invB;
         float mnB = active ? fB : FLT_MAX, mxB = active ? fB : -FLT_MAX;
         if (CH == 4)
@@ -1035,13 +1045,13 @@ namespace limg_hip
           wave_min_max(mnB, mxB);
           float e[4], v[4];
 #pragma unroll
-          for (int c = 0; c < 4; c++) { est8[b][c] = est8[b][c] + fB * dirB[c]; e[c] = pf[c] - est8[b][c]; }
+          for (int c = 0; c < 4; c++) { est8[i][c] = est8[i][c] + fB * dirB[c]; e[c] = pf[c] - est8[i][c]; }
           unit2<CH>(s_rsq, e, active, v);
-          store_v(V + b * kVDw, lane, v);
+          store_v(V + i * kVDw, lane, v);
           if (lane == 0)
           {
             blk[b].mm[2] = mnB; blk[b].mm[3] = mxB;
-            *reinterpret_cast<float4 *>(blk[b].est0) = make_float4(est8[b][0], est8[b][1], est8[b][2], est8[b][3]);
+            *reinterpret_cast<float4 *>(blk[b].est0) = make_float4(est8[i][0], est8[i][1], est8[i][2], est8[i][3]);
           }
         }
         else
@@ -1060,7 +1070,7 @@ namespace limg_hip
             const float invC = 1.0f / dpps<CH>(dirC, dirC);
             float e[4];
 #pragma unroll
-            for (int c = 0; c < 4; c++) e[c] = pf[c] - (est8[b][c] + fB * dirB[c]);
+            for (int c = 0; c < 4; c++) e[c] = pf[c] - (est8[i][c] + fB * dirB[c]);
             const float fC = dpps<CH>(e, dirC) * invC;
             mnC = active ? fC : FLT_MAX; mxC = active ? fC : -FLT_MAX;
             wave_min_max(mnB, mxB);
@@ -1079,12 +1089,13 @@ namespace limg_hip
       if (CH == 4)
       {
         // blocks that skipped phase C left stale pass-2 contributions in V; their dirC is never used (flags)
-        serial_sums2<CH, kDirC>(V, blk, lane);
+        serial_sums2<CH, kDirC>(V, blkh, lane);
         // ---- phase D: factor C extrema (pass 4).  Upstream never advances its estimate pointer in this loop
         //      (src/limg_factorization.h:748-758), so every pixel is measured against pixel 0's A+B estimate.
 #pragma unroll
-        for (int b = 0; b < kBlocksPerWave; b++)
+        for (int i = 0; i < kBatch; i++)
         {
+          const int b = h * kBatch + i;
           uint32_t rx, n;
           if (!geom(b, rx, n)) continue;
           if ((uint32_t)sgpr((int)blk[b].flags) & kZeroC) continue;
@@ -1092,7 +1103,7 @@ namespace limg_hip
           const float dirC[4] = { dC4.x, dC4.y, dC4.z, dC4.w }, est0[4] = { e04.x, e04.y, e04.z, e04.w };
           const float invC = blk[b].invC;
           float pf[4], l[4];
-          px_to_float(px8[b], pf);
+          px_to_float(px8[i], pf);
           const bool active = (uint32_t)lane < n;
 #pragma unroll
           for (int c = 0; c < 4; c++) l[c] = pf[c] - est0[c];
@@ -1102,6 +1113,7 @@ namespace limg_hip
           if (lane == 0) { blk[b].mm[4] = mnC; blk[b].mm[5] = mxC; }
         }
       }
+      } // batches
       wave_lds_fence();
 
       // ---- records (src/limg_factorization.h:764-790): 8 lanes per block, 3 values per lane --------------------------
@@ -1415,7 +1427,7 @@ namespace limg_hip
     // F task: dither + stores + decode of one work strip from the parked per-block results.
     // PERSIST == false: the strip's chain position comes from k_strip_scan (p.stripBase);
     // PERSIST == true : from the look-back over the descriptors, and the strip's inclusive count is published first thing.
-    static_assert(kPhaseFBytes + kStripBlocks * 48 <= kLdsVBytes, "the F task's LDS must fit the E task's parked-contribution area");
+    static_assert(kPhaseFBytes + kStripBlocks * 48 <= kLdsTotal - kLdsStrip - 16, "the F step's LDS overlays everything of the E step but the rsqrt table");
 
     template <int CH, bool PERSIST>
     __device__ __forceinline__ void dither_store_strip(const EncodeParams &p, const uint32_t id, uint8_t *fbase, const uint8_t *park)
@@ -1545,7 +1557,7 @@ namespace limg_hip
     // drift apart, E and F steps of different workgroups overlap on every CU.
     // Progress: a look-back only waits for strips with smaller tickets; those were drawn earlier, and an E step never waits.
     template <int CH>
-    __global__ __launch_bounds__(kThreads, 3) void k_encode_persistent(const EncodeParams p)
+    __global__ __launch_bounds__(kThreads, 4) void k_encode_persistent(const EncodeParams p)
     {
       __shared__ __attribute__((aligned(16))) uint8_t s_lds[kLdsTotal];
       __shared__ uint32_t s_ticket;
@@ -1565,7 +1577,7 @@ namespace limg_hip
         if (prev != 0xFFFFFFFFu)
         {
           __syncthreads();
-          step_f<CH>(kp, prev, s_lds + kLdsV, park + (slot ^ 1u) * kParkBytes);
+          step_f<CH>(kp, prev, s_lds + kLdsStrip, park + (slot ^ 1u) * kParkBytes);
         }
         if (t >= S) break;
         prev = t;
