@@ -76,7 +76,6 @@ def main():
     ap.add_argument("--error-factor", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split", action="store_true", help="three-launch path instead of the fused kernel")
-    ap.add_argument("--dbg", type=int, default=0, help="timing experiments (results invalid)")
     ap.add_argument("--forced-shift", type=int, default=-1, help="bypass the shift search with this shift on all three factors (bit-crush sweep)")
     args = ap.parse_args()
 
@@ -102,8 +101,8 @@ def main():
 
     W = H = args.size
     g = limg_amd.LimgHip(local_rank if world > 1 else 0)
-    if args.forced_shift >= 0 or args.split or args.dbg:
-        g.set_options(forced_shift=(args.forced_shift,) * 3 if args.forced_shift >= 0 else None, force_split=args.split, dbg=args.dbg)
+    if args.forced_shift >= 0 or args.split:
+        g.set_options(forced_shift=(args.forced_shift,) * 3 if args.forced_shift >= 0 else None, force_split=args.split)
     img = g.synth_device(args.workload, W, H, seed=1 + rank)
     planes = g.alloc_planes_device(W, H)
     torch.cuda.synchronize()

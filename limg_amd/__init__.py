@@ -123,7 +123,7 @@ class LimgHip:
         except Exception:
             pass
 
-    def set_options(self, forced_shift=None, force_split=False, dither_pcg=False, dbg=0):
+    def set_options(self, forced_shift=None, force_split=False, dither_pcg=False):
         o = Options()
         self.lib.limg_hip_default_options(C.byref(o))
         if forced_shift is not None:
@@ -131,7 +131,6 @@ class LimgHip:
                 o.forced_shift[i] = int(forced_shift[i])
         o.force_split_kernels = int(force_split)
         o.dither_pcg = int(dither_pcg)
-        o.reserved[0] = int(dbg)
         _check(self.lib.limg_hip_set_options(self.ctx, C.byref(o)), "limg_hip_set_options")
 
     def set_forced_shift(self, shift=None):

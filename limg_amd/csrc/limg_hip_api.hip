@@ -192,7 +192,6 @@ namespace
       HIP_TRY(hipMemsetAsync(c->lookback.p, 0, 16 + strips * 8, stream));
       p.ticket = (uint32_t *)c->lookback.p;
       p.desc = (unsigned long long *)((uint8_t *)c->lookback.p + 16);
-      p.dbg = c->opt.reserved[0];
       p.compactOut = compact != nullptr;
       if ((r = c->park.ensure((size_t)c->persistentWorkgroups * 2 * 8192)) != limg_hip_success) return r;
       p.park = (uint8_t *)c->park.p;

@@ -39,7 +39,6 @@ namespace limg_hip
     uint32_t *ticket;   // [0] = next strip id, [1] = look-back timeout flag
     uint8_t *park;      // persistent kernel: per workgroup two 8 KiB slots holding a strip's parked results between its E and F steps
     int32_t compactOut; // persistent kernel: also write records / shift words to the raster-order arrays
-    int32_t dbg;        // timing experiments only (limg_hip_options.reserved[0]): 1 = no look-back, 2 = no pixel phase, 4 = no const stores
   };
 
   void launch_fit_search(const EncodeParams &p, int channels, hipStream_t s);

@@ -1,13 +1,19 @@
 // limg_hip_kernels.hip -- gfx950 kernels of the limg encode hot path.
 //
 // Path (reference file:line, all relative to the upstream repository):
-//   k_fit_search   : block gather src/limg.cpp:1899-1905, channel sums :466-497, direction fit + extrema
-//                    src/limg_factorization.h:578-794 (4 ch) / :382-576 (3 ch), colour-error state src/limg_internal.h:426-452,
-//                    per-pixel factors src/limg_factorization.h:98-197, shift search src/limg_bit_crush.h:331-392 + :502-666
-//                    (accurate mode :668-830) on top of the trial src/limg_bit_crush_simd.h:311-810
-//   k_strip_scan   : the dither chain order of src/limg.cpp:1893,1951-1958 turned into call indices (exclusive scan)
-//   k_dither_store : dither src/limg.cpp:824-879 (noise bytes come from the context's table), plane stores :2004-2093,
-//                    integer decode src/limg_decode.h:36-236
+//   E step (fit_search_strip)   : block gather src/limg.cpp:1899-1905, channel sums :466-497, direction fit + extrema
+//                                 src/limg_factorization.h:578-794 (4 ch) / :382-576 (3 ch), colour-error state
+//                                 src/limg_internal.h:426-452, per-pixel factors src/limg_factorization.h:98-197, shift search
+//                                 src/limg_bit_crush.h:331-392 + :502-666 (accurate mode :668-830) on top of the trial
+//                                 src/limg_bit_crush_simd.h:311-810
+//   F step (dither_store_strip) : dither src/limg.cpp:824-879 / :799-822 (noise bytes from the context's table), plane stores
+//                                 :2004-2093, integer decode src/limg_decode.h:36-236
+//   chain position              : the dither chain order of src/limg.cpp:1893,1951-1958 = exclusive prefix of the per-block
+//                                 dither-call counts (decoupled look-back in the persistent kernel, k_strip_scan in the split path)
+//
+// Kernels: k_encode_persistent (one launch per image: every workgroup loops over work strips, E step of a new strip then the
+// F step of the strip it fitted one iteration earlier) and the three-launch split path k_fit_search / k_strip_scan /
+// k_dither_store (images with partial edge blocks, whose chain has to be walked on the host; `_perf` mode; A/B testing).
 //
 // Work decomposition: one 256-thread workgroup owns a "work strip" of 32 adjacent 8x8 image blocks (256 x 8 pixels): its
 // eight 1 KiB pixel rows are read with 16-byte-per-lane loads into LDS, each of the 4 waves then owns 8 blocks and works
@@ -16,10 +22,10 @@
 // Float-stage numerics are those of the reference's SSE4.1 path executed strictly (see DESIGN.md "numerics"):
 //   * DPPS summation order (x0y0 + x1y1) + (x2y2 + x3y3), no FMA contraction (built with -ffp-contract=off);
 //   * RSQRTPS through the captured 2048-entry table (limg_rsqrt_x86_table.h) held in LDS;
-//   * the three direction accumulations run in *pixel order*: the per-pixel unit vectors of 8 blocks are parked in LDS
-//     and 32 lanes (8 blocks x 4 channels) each walk one serial 64-term chain -- the serial order costs ~2 instructions
-//     per term for 32 chains at once instead of a 64-step dependent chain per block;
-//   * correctly rounded division (hipcc default) and round-to-nearest-even conversions.
+//   * the three direction accumulations run in *pixel order*: the per-pixel unit vectors of a batch of 4 blocks are parked in
+//     LDS and 16 lanes (4 blocks x 4 channels) each walk one serial 64-term chain -- ~2 instructions per term for 16
+//     chains at once instead of a 64-step dependent chain per block;
+//   * correctly rounded division (hipcc default), once per batch and lane-parallel; round-to-nearest-even conversions.
 #include "limg_hip_internal.h"
 #include "limg_rsqrt_x86_table.h"
 #include "limg_search_table.h"
@@ -41,17 +47,6 @@ namespace limg_hip
     __constant__ uint2 d_search_tab[LIMG_SEARCH_STATES] = LIMG_SEARCH_TABLE_INIT;
 
     enum : uint32_t { kZeroA = 1u, kZeroB = 2u, kZeroC = 4u, kValid = 8u };
-
-    // per-block state parked in LDS between the phases of k_fit_search
-    struct Blk
-    {
-      float avg[4], dirA[4], dirB[4], dirC[4], est0[4];
-      float mm[6]; // minA maxA minB maxB minC maxC
-      float inv_count, invN[3];
-      uint32_t n, rx, flags, pad[3];
-      int16_t rec[24]; // dirA_min[4] dirA_max[4] dirB_offset[4] dirB_mag[4] dirC_offset[4] dirC_mag[4]
-    };
-    static_assert(sizeof(Blk) == 192, "Blk layout");
 
     // ---- wave64 helpers -------------------------------------------------------------------------------------------
     __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -78,21 +73,6 @@ namespace limg_hip
       return (uint32_t)__builtin_amdgcn_readlane(v, 63);
     }
 
-    // exact (order independent) float min / max over the wave; no NaN may be present
-    template <bool MAX>
-    __device__ __forceinline__ float wave_minmax(float x)
-    {
-      auto op = [](float a, float b) { return MAX ? __builtin_fmaxf(a, b) : __builtin_fminf(a, b); };
-      int v = __float_as_int(x);
-      v = __float_as_int(op(__int_as_float(v), __int_as_float(dpp<0xB1, 0xF>(v, v))));
-      v = __float_as_int(op(__int_as_float(v), __int_as_float(dpp<0x4E, 0xF>(v, v))));
-      v = __float_as_int(op(__int_as_float(v), __int_as_float(dpp<0x141, 0xF>(v, v))));
-      v = __float_as_int(op(__int_as_float(v), __int_as_float(dpp<0x140, 0xF>(v, v))));
-      v = __float_as_int(op(__int_as_float(v), __int_as_float(dpp<0x142, 0xA>(v, v))));
-      v = __float_as_int(op(__int_as_float(v), __int_as_float(dpp<0x143, 0xC>(v, v))));
-      return __int_as_float(__builtin_amdgcn_readlane(v, 63));
-    }
-
     __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
     __device__ __forceinline__ float sgprf(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
@@ -106,39 +86,6 @@ namespace limg_hip
       return (p0 + p1) + (p2 + p3);
     }
 
-    // RSQRTPS (Intel) through the table in LDS; argument is a finite positive normal number here
-    __device__ __forceinline__ float rsqrt_x86(const unsigned short *tab, float x)
-    {
-      const uint32_t b = __float_as_uint(x);
-      const uint32_t idx = ((b >> 13) & 0x7FFu) ^ 0x400u; // [exponent lsb : top 10 mantissa bits], odd exponents first
-      const int e = (int)((b >> 23) & 0xFF);
-      const int k = (e - 127) >> 1;
-      return __uint_as_float(((uint32_t)(126 - k) << 23) | ((uint32_t)tab[idx] << 11));
-    }
-
-    // MINPS / MAXPS operand semantics (second operand when unordered); inputs here are never NaN but keep the form
-    __device__ __forceinline__ float minps(float a, float b) { return a < b ? a : b; }
-    __device__ __forceinline__ float maxps(float a, float b) { return a > b ? a : b; }
-
-    // sign-normalised unit vector of one pixel's difference vector (src/limg_factorization.h:605-623 and twins)
-    template <int CH>
-    __device__ __forceinline__ void unit_contribution(const unsigned short *tab, const float d[4], bool active, float out[4])
-    {
-      const bool nz = !(d[0] == 0.0f && d[1] == 0.0f && d[2] == 0.0f && d[3] == 0.0f);
-      const float e3 = FLT_EPSILON * 3, e2 = FLT_EPSILON * 2, e1 = FLT_EPSILON;
-      const float hmin0 = minps(d[0] - e3, d[2] - e1), hmin1 = minps(d[1] - e2, d[3] - 0.0f);
-      const float hmax0 = maxps(d[0] + e3, d[2] + e1), hmax1 = maxps(d[1] + e2, d[3] + 0.0f);
-      const float abs_min = __builtin_fabsf(minps(hmin0, hmin1));
-      const float mx = maxps(hmax0, hmax1);
-      float len2 = dpps<CH>(d, d);
-      len2 = nz ? len2 : 1.0f; // keep the table index sane on skipped lanes
-      float inv = rsqrt_x86(tab, len2);
-      inv = (abs_min > mx) ? -inv : inv;
-      const bool use = nz && active;
-#pragma unroll
-      for (int c = 0; c < 4; c++) out[c] = use ? d[c] * inv : 0.0f;
-    }
-
     __device__ __forceinline__ void px_to_float(uint32_t px, float f[4])
     {
       f[0] = (float)(px & 0xFF); f[1] = (float)((px >> 8) & 0xFF); f[2] = (float)((px >> 16) & 0xFF); f[3] = (float)(px >> 24);
@@ -149,24 +96,6 @@ namespace limg_hip
     __device__ __forceinline__ void store_v(float *V, int lane, const float v[4])
     {
       *reinterpret_cast<float4 *>(V + lane * 4) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-
-    // Pixel-order accumulation of the parked contributions of this wave's 8 blocks: lane (b, c) walks V[b][0..63][c].
-    __device__ __forceinline__ void serial_sums(const float *V, Blk *blk, int which, int lane)
-    {
-      wave_lds_fence();
-      if (lane < 32)
-      {
-        const int b = lane >> 2, c = lane & 3;
-        const float *src = V + b * kVDw + c;
-        float s = 0.0f;
-#pragma unroll 16
-        for (int i = 0; i < 64; i++) s = s + src[i * 4];
-        const float dir = s * blk[b].inv_count;
-        float *dst = which == 0 ? blk[b].dirA : (which == 1 ? blk[b].dirB : blk[b].dirC);
-        dst[c] = dir;
-      }
-      wave_lds_fence();
     }
 
     // ---- integer stage ------------------------------------------------------------------------------------------------
@@ -742,9 +671,11 @@ namespace limg_hip
     __device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
     __device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
-    // sign-normalised unit vector, lean form of `unit_contribution` (same arithmetic; min/max by v_min3/v_max3 -- their
-    // only differences from MINPS/MAXPS are NaN handling and the sign of a zero result, neither of which can reach the
-    // `|min| > max` comparison outcome; the NaN-producing degenerate cases never get here, see kZero* flags).
+    // Sign-normalised unit vector of one pixel's difference vector (src/limg_factorization.h:605-623 and its twins in every
+    // pass): bias each lane by {3e,2e,e,0}, flip the sign when |min over lanes| > max over lanes, scale by RSQRTPS(d.d).
+    // min/max by v_min3/v_max3: their only differences from MINPS/MAXPS are NaN handling and the sign of a zero result,
+    // neither of which can reach the comparison's outcome; the NaN-producing degenerate cases never get here (kZero* flags).
+    // RSQRTPS = the captured Intel table: index = [exponent lsb : top 10 mantissa bits], exponent = 126 - floor((e - 127) / 2).
     template <int CH>
     __device__ __forceinline__ void unit2(const unsigned short *tab, const float d[4], bool active, float out[4])
     {
