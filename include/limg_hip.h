@@ -61,7 +61,9 @@ typedef struct limg_hip_options
   int32_t forced_shift[3]; /* all three in 0..8: bypass the shift search (a10-a12) with this triple; otherwise {-1,-1,-1} */
   int32_t force_split_kernels; /* non-0: use the three-launch path (fit+search, scan, dither+store) even where the persistent kernel applies */
   int32_t dither_pcg;          /* non-0: the reference's PCG dither (src/limg.cpp:799-822, what it runs on hosts without AES-NI) instead of the AES one */
-  int32_t reserved[3];
+  int32_t test_record_limit;   /* test hook, 0 = default: blocks with a record value of magnitude >= this take the generic 32-bit trial
+                                  (default 8001: a fit of byte pixels never gets there); 1 sends every block through it */
+  int32_t reserved[2];
 } limg_hip_options;
 
 typedef struct limg_hip_context limg_hip_context;

@@ -41,7 +41,7 @@ class CompactOut(C.Structure):
 
 
 class Options(C.Structure):
-    _fields_ = [("forced_shift", C.c_int32 * 3), ("force_split_kernels", C.c_int32), ("dither_pcg", C.c_int32), ("reserved", C.c_int32 * 3)]
+    _fields_ = [("forced_shift", C.c_int32 * 3), ("force_split_kernels", C.c_int32), ("dither_pcg", C.c_int32), ("test_record_limit", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 def load_library(path=None):
@@ -123,7 +123,7 @@ class LimgHip:
         except Exception:
             pass
 
-    def set_options(self, forced_shift=None, force_split=False, dither_pcg=False):
+    def set_options(self, forced_shift=None, force_split=False, dither_pcg=False, test_record_limit=0):
         o = Options()
         self.lib.limg_hip_default_options(C.byref(o))
         if forced_shift is not None:
@@ -131,6 +131,7 @@ class LimgHip:
                 o.forced_shift[i] = int(forced_shift[i])
         o.force_split_kernels = int(force_split)
         o.dither_pcg = int(dither_pcg)
+        o.test_record_limit = int(test_record_limit)
         _check(self.lib.limg_hip_set_options(self.ctx, C.byref(o)), "limg_hip_set_options")
 
     def set_forced_shift(self, shift=None):

@@ -158,6 +158,7 @@ namespace
     const bool forced = c->opt.forced_shift[0] >= 0 && c->opt.forced_shift[0] <= 8 && c->opt.forced_shift[1] >= 0 && c->opt.forced_shift[1] <= 8 &&
                         c->opt.forced_shift[2] >= 0 && c->opt.forced_shift[2] <= 8;
     for (int i = 0; i < 3; i++) p.forced[i] = forced ? c->opt.forced_shift[i] : -1;
+    p.recordLimit = c->opt.test_record_limit > 0 ? c->opt.test_record_limit - 1 : 8000;
     const Partition pt = partition(sizeY, poolThreads);
     p.chainCount = pt.chainCount; p.chainRows = pt.chainRows;
 

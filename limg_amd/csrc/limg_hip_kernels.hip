@@ -147,12 +147,11 @@ namespace limg_hip
     //  * the weighted squared error is one v_dot2_u32_u16.
     // The R term of every factor carries a +0x2000 bias (folded into the additive constant, so it costs nothing) which keeps
     // the low halves positive: the three packed terms can then be summed with one plain 32-bit add3 without a borrow reaching
-    // the G half.  Valid while every record value is small (|v| <= 8000, far above what a fit of byte pixels can produce:
+    // the G half.  Valid while every record value is small (|v| <= p.recordLimit = 8000, far above what a fit of byte pixels can produce:
     // |A| <= 765, |B| <= 1020, |C| <= 2040); phase E falls back to the generic 32-bit form otherwise.
     typedef short short2_t __attribute__((ext_vector_type(2)));
     typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
     constexpr int kTermBias = 0x2000;
-    constexpr int kRecordLimit = 8000;
 
     // 24-bit integer multiplies (full rate; v_mul_lo_u32 is quarter rate).  Operands here always fit: see kRecordLimit.
     __device__ __forceinline__ int mul_i24(int a, int b) { int r; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -375,6 +374,25 @@ namespace limg_hip
           b = 0;
         }
       }
+    }
+
+    // generic-path search (see phase E): real function, rarely if ever executed
+    __device__ __attribute__((noinline)) uint32_t search_generic(uint32_t px, uint32_t fA, uint32_t fB, uint32_t fC, const int16_t *rec /* LDS */, bool active,
+                                                                 uint32_t maxPixel32, uint64_t maxBlockN, bool fast)
+    {
+      RecU r;
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+      {
+        const int loA = rec[c], hiA = rec[4 + c], loB = rec[8 + c], hiB = rec[12 + c], loC = rec[16 + c], hiC = rec[20 + c];
+        r.nA[c] = sgpr(hiA - loA); r.nB[c] = sgpr(hiB - loB); r.nC[c] = sgpr(hiC - loC);
+        r.mA[c] = sgpr((int)(((uint32_t)loA << 8) + 128u)); r.mB[c] = sgpr((int)(((uint32_t)loB << 8) + 128u)); r.mC[c] = sgpr((int)(((uint32_t)loC << 8) + 128u));
+      }
+      uint32_t shift[3] = { 0, 0, 0 };
+      auto T = [&](uint32_t a, uint32_t bb, uint32_t c, uint32_t &be2) -> bool { return trial(px, fA, fB, fC, r, a, bb, c, active, maxPixel32, maxBlockN, be2); };
+      if (fast) search_fast(T, shift);
+      else search_accurate(T, shift);
+      return shift[0] | (shift[1] << 8) | (shift[2] << 16);
     }
 
     // =====================================================================================================================
@@ -1064,7 +1082,7 @@ namespace limg_hip
           if (r == 0) val = blk[b].avg[c] + val;
           int q = cvt_rne(val);
           if ((CH == 3 && c == 3) || !(flags & kValid)) q = 0;
-          big |= (q > kRecordLimit || q < -kRecordLimit) ? 1u : 0u;
+          big |= (q > p.recordLimit || q < -p.recordLimit) ? 1u : 0u;
           blk[b].rec[kc] = (int16_t)q;
         }
         big |= (uint32_t)dpp<0xB1, 0xF>(0, (int)big);
@@ -1222,16 +1240,10 @@ namespace limg_hip
           }
           else
           {
-            RecU r;
-#pragma unroll
-            for (int c = 0; c < 3; c++)
-            {
-              r.nA[c] = sgpr(rhi[0][c] - rlo[0][c]); r.nB[c] = sgpr(rhi[1][c] - rlo[1][c]); r.nC[c] = sgpr(rhi[2][c] - rlo[2][c]);
-              r.mA[c] = sgpr((int)(((uint32_t)rlo[0][c] << 8) + 128u)); r.mB[c] = sgpr((int)(((uint32_t)rlo[1][c] << 8) + 128u)); r.mC[c] = sgpr((int)(((uint32_t)rlo[2][c] << 8) + 128u));
-            }
-            auto T = [&](uint32_t a, uint32_t bb, uint32_t c, uint32_t &be2) -> bool { return trial(px, fA, fB, fC, r, a, bb, c, active, p.maxPixel32, maxBlockN, be2); };
-            if (p.fast) search_fast(T, shift);
-            else search_accurate(T, shift);
+            // out-of-range record (never produced by a fit of byte pixels; kept so that no input can break exactness):
+            // generic 32-bit trial, deliberately a real call so that none of it is speculated into the common path
+            const uint32_t packed = search_generic(px, fA, fB, fC, blk[b].rec, active, p.maxPixel32, maxBlockN, p.fast != 0);
+            shift[0] = packed & 0xFF; shift[1] = (packed >> 8) & 0xFF; shift[2] = (packed >> 16) & 0xFF;
           }
         }
 

@@ -134,6 +134,19 @@ def test_pcg_dither(gpu, oracle, w, h):
     _assert_planes(got, oracle.encode3d(img, True, dither_mode=DITHER_PCG), (w, h))
 
 
+@pytest.mark.parametrize("alpha,fast", [(True, True), (False, True), (True, False)])
+def test_generic_trial_path(gpu, oracle, alpha, fast):
+    """The packed 16-bit trial is only valid for small record values; larger ones (never produced by a fit of byte pixels)
+    take a generic 32-bit trial.  The test hook sends every block through that path."""
+    img = oracle.photo_noise(256, 32, 37)
+    gpu.set_options(force_split=(gpu.mode == "split"), test_record_limit=1)
+    try:
+        got = gpu.encode3d(img, alpha, fast=fast)
+    finally:
+        gpu.set_options(force_split=(gpu.mode == "split"))
+    _assert_planes(got, oracle.encode3d(img, alpha, fast=fast), (alpha, fast))
+
+
 def test_degenerate_blocks(gpu, oracle):
     """flat blocks (dirA == 0), single-line blocks (dirB == 0), planes (dirC noise), extreme values."""
     img = np.zeros((16, 256), dtype=np.uint32)
