@@ -87,12 +87,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    dev = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        ndev = torch.cuda.device_count()
+        if ndev >= world:
+            dev = local_rank
+            torch.cuda.set_device(dev)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))  # RCCL over xGMI
+        else:
+            # rehearsal on a box with fewer GPUs than ranks (ranks share cards): RCCL refuses duplicate devices, use gloo
+            dev = local_rank % max(ndev, 1)
+            torch.cuda.set_device(dev)
+            dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(0)
     n_gpus = max(world, 1)
@@ -100,7 +109,7 @@ def main():
         print("bench.py: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
     W = H = args.size
-    g = limg_amd.LimgHip(local_rank if world > 1 else 0)
+    g = limg_amd.LimgHip(dev)
     if args.forced_shift >= 0 or args.split:
         g.set_options(forced_shift=(args.forced_shift,) * 3 if args.forced_shift >= 0 else None, force_split=args.split)
     img = g.synth_device(args.workload, W, H, seed=1 + rank)
@@ -125,7 +134,7 @@ def main():
     kernels = g.profile_end(args.steps)
     if dist is not None:
         dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     torch.cuda.synchronize()

@@ -689,30 +689,62 @@ namespace limg_hip
     __device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
     __device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
+    // ---- 4-channel float vectors in "DPPS order" -----------------------------------------------------------------------------
+    // A pixel-space vector lives in two register pairs a = (x0, x2), b = (x1, x3): then DPPS's (x0y0 + x1y1) + (x2y2 + x3y3)
+    // is  m = a*a', n = b*b' (v_pk_mul_f32), s = m + n = (p0 + p1, p2 + p3) (v_pk_add_f32), s.x + s.y  -- 4 instructions, each
+    // product and sum rounded exactly like the SSE code.  The LDS copies (avg, dirA..C, est0, parked contributions) use the same
+    // slot order [x0, x2, x1, x3]; `slot_of` maps a channel to its slot.
+    typedef float float2_t __attribute__((ext_vector_type(2)));
+    struct V4 { float2_t a, b; };
+    __device__ __forceinline__ constexpr int slot_of(int c) { return c == 1 ? 2 : (c == 2 ? 1 : c); }
+    __device__ __forceinline__ V4 ld4(const float *p) { const float4 v = *reinterpret_cast<const float4 *>(p); V4 r; r.a = float2_t{ v.x, v.y }; r.b = float2_t{ v.z, v.w }; return r; }
+    __device__ __forceinline__ void st4(float *p, const V4 &v) { *reinterpret_cast<float4 *>(p) = make_float4(v.a.x, v.a.y, v.b.x, v.b.y); }
+    __device__ __forceinline__ V4 px_to_v4(uint32_t px)
+    {
+      V4 r;
+      r.a = float2_t{ (float)(px & 0xFF), (float)((px >> 16) & 0xFF) };
+      r.b = float2_t{ (float)((px >> 8) & 0xFF), (float)(px >> 24) };
+      return r;
+    }
+    __device__ __forceinline__ V4 operator-(const V4 &x, const V4 &y) { V4 r; r.a = x.a - y.a; r.b = x.b - y.b; return r; }
+    __device__ __forceinline__ V4 operator+(const V4 &x, const V4 &y) { V4 r; r.a = x.a + y.a; r.b = x.b + y.b; return r; }
+    __device__ __forceinline__ V4 operator*(const V4 &x, float s) { V4 r; r.a = x.a * s; r.b = x.b * s; return r; }
+    template <int CH>
+    __device__ __forceinline__ float dp4(const V4 &x, const V4 &y)
+    {
+      const float2_t m = x.a * y.a;
+      float2_t n = x.b * y.b;
+      if (CH == 3) n.y = 0.0f; // DPPS mask 0x7F
+      const float2_t s2 = m + n;
+      return s2.x + s2.y;
+    }
+    template <int CH>
+    __device__ __forceinline__ void mask_alpha(V4 &v) { if (CH == 3) v.b.y = 0.0f; }
+
     // Sign-normalised unit vector of one pixel's difference vector (src/limg_factorization.h:605-623 and its twins in every
     // pass): bias each lane by {3e,2e,e,0}, flip the sign when |min over lanes| > max over lanes, scale by RSQRTPS(d.d).
     // min/max by v_min3/v_max3: their only differences from MINPS/MAXPS are NaN handling and the sign of a zero result,
     // neither of which can reach the comparison's outcome; the NaN-producing degenerate cases never get here (kZero* flags).
     // RSQRTPS = the captured Intel table: index = [exponent lsb : top 10 mantissa bits], exponent = 126 - floor((e - 127) / 2).
     template <int CH>
-    __device__ __forceinline__ void unit2(const unsigned short *tab, const float d[4], bool active, float out[4])
+    __device__ __forceinline__ V4 unit4(const unsigned short *tab, const V4 &d, bool active)
     {
-      const float e3 = FLT_EPSILON * 3, e2 = FLT_EPSILON * 2, e1 = FLT_EPSILON;
-      const float mn = vmin3(d[0] - e3, d[2] - e1, vmin(d[1] - e2, d[3] - 0.0f));
-      const float mx = vmax3(d[0] + e3, d[2] + e1, vmax(d[1] + e2, d[3] + 0.0f));
-      const uint32_t anybits = (__float_as_uint(d[0]) | __float_as_uint(d[1]) | __float_as_uint(d[2]) | __float_as_uint(d[3])) << 1;
+      const float2_t biasA = { FLT_EPSILON * 3, FLT_EPSILON * 1 }, biasB = { FLT_EPSILON * 2, 0.0f };
+      const float2_t mbA = d.a - biasA, mbB = d.b - biasB, xbA = d.a + biasA, xbB = d.b + biasB;
+      const float mn = vmin3(mbA.x, mbA.y, vmin(mbB.x, mbB.y));
+      const float mx = vmax3(xbA.x, xbA.y, vmax(xbB.x, xbB.y));
+      const uint32_t anybits = (__float_as_uint(d.a.x) | __float_as_uint(d.a.y) | __float_as_uint(d.b.x) | __float_as_uint(d.b.y)) << 1;
       const bool use = (anybits != 0u) && active;
-      float len2 = dpps<CH>(d, d);
+      const float len2 = dp4<CH>(d, d);
       // RSQRTPS table lookup; for skipped lanes len2 == 0 => index 0x400, exponent garbage: result discarded below
-      const uint32_t b = __float_as_uint(len2);
-      const uint32_t idx2 = ((b >> 12) & 0xFFEu) ^ 0x800u; // byte offset into the u16 table
+      const uint32_t bits = __float_as_uint(len2);
+      const uint32_t idx2 = ((bits >> 12) & 0xFFEu) ^ 0x800u; // byte offset into the u16 table
       const uint32_t tv = *reinterpret_cast<const unsigned short *>(reinterpret_cast<const unsigned char *>(tab) + idx2);
-      const uint32_t ex = (380u - (b >> 23)) >> 1; // 126 - floor((e - 127) / 2)
+      const uint32_t ex = (380u - (bits >> 23)) >> 1; // 126 - floor((e - 127) / 2)
       float inv = __uint_as_float((ex << 23) | (tv << 11));
       inv = (-mn > mx) ? -inv : inv; // |min| > max  (min >= 0 can never satisfy either form)
       inv = use ? inv : 0.0f;
-#pragma unroll
-      for (int c = 0; c < 4; c++) out[c] = d[c] * inv;
+      return d * inv;
     }
 
     enum : int { kDirA = 0, kDirB = 1, kDirC = 2 };
@@ -736,10 +768,11 @@ namespace limg_hip
         const float dir = s * blk[b].inv_count;
         float *dst = WHICH == kDirA ? blk[b].dirA : (WHICH == kDirB ? blk[b].dirB : blk[b].dirC);
         dst[c] = dir;
-        // (p0 + p1) + (p2 + p3) inside each quad of lanes; float add is commutative so the xor butterflies give exactly that
+        // (p0 + p1) + (p2 + p3) inside each quad of lanes (slot order x0 x2 x1 x3: channels 0,1 sit in slots 0,2); float add is
+        // commutative, so the two xor butterflies give exactly that
         float p = (CH == 3 && c == 3) ? 0.0f : dir * dir;
-        p = p + __int_as_float(dpp<0xB1, 0xF>(0, __float_as_int(p)));
-        p = p + __int_as_float(dpp<0x4E, 0xF>(0, __float_as_int(p)));
+        p = p + __int_as_float(dpp<0x4E, 0xF>(0, __float_as_int(p))); // slot ^ 2
+        p = p + __int_as_float(dpp<0xB1, 0xF>(0, __float_as_int(p))); // slot ^ 1
         uint32_t z = (dir == 0.0f) ? 1u : 0u;
         z &= (uint32_t)dpp<0xB1, 0xF>(0, (int)z);
         z &= (uint32_t)dpp<0x4E, 0xF>(0, (int)z);
@@ -889,7 +922,7 @@ namespace limg_hip
       for (int h = 0; h < kBlocksPerWave / kBatch; h++)
       {
       uint32_t px8[kBatch];
-      float est8[kBatch][4];
+      V4 est8[kBatch];
       BlkF *const blkh = blk + h * kBatch;
 
       // ---- phase A: sums, average, first direction pass (a4, a5/a6 pass 1) ------------------------------------------
@@ -899,8 +932,7 @@ namespace limg_hip
         const int b = h * kBatch + i;
         uint32_t rx, n;
         px8[i] = 0;
-#pragma unroll
-        for (int c = 0; c < 4; c++) est8[i][c] = 0.0f;
+        est8[i].a = float2_t{ 0.0f, 0.0f }; est8[i].b = float2_t{ 0.0f, 0.0f };
         if (!geom(b, rx, n))
         {
           if (lane == 0) { blk[b].flags = 0; blk[b].n = 0; blk[b].inv_count = 0.0f; }
@@ -913,25 +945,19 @@ namespace limg_hip
         uint32_t px = s_strip[ly * kRowDw + sb * kBlock + lx];
         px = (uint32_t)lane < n ? px : 0u;
         px8[i] = px;
-        float pf[4];
-        px_to_float(px, pf);
+        const V4 pf = px_to_v4(px);
         const uint32_t s02 = wave_sum(px & 0x00FF00FFu), s13 = wave_sum((px >> 8) & 0x00FF00FFu);
         float inv_count = 0.015625f;
         if (n != 64) inv_count = 1.0f / (float)n;
-        float avg[4];
-        avg[0] = (float)(int)(s02 & 0xFFFF) * inv_count;
-        avg[1] = (float)(int)(s13 & 0xFFFF) * inv_count;
-        avg[2] = (float)(int)(s02 >> 16) * inv_count;
-        avg[3] = CH == 4 ? (float)(int)(s13 >> 16) * inv_count : 0.0f;
-        float d[4], v[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) d[c] = pf[c] - avg[c];
-        if (CH == 3) d[3] = 0.0f;
-        unit2<CH>(s_rsq, d, (uint32_t)lane < n, v);
-        store_v(V + i * kVDw, lane, v);
+        V4 avg;
+        avg.a = float2_t{ (float)(int)(s02 & 0xFFFF), (float)(int)(s02 >> 16) } * inv_count;
+        avg.b = float2_t{ (float)(int)(s13 & 0xFFFF), CH == 4 ? (float)(int)(s13 >> 16) : 0.0f } * inv_count;
+        V4 d = pf - avg;
+        mask_alpha<CH>(d);
+        st4(V + i * kVDw + lane * 4, unit4<CH>(s_rsq, d, (uint32_t)lane < n));
         if (lane == 0)
         {
-          *reinterpret_cast<float4 *>(blk[b].avg) = make_float4(avg[0], avg[1], avg[2], avg[3]);
+          st4(blk[b].avg, avg);
           *reinterpret_cast<float4 *>(blk[b].dirB) = make_float4(0.f, 0.f, 0.f, 0.f);
           *reinterpret_cast<float4 *>(blk[b].dirC) = make_float4(0.f, 0.f, 0.f, 0.f);
           *reinterpret_cast<float4 *>(blk[b].est0) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -950,23 +976,18 @@ namespace limg_hip
         uint32_t rx, n;
         if (!geom(b, rx, n)) continue;
         if ((uint32_t)sgpr((int)blk[b].flags) & kZeroA) continue;
-        const float4 dA4 = *reinterpret_cast<const float4 *>(blk[b].dirA), av4 = *reinterpret_cast<const float4 *>(blk[b].avg);
-        const float dirA[4] = { dA4.x, dA4.y, dA4.z, dA4.w }, avg[4] = { av4.x, av4.y, av4.z, av4.w };
+        const V4 dirA = ld4(blk[b].dirA), avg = ld4(blk[b].avg);
         const float invA = blk[b].invA;
-        float pf[4], l[4], e[4], v[4];
-        px_to_float(px8[i], pf);
+        const V4 pf = px_to_v4(px8[i]);
         const bool active = (uint32_t)lane < n;
-#pragma unroll
-        for (int c = 0; c < 4; c++) l[c] = pf[c] - avg[c];
-        const float fA = dpps<CH>(l, dirA) * invA;
+        const float fA = dp4<CH>(pf - avg, dirA) * invA;
         float mn = active ? fA : 0.0f, mx = mn; // min / max start at 0 upstream (src/limg_factorization.h:633-634)
         wave_min_max(mn, mx);
         mn = vmin(mn, 0.0f); mx = vmax(mx, 0.0f);
-#pragma unroll
-        for (int c = 0; c < 4; c++) { est8[i][c] = avg[c] + fA * dirA[c]; e[c] = pf[c] - est8[i][c]; }
-        if (CH == 3) e[3] = 0.0f;
-        unit2<CH>(s_rsq, e, active, v);
-        store_v(V + i * kVDw, lane, v);
+        est8[i] = avg + dirA * fA;
+        V4 e = pf - est8[i];
+        mask_alpha<CH>(e);
+        st4(V + i * kVDw + lane * 4, unit4<CH>(s_rsq, e, active));
         if (lane == 0) { blk[b].mm[0] = mn; blk[b].mm[1] = mx; }
       }
       serial_sums2<CH, kDirB>(V, blkh, lane);
@@ -979,48 +1000,39 @@ namespace limg_hip
         uint32_t rx, n;
         if (!geom(b, rx, n)) continue;
         if ((uint32_t)sgpr((int)blk[b].flags) & kZeroB) continue; // 1/0 = inf => every fB is NaN upstream => B and C collapse to 0
-        const float4 dB4 = *reinterpret_cast<const float4 *>(blk[b].dirB);
-        const float dirB[4] = { dB4.x, dB4.y, dB4.z, dB4.w };
+        const V4 dirB = ld4(blk[b].dirB);
         const float invB = blk[b].invB;
-        float pf[4], l[4];
-        px_to_float(px8[i], pf);
+        const V4 pf = px_to_v4(px8[i]);
         const bool active = (uint32_t)lane < n;
-#pragma unroll
-        for (int c = 0; c < 4; c++) l[c] = pf[c] - est8[i][c];
-        const float fB = dpps<CH>(l, dirB) * invB;
+        const float fB = dp4<CH>(pf - est8[i], dirB) * invB;
         float mnB = active ? fB : FLT_MAX, mxB = active ? fB : -FLT_MAX;
         if (CH == 4)
         {
           wave_min_max(mnB, mxB);
-          float e[4], v[4];
-#pragma unroll
-          for (int c = 0; c < 4; c++) { est8[i][c] = est8[i][c] + fB * dirB[c]; e[c] = pf[c] - est8[i][c]; }
-          unit2<CH>(s_rsq, e, active, v);
-          store_v(V + i * kVDw, lane, v);
+          est8[i] = est8[i] + dirB * fB;
+          st4(V + i * kVDw + lane * 4, unit4<CH>(s_rsq, pf - est8[i], active));
           if (lane == 0)
           {
             blk[b].mm[2] = mnB; blk[b].mm[3] = mxB;
-            *reinterpret_cast<float4 *>(blk[b].est0) = make_float4(est8[i][0], est8[i][1], est8[i][2], est8[i][3]);
+            st4(blk[b].est0, est8[i]);
           }
         }
         else
         {
-          // dirC = dirA x dirB (src/limg_factorization.h:498-507)
-          const float4 dA4 = *reinterpret_cast<const float4 *>(blk[b].dirA);
-          float dirC[4];
-          dirC[0] = dA4.y * dirB[2] - dA4.z * dirB[1];
-          dirC[1] = dA4.z * dirB[0] - dA4.x * dirB[2];
-          dirC[2] = dA4.x * dirB[1] - dA4.y * dirB[0];
-          dirC[3] = 0.0f;
-          const bool zeroC = sgpr((dirC[0] == 0.0f && dirC[1] == 0.0f && dirC[2] == 0.0f) ? 1 : 0) != 0;
+          // dirC = dirA x dirB (src/limg_factorization.h:498-507); slots: a = (x0, x2), b = (x1, x3)
+          const V4 dirA = ld4(blk[b].dirA);
+          V4 dirC;
+          dirC.a.x = dirA.b.x * dirB.a.y - dirA.a.y * dirB.b.x; // A1 B2 - A2 B1
+          dirC.b.x = dirA.a.y * dirB.a.x - dirA.a.x * dirB.a.y; // A2 B0 - A0 B2
+          dirC.a.y = dirA.a.x * dirB.b.x - dirA.b.x * dirB.a.x; // A0 B1 - A1 B0
+          dirC.b.y = 0.0f;
+          const bool zeroC = sgpr((dirC.a.x == 0.0f && dirC.b.x == 0.0f && dirC.a.y == 0.0f) ? 1 : 0) != 0;
           float mnC = 0.0f, mxC = 0.0f;
           if (!zeroC)
           {
-            const float invC = 1.0f / dpps<CH>(dirC, dirC);
-            float e[4];
-#pragma unroll
-            for (int c = 0; c < 4; c++) e[c] = pf[c] - (est8[i][c] + fB * dirB[c]);
-            const float fC = dpps<CH>(e, dirC) * invC;
+            const float invC = 1.0f / dp4<CH>(dirC, dirC);
+            const V4 e = pf - (est8[i] + dirB * fB);
+            const float fC = dp4<CH>(e, dirC) * invC;
             mnC = active ? fC : FLT_MAX; mxC = active ? fC : -FLT_MAX;
             wave_min_max(mnB, mxB);
             wave_min_max(mnC, mxC);
@@ -1030,7 +1042,7 @@ namespace limg_hip
           if (lane == 0)
           {
             blk[b].mm[2] = mnB; blk[b].mm[3] = mxB; blk[b].mm[4] = mnC; blk[b].mm[5] = mxC;
-            *reinterpret_cast<float4 *>(blk[b].dirC) = make_float4(dirC[0], dirC[1], dirC[2], 0.0f);
+            st4(blk[b].dirC, dirC);
             if (zeroC) blk[b].flags |= kZeroC;
           }
         }
@@ -1048,15 +1060,11 @@ namespace limg_hip
           uint32_t rx, n;
           if (!geom(b, rx, n)) continue;
           if ((uint32_t)sgpr((int)blk[b].flags) & kZeroC) continue;
-          const float4 dC4 = *reinterpret_cast<const float4 *>(blk[b].dirC), e04 = *reinterpret_cast<const float4 *>(blk[b].est0);
-          const float dirC[4] = { dC4.x, dC4.y, dC4.z, dC4.w }, est0[4] = { e04.x, e04.y, e04.z, e04.w };
+          const V4 dirC = ld4(blk[b].dirC), est0 = ld4(blk[b].est0);
           const float invC = blk[b].invC;
-          float pf[4], l[4];
-          px_to_float(px8[i], pf);
+          const V4 pf = px_to_v4(px8[i]);
           const bool active = (uint32_t)lane < n;
-#pragma unroll
-          for (int c = 0; c < 4; c++) l[c] = pf[c] - est0[c];
-          const float fC = dpps<CH>(l, dirC) * invC;
+          const float fC = dp4<CH>(pf - est0, dirC) * invC;
           float mnC = active ? fC : FLT_MAX, mxC = active ? fC : -FLT_MAX;
           wave_min_max(mnC, mxC);
           if (lane == 0) { blk[b].mm[4] = mnC; blk[b].mm[5] = mxC; }
@@ -1075,11 +1083,12 @@ namespace limg_hip
         {
           const int kc = j + 8 * r, k = kc >> 2, c = kc & 3; // k = 2 r + (j >> 2): A for r == 0, B for r == 1, C for r == 2
           const float *dir = r == 0 ? blk[b].dirA : (r == 1 ? blk[b].dirB : blk[b].dirC);
-          float m = blk[b].mm[k], dv = dir[c];
+          const int sl = slot_of(c);
+          float m = blk[b].mm[k], dv = dir[sl];
           const bool dead = (r == 2 && (flags & kZeroC)) || (r >= 1 && (flags & kZeroB)) || (flags & kZeroA);
           if (dead) { m = 0.0f; dv = 0.0f; }
           float val = m * dv;
-          if (r == 0) val = blk[b].avg[c] + val;
+          if (r == 0) val = blk[b].avg[sl] + val;
           int q = cvt_rne(val);
           if ((CH == 3 && c == 3) || !(flags & kValid)) q = 0;
           big |= (q > p.recordLimit || q < -p.recordLimit) ? 1u : 0u;
@@ -1098,7 +1107,7 @@ namespace limg_hip
         {
           const int b = r * 4 + (lane >> 4), w = lane & 15;
           const uint32_t sb = wave * kBlocksPerWave + b, bx = strip * kStripBlocks + sb;
-          const uint32_t val = w < 4 ? __float_as_uint(blk[b].avg[w]) : reinterpret_cast<const uint32_t *>(blk[b].rec)[w - 4];
+          const uint32_t val = w < 4 ? __float_as_uint(blk[b].avg[slot_of(w)]) : reinterpret_cast<const uint32_t *>(blk[b].rec)[w - 4];
           if (bx < p.blocksX && (!PERSIST || p.compactOut)) reinterpret_cast<uint32_t *>(p.records + (size_t)by * p.blocksX + bx)[w] = val;
           if (PERSIST && w >= 4) reinterpret_cast<uint32_t *>(park + kParkRec)[sb * 12 + (w - 4)] = val;
         }
