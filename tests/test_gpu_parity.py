@@ -218,3 +218,52 @@ def test_full_size_properties(gpu, oracle):
                 assert torch.equal(part[k], planes[k][s * rows:(s + 1) * rows]), (kind, s, k)
         del planes, part, d_img
         torch.cuda.empty_cache()
+
+
+def test_error_codes(gpu):
+    """Same enum values as limg_result (src/limg.h:9-18): null -> ArgumentNull (102), bad sizes -> InvalidParameter (101)."""
+    import ctypes as C
+    import limg_amd
+    L = gpu.lib
+    img = np.zeros((8, 8), dtype=np.uint32)
+    planes = {k: np.zeros((8, 8), dtype=np.uint32 if k in limg_amd.P32 else np.uint8) for k in limg_amd.PLANES}
+    info = limg_amd.Info(*[planes[k].ctypes.data for k in limg_amd.PLANES])
+    assert L.limg_hip_encode3d(gpu.ctx, None, 8, 8, 1, C.byref(info), 100, 0, 1) == 102
+    assert L.limg_hip_encode3d(gpu.ctx, img.ctypes.data_as(C.c_void_p), 8, 8, 1, None, 100, 0, 1) == 102
+    assert L.limg_hip_encode3d(None, img.ctypes.data_as(C.c_void_p), 8, 8, 1, C.byref(info), 100, 0, 1) == 102
+    assert L.limg_hip_encode3d(gpu.ctx, img.ctypes.data_as(C.c_void_p), 0, 8, 1, C.byref(info), 100, 0, 1) == 101
+    bad = limg_amd.Info(*[planes[k].ctypes.data for k in limg_amd.PLANES])
+    bad.pFactorsC = None
+    assert L.limg_hip_encode3d(gpu.ctx, img.ctypes.data_as(C.c_void_p), 8, 8, 1, C.byref(bad), 100, 0, 1) == 102
+    assert L.limg_hip_encode3d_perf(gpu.ctx, None, 8, 8, 1, 100, 0, 1) == 102
+    assert L.limg_hip_encode3d(gpu.ctx, img.ctypes.data_as(C.c_void_p), 8, 8, 1, C.byref(info), 100, 0, 1) == 0
+
+
+def test_perf_entry_and_compact_outputs(gpu, oracle):
+    """`_perf` behaviour (no planes) still produces the per-block compact outputs when asked: records + shifts == oracle."""
+    import torch
+    img = oracle.photo_noise(256, 32, 41)
+    gpu.encode3d_perf(img, True)  # must simply succeed
+    want = oracle.encode3d(img, True, extras=True)
+    d_img = torch.from_numpy(img.view(np.int32)).cuda()
+    rec = torch.zeros((4 * 32, 16), dtype=torch.int32, device="cuda")
+    sh = torch.zeros(4 * 32, dtype=torch.int32, device="cuda")
+    gpu.encode3d_device(d_img, True, None, records=rec, shifts=sh)
+    torch.cuda.synchronize()
+    grec = rec.cpu().numpy().view(REC_DTYPE).reshape(4, 32)
+    for f in REC_DTYPE.names:
+        assert np.array_equal(grec[f], want["records"][f]), f
+    gsh = sh.cpu().numpy().astype(np.uint32).reshape(4, 32)
+    for i in range(3):
+        assert np.array_equal((gsh >> (8 * i)) & 0xFF, want["shifts"][:, :, i])
+
+
+def test_repeatability_and_context_reuse(gpu, oracle):
+    """Back-to-back encodes of different sizes through one context (buffers and the noise table are reused / regrown)."""
+    for (w, h) in ((512, 64), (64, 512), (1024, 1024), (512, 64)):
+        img = oracle.photo_noise(w, h, w + h)
+        a = gpu.encode3d(img, True)
+        b = gpu.encode3d(img, True)
+        for k in PLANES:
+            assert np.array_equal(a[k], b[k]), k
+        assert oracle.fnv(a["pDecoded"]) == oracle.fnv(oracle.encode3d(img, True)["pDecoded"])
