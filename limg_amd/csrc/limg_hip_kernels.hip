@@ -156,6 +156,7 @@ namespace limg_hip
     // 24-bit integer multiplies (full rate; v_mul_lo_u32 is quarter rate).  Operands here always fit: see kRecordLimit.
     __device__ __forceinline__ int mul_i24(int a, int b) { int r; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
     __device__ __forceinline__ uint32_t mul_u24(uint32_t a, uint32_t b) { uint32_t r; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+    __device__ __forceinline__ int med3_i32(int a, int b, int c) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
     __device__ __forceinline__ int mad_i24(int a, int b, int c) { int r; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
     struct TrialState
@@ -164,7 +165,7 @@ namespace limg_hip
       uint32_t fA, fB, fC;
       uint32_t pxRGb; // (R + 3 * bias) | G << 16
       uint32_t loRG, hiRG;
-      int pxB;
+      int pxB, pxBlo;
       // wave-uniform record view: n* scalars, m* = (min << 8) + 128 (+ bias << 8 for R)
       int nA[3], nB[3], nC[3];
       int mA[3], mB[3], mC[3];
@@ -204,9 +205,7 @@ namespace limg_hip
       short2_t e = __builtin_bit_cast(short2_t, t.pxRGb) - __builtin_bit_cast(short2_t, estRG);
       e = __builtin_elementwise_max(e, __builtin_bit_cast(short2_t, t.loRG));
       e = __builtin_elementwise_min(e, __builtin_bit_cast(short2_t, t.hiRG));
-      int dB = t.pxB - estB;
-      dB = dB > t.pxB - 255 ? dB : t.pxB - 255;
-      dB = dB < t.pxB ? dB : t.pxB;
+      int dB = med3_i32(t.pxB - estB, t.pxBlo, t.pxB); // clamp(px - S, px - 255, px)
       const ushort2_t eu = __builtin_bit_cast(ushort2_t, e);
       const ushort2_t sq = eu * eu; // d^2 <= 65025 fits 16 bits; (-d)^2 mod 2^16 == d^2
       const uint32_t sqB = (uint32_t)mul_i24(dB, dB);
@@ -645,6 +644,7 @@ namespace limg_hip
       uint32_t flags, n;                                // 128
       int16_t rec[24];                                  // 176
       float pad[4];                                     // 192
+      int32_t tn[3][4], tm[3][4];                       // 288: packed-trial constants (RGB): integer normals, (min << 8) + 128 (+ R bias)
     };
     struct BlkE
     {
@@ -653,7 +653,7 @@ namespace limg_hip
       float invN[3];   // 108
     };
     static_assert(sizeof(BlkE) <= 120, "BlkE must fit the dead float-stage fields");
-    static_assert(sizeof(BlkF) == 192, "BlkF layout");
+    static_assert(sizeof(BlkF) == 288, "BlkF layout");
 
     // exact min / max over the wave of two values at once (no NaN present); results wave-uniform.
     // Hand-written DPP: the two chains interleave so each needs only one wait state between dependent steps.
@@ -848,7 +848,7 @@ namespace limg_hip
 
     // LDS of an E task (fit + search of one work strip); the F task's areas overlay `V`.
     constexpr int kLdsRsq = 0, kLdsStrip = 4096, kLdsV = kLdsStrip + 8 * kRowDw * 4, kLdsVBytes = kWaves * kBatch * kVDw * 4;
-    constexpr int kLdsBlk = kLdsV + kLdsVBytes, kLdsCalls = kLdsBlk + kStripBlocks * 192, kLdsTotal = kLdsCalls + 16;
+    constexpr int kLdsBlk = kLdsV + kLdsVBytes, kLdsCalls = kLdsBlk + kStripBlocks * 288, kLdsTotal = kLdsCalls + 16;
     static_assert(kLdsTotal <= 40960 - 16, "at least 4 workgroups per CU");
 
     __device__ __forceinline__ void load_rsqrt_table(uint8_t *lds, int tid)
@@ -1142,6 +1142,8 @@ namespace limg_hip
             BlkE *e = reinterpret_cast<BlkE *>(&blk[b]);
             e->nrm[f][c] = nrm[r]; e->off[f][c] = off[r];
             if (c == 0) e->invN[f] = invn[r];
+            blk[b].tn[f][c] = (int)nrm[r];                                                     // exact: |hi - lo| < 2^17
+            blk[b].tm[f][c] = ((int)off[r] << 8) + 128 + (c == 0 ? (kTermBias << 8) : 0);
           }
         }
       }
@@ -1204,12 +1206,6 @@ namespace limg_hip
           const uint64_t lim64 = (maxBlockN + 15ull) >> 4;
           const uint32_t blockLimit = (uint32_t)sgpr((int)(lim64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)lim64));
           const bool big = ((uint32_t)sgpr((int)blk[b].flags) & kBig) != 0;
-          // integer record view (RGB lanes); kept in VGPRs: they are operands of v_mad_i32_i24
-          int rlo[3][3], rhi[3][3];
-#pragma unroll
-          for (int f = 0; f < 3; f++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) { rlo[f][c] = blk[b].rec[f * 8 + c]; rhi[f][c] = blk[b].rec[f * 8 + 4 + c]; }
           if (!big)
           {
             TrialState t;
@@ -1219,12 +1215,13 @@ namespace limg_hip
             t.hiRG = R | (G << 16);
             t.loRG = ((R - 255u) & 0xFFFFu) | ((G - 255u) << 16);
             t.pxB = (int)((px >> 16) & 0xFF);
-#pragma unroll
-            for (int c = 0; c < 3; c++)
+            t.pxBlo = t.pxB - 255;
             {
-              const int bias = c == 0 ? (kTermBias << 8) : 0;
-              t.nA[c] = rhi[0][c] - rlo[0][c]; t.nB[c] = rhi[1][c] - rlo[1][c]; t.nC[c] = rhi[2][c] - rlo[2][c];
-              t.mA[c] = (rlo[0][c] << 8) + 128 + bias; t.mB[c] = (rlo[1][c] << 8) + 128 + bias; t.mC[c] = (rlo[2][c] << 8) + 128 + bias;
+              // uniform values, kept in VGPRs: they are operands of v_mad_i32_i24
+              const int4 a4 = *reinterpret_cast<const int4 *>(blk[b].tn[0]), b4 = *reinterpret_cast<const int4 *>(blk[b].tn[1]), c4 = *reinterpret_cast<const int4 *>(blk[b].tn[2]);
+              const int4 ma = *reinterpret_cast<const int4 *>(blk[b].tm[0]), mb = *reinterpret_cast<const int4 *>(blk[b].tm[1]), mc = *reinterpret_cast<const int4 *>(blk[b].tm[2]);
+              t.nA[0] = a4.x; t.nA[1] = a4.y; t.nA[2] = a4.z; t.nB[0] = b4.x; t.nB[1] = b4.y; t.nB[2] = b4.z; t.nC[0] = c4.x; t.nC[1] = c4.y; t.nC[2] = c4.z;
+              t.mA[0] = ma.x; t.mA[1] = ma.y; t.mA[2] = ma.z; t.mB[0] = mb.x; t.mB[1] = mb.y; t.mB[2] = mb.z; t.mC[0] = mc.x; t.mC[1] = mc.y; t.mC[2] = mc.z;
             }
             t.cA = t.cB = t.cC = 0xFFu;
             t.tA_RG = t.tB_RG = t.tC_RG = 0; t.tA_B = t.tB_B = t.tC_B = 0;
