@@ -502,10 +502,10 @@ namespace limg_hip
 
     // dither + decode of the wave's 8 blocks into the per-wave staging areas, then the per-pixel planes' stores
     template <int CH>
-    __device__ __forceinline__ void phase_f_pixels(const EncodeParams &p, const StripLds &L, uint32_t strip, uint32_t x0, uint32_t y0, uint32_t ry, int lane, int wave)
+    __device__ __forceinline__ void phase_f_pixels(const EncodeParams &p, const StripLds &L, uint32_t strip, uint32_t x0, uint32_t y0, uint32_t ry, int lane, int wave, int tid)
     {
       uint32_t *dec = L.dec + wave * 512;
-      uint8_t *out = L.out + wave * 1536;
+      uint8_t *out = L.out; // [3 planes][8 rows][256 px]: strip-wide rows, so that the stores below write whole 128-byte lines
       // All noise bytes of the wave's 8 blocks are requested up front (up to 24 independent 64-byte loads in flight): fetched
       // block by block, each block would expose a full memory round trip.
       uint32_t nz8[kBlocksPerWave][3];
@@ -578,40 +578,39 @@ namespace limg_hip
           const uint32_t wo = ly * 64 + b * kBlock + lx;
           dec[wo] = decoded;
 #pragma unroll
-          for (int k = 0; k < 3; k++) out[k * 512 + wo] = (uint8_t)(f[k] << shift[k]); // shift 8 => 0 (src/limg.cpp:2054-2062)
+          for (int k = 0; k < 3; k++) out[k * 2048 + o] = (uint8_t)(f[k] << shift[k]); // shift 8 => 0 (src/limg.cpp:2054-2062)
         }
       }
       wave_lds_fence();
 
       const uint32_t wx0 = x0 + wave * 64;
-      if (wx0 >= p.sizeX) return;
-      const uint32_t ww = min(p.sizeX - wx0, 64u);
-      uint8_t *planes8[3] = { p.info.pFactorsA, p.info.pFactorsB, p.info.pFactorsC };
-      if ((uint32_t)lane < ww)
-        for (uint32_t row = 0; row < ry; row++) p.info.pDecoded[(size_t)(y0 + row) * p.sizeX + wx0 + lane] = dec[row * 64 + lane];
-      if ((p.sizeX & 3u) == 0)
-      { // 4 bytes per lane: lane -> (row = lane >> 4, 4-px chunk = lane & 15), two passes cover 8 rows
-#pragma unroll
-        for (int pass = 0; pass < 2; pass++)
+      if (wx0 < p.sizeX)
+      {
+        const uint32_t ww = min(p.sizeX - wx0, 64u);
+        if ((uint32_t)lane < ww)
+          for (uint32_t row = 0; row < ry; row++) p.info.pDecoded[(size_t)(y0 + row) * p.sizeX + wx0 + lane] = dec[row * 64 + lane];
+      }
+      __syncthreads(); // the three factor planes are stored strip-wide: 16 bytes per lane, whole rows of 256 bytes
+      {
+        const uint32_t stripW = min(p.sizeX - x0, (uint32_t)(kStripBlocks * kBlock));
+        uint8_t *planes8[3] = { p.info.pFactorsA, p.info.pFactorsB, p.info.pFactorsC };
+        if ((p.sizeX & 15u) == 0)
         {
-          const uint32_t row = pass * 4 + (lane >> 4), ch = (lane & 15) * 4;
-          if (row < ry && ch < ww)
+          for (int i = tid; i < 384; i += kThreads)
           {
-            const size_t g = (size_t)(y0 + row) * p.sizeX + wx0 + ch;
-#pragma unroll
-            for (int k = 0; k < 3; k++) *reinterpret_cast<uint32_t *>(planes8[k] + g) = *reinterpret_cast<const uint32_t *>(&out[k * 512 + row * 64 + ch]);
+            const int pl = i >> 7, row = (i & 127) >> 4, col = (i & 15) * 16;
+            if ((uint32_t)row < ry && (uint32_t)col < stripW)
+              *reinterpret_cast<uint4 *>(planes8[pl] + (size_t)(y0 + row) * p.sizeX + x0 + col) = *reinterpret_cast<const uint4 *>(out + pl * 2048 + row * 256 + col);
           }
         }
-      }
-      else
-      {
-        for (uint32_t row = 0; row < ry; row++)
-          if ((uint32_t)lane < ww)
+        else
+        {
+          for (int i = tid; i < 3 * 2048; i += kThreads)
           {
-            const size_t g = (size_t)(y0 + row) * p.sizeX + wx0 + lane;
-#pragma unroll
-            for (int k = 0; k < 3; k++) planes8[k][g] = out[k * 512 + row * 64 + lane];
+            const int pl = i >> 11, row = (i & 2047) >> 8, col = i & 255;
+            if ((uint32_t)row < ry && (uint32_t)col < stripW) planes8[pl][(size_t)(y0 + row) * p.sizeX + x0 + col] = out[i];
           }
+        }
       }
     }
 
@@ -863,7 +862,7 @@ namespace limg_hip
     constexpr int kParkFac = 0, kParkRec = 6144, kParkShift = 6144 + 1536, kParkBytes = 8192;
 
     template <int CH, bool PERSIST>
-    __device__ __forceinline__ void fit_search_strip(const EncodeParams &p, const uint32_t id, uint8_t *lds, uint8_t *park)
+    __device__ __forceinline__ void fit_search_strip(const EncodeParams &p, const uint32_t id, uint8_t *lds, uint8_t *park, const int tid)
     {
       unsigned short *s_rsq = reinterpret_cast<unsigned short *>(lds + kLdsRsq);
       uint32_t *s_strip = reinterpret_cast<uint32_t *>(lds + kLdsStrip);
@@ -871,7 +870,6 @@ namespace limg_hip
       BlkF *s_blk = reinterpret_cast<BlkF *>(lds + kLdsBlk);
       uint32_t *s_calls = reinterpret_cast<uint32_t *>(lds + kLdsCalls);
 
-      const int tid = (int)threadIdx.x;
       const int lane = tid & 63, wave = tid >> 6;
       const uint32_t strip = id % p.stripsX, by = id / p.stripsX;
       const uint32_t x0 = strip * (kStripBlocks * kBlock), y0 = by * kBlock;
@@ -1379,10 +1377,9 @@ namespace limg_hip
     static_assert(kPhaseFBytes + kStripBlocks * 48 <= kLdsTotal - kLdsStrip - 16, "the F step's LDS overlays everything of the E step but the rsqrt table");
 
     template <int CH, bool PERSIST>
-    __device__ __forceinline__ void dither_store_strip(const EncodeParams &p, const uint32_t id, uint8_t *fbase, const uint8_t *park)
+    __device__ __forceinline__ void dither_store_strip(const EncodeParams &p, const uint32_t id, uint8_t *fbase, const uint8_t *park, const int tid)
     {
       int16_t *s_rec = reinterpret_cast<int16_t *>(fbase + kPhaseFBytes); // [32][24]
-      const int tid = (int)threadIdx.x;
       const int lane = tid & 63, wave = tid >> 6;
       const uint32_t strip = id % p.stripsX, by = id / p.stripsX;
       const uint32_t x0 = strip * (kStripBlocks * kBlock), y0 = by * kBlock;
@@ -1458,7 +1455,7 @@ namespace limg_hip
         phase_f_first_calls(L, base, lane);
       }
       __syncthreads();
-      phase_f_pixels<CH>(p, L, strip, x0, y0, ry, lane, wave);
+      phase_f_pixels<CH>(p, L, strip, x0, y0, ry, lane, wave, tid);
     }
 
     // ---- kernels ---------------------------------------------------------------------------------------------------------
@@ -1467,37 +1464,19 @@ namespace limg_hip
     {
       __shared__ __attribute__((aligned(16))) uint8_t s_lds[kLdsTotal];
       load_rsqrt_table(s_lds, (int)threadIdx.x);
-      fit_search_strip<CH, false>(p, blockIdx.x, s_lds, nullptr);
+      fit_search_strip<CH, false>(p, blockIdx.x, s_lds, nullptr, (int)threadIdx.x);
     }
 
     template <int CH>
     __global__ __launch_bounds__(kThreads) void k_dither_store(const EncodeParams p)
     {
       __shared__ __attribute__((aligned(16))) uint8_t s_lds[kPhaseFBytes + kStripBlocks * 48];
-      dither_store_strip<CH, false>(p, blockIdx.x, s_lds, nullptr);
+      dither_store_strip<CH, false>(p, blockIdx.x, s_lds, nullptr, (int)threadIdx.x);
     }
 
-    // The two steps are compiled as real functions for the persistent kernel: inlined into one loop body the register allocator
-    // blends their live ranges (194 VGPRs => 2 waves/SIMD); as calls each keeps its own footprint (<= 3 waves/SIMD, no spills).
-    // They re-read the kernel arguments from the kernarg segment (scalar loads) instead of receiving a pointer to a stack copy.
-    typedef const EncodeParams __attribute__((address_space(4))) *KernargPtr;
-    template <int CH>
-    __device__ __attribute__((noinline)) void step_e(KernargPtr kp, uint32_t id, uint8_t *lds, uint8_t *park)
-    {
-#if defined(__HIP_DEVICE_COMPILE__)
-      const EncodeParams p = *kp;
-      fit_search_strip<CH, true>(p, id, lds, park);
-#endif
-    }
-    template <int CH>
-    __device__ __attribute__((noinline)) void step_f(KernargPtr kp, uint32_t id, uint8_t *fbase, const uint8_t *park)
-    {
-#if defined(__HIP_DEVICE_COMPILE__)
-      const EncodeParams p = *kp;
-      dither_store_strip<CH, true>(p, id, fbase, park);
-#endif
-    }
-
+    // Both steps are inlined into the loop.  Left alone, LLVM hoists every lane-dependent address computation of both steps
+    // out of the loop (they only depend on threadIdx) and keeps them all live: 194 VGPRs.  Passing the thread id through an
+    // empty asm at the top of each iteration makes it opaque per iteration, which keeps the two steps' live ranges apart.
     // Persistent single-launch encode: 3 workgroups per CU loop over the work strips (ticket order).  Each iteration runs the
     // VALU-bound E step (fit + search) of a new strip and then the HBM-bound F step (dither, decode, all plane stores) of the
     // strip the SAME workgroup fitted one iteration earlier, whose parked results sit in a private, L2-resident 8 KiB slot.
@@ -1511,7 +1490,6 @@ namespace limg_hip
       __shared__ __attribute__((aligned(16))) uint8_t s_lds[kLdsTotal];
       __shared__ uint32_t s_ticket;
       const int tid = (int)threadIdx.x;
-      const KernargPtr kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
       load_rsqrt_table(s_lds, tid);
       const uint32_t S = p.stripsX * p.blocksY;
       uint8_t *park = p.park + (size_t)blockIdx.x * 2 * kParkBytes;
@@ -1522,11 +1500,15 @@ namespace limg_hip
         if (tid == 0) s_ticket = atomicAdd(p.ticket, 1u);
         __syncthreads();
         const uint32_t t = s_ticket;
-        if (t < S) step_e<CH>(kp, t, s_lds, park + slot * kParkBytes);
+        int tid_e = tid;
+        asm volatile("" : "+v"(tid_e));
+        if (t < S) fit_search_strip<CH, true>(p, t, s_lds, park + slot * kParkBytes, tid_e);
         if (prev != 0xFFFFFFFFu)
         {
           __syncthreads();
-          step_f<CH>(kp, prev, s_lds + kLdsStrip, park + (slot ^ 1u) * kParkBytes);
+          int tid_f = tid;
+          asm volatile("" : "+v"(tid_f));
+          dither_store_strip<CH, true>(p, prev, s_lds + kLdsStrip, park + (slot ^ 1u) * kParkBytes, tid_f);
         }
         if (t >= S) break;
         prev = t;
