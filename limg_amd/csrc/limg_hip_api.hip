@@ -283,7 +283,7 @@ extern "C"
     if (!c) return limg_hip_error_MemoryAllocationFailure;
     c->device = device;
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->persistentWorkgroups = 4 * prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->persistentWorkgroups = 5 * prop.multiProcessorCount;
     limg_hip_default_options(&c->opt);
     *ppCtx = c;
     return limg_hip_success;

@@ -21,7 +21,7 @@
 //
 // Float-stage numerics are those of the reference's SSE4.1 path executed strictly (see DESIGN.md "numerics"):
 //   * DPPS summation order (x0y0 + x1y1) + (x2y2 + x3y3), no FMA contraction (built with -ffp-contract=off);
-//   * RSQRTPS through the captured 2048-entry table (limg_rsqrt_x86_table.h) held in LDS;
+//   * RSQRTPS through the captured 2048-entry table (limg_rsqrt_x86_table.h), read through the vector L1;
 //   * the three direction accumulations run in *pixel order*: the per-pixel unit vectors of a batch of 4 blocks are parked in
 //     LDS and 16 lanes (4 blocks x 4 channels) each walk one serial 64-term chain -- ~2 instructions per term for 16
 //     chains at once instead of a 64-step dependent chain per block;
@@ -643,7 +643,6 @@ namespace limg_hip
       uint32_t flags, n;                                // 128
       int16_t rec[24];                                  // 176
       float pad[4];                                     // 192
-      int32_t tn[3][4], tm[3][4];                       // 288: packed-trial constants (RGB): integer normals, (min << 8) + 128 (+ R bias)
     };
     struct BlkE
     {
@@ -652,7 +651,7 @@ namespace limg_hip
       float invN[3];   // 108
     };
     static_assert(sizeof(BlkE) <= 120, "BlkE must fit the dead float-stage fields");
-    static_assert(sizeof(BlkF) == 288, "BlkF layout");
+    static_assert(sizeof(BlkF) == 192, "BlkF layout");
 
     // exact min / max over the wave of two values at once (no NaN present); results wave-uniform.
     // Hand-written DPP: the two chains interleave so each needs only one wait state between dependent steps.
@@ -846,15 +845,10 @@ namespace limg_hip
     }
 
     // LDS of an E task (fit + search of one work strip); the F task's areas overlay `V`.
-    constexpr int kLdsRsq = 0, kLdsStrip = 4096, kLdsV = kLdsStrip + 8 * kRowDw * 4, kLdsVBytes = kWaves * kBatch * kVDw * 4;
-    constexpr int kLdsBlk = kLdsV + kLdsVBytes, kLdsCalls = kLdsBlk + kStripBlocks * 288, kLdsTotal = kLdsCalls + 16;
-    static_assert(kLdsTotal <= 40960 - 16, "at least 4 workgroups per CU");
+    constexpr int kLdsStrip = 0, kLdsV = kLdsStrip + 8 * kRowDw * 4, kLdsVBytes = kWaves * kBatch * kVDw * 4;
+    constexpr int kLdsBlk = kLdsV + kLdsVBytes, kLdsCalls = kLdsBlk + kStripBlocks * 192, kLdsTotal = kLdsCalls + 16;
+    static_assert(kLdsTotal <= 32768 - 16, "5 workgroups per CU");
 
-    __device__ __forceinline__ void load_rsqrt_table(uint8_t *lds, int tid)
-    {
-      for (int i = tid; i < 2048 / 8; i += kThreads)
-        reinterpret_cast<uint4 *>(lds + kLdsRsq)[i] = reinterpret_cast<const uint4 *>(d_rsqrt_x86_tab)[i];
-    }
 
     // PERSIST == false: split path, the strip's call count goes to p.stripCalls for k_strip_scan.
     // PERSIST == true : persistent kernel, the count is published as an "aggregate" look-back descriptor.
@@ -864,7 +858,9 @@ namespace limg_hip
     template <int CH, bool PERSIST>
     __device__ __forceinline__ void fit_search_strip(const EncodeParams &p, const uint32_t id, uint8_t *lds, uint8_t *park, const int tid)
     {
-      unsigned short *s_rsq = reinterpret_cast<unsigned short *>(lds + kLdsRsq);
+      // the 4 KiB RSQRTPS table is read straight from global memory (it lives in the CU's vector L1): keeping a copy in LDS would
+      // cost the fifth workgroup per CU
+      const unsigned short *s_rsq = d_rsqrt_x86_tab;
       uint32_t *s_strip = reinterpret_cast<uint32_t *>(lds + kLdsStrip);
       float *s_V = reinterpret_cast<float *>(lds + kLdsV);
       BlkF *s_blk = reinterpret_cast<BlkF *>(lds + kLdsBlk);
@@ -1140,8 +1136,6 @@ namespace limg_hip
             BlkE *e = reinterpret_cast<BlkE *>(&blk[b]);
             e->nrm[f][c] = nrm[r]; e->off[f][c] = off[r];
             if (c == 0) e->invN[f] = invn[r];
-            blk[b].tn[f][c] = (int)nrm[r];                                                     // exact: |hi - lo| < 2^17
-            blk[b].tm[f][c] = ((int)off[r] << 8) + 128 + (c == 0 ? (kTermBias << 8) : 0);
           }
         }
       }
@@ -1214,12 +1208,13 @@ namespace limg_hip
             t.loRG = ((R - 255u) & 0xFFFFu) | ((G - 255u) << 16);
             t.pxB = (int)((px >> 16) & 0xFF);
             t.pxBlo = t.pxB - 255;
-            {
-              // uniform values, kept in VGPRs: they are operands of v_mad_i32_i24
-              const int4 a4 = *reinterpret_cast<const int4 *>(blk[b].tn[0]), b4 = *reinterpret_cast<const int4 *>(blk[b].tn[1]), c4 = *reinterpret_cast<const int4 *>(blk[b].tn[2]);
-              const int4 ma = *reinterpret_cast<const int4 *>(blk[b].tm[0]), mb = *reinterpret_cast<const int4 *>(blk[b].tm[1]), mc = *reinterpret_cast<const int4 *>(blk[b].tm[2]);
-              t.nA[0] = a4.x; t.nA[1] = a4.y; t.nA[2] = a4.z; t.nB[0] = b4.x; t.nB[1] = b4.y; t.nB[2] = b4.z; t.nC[0] = c4.x; t.nC[1] = c4.y; t.nC[2] = c4.z;
-              t.mA[0] = ma.x; t.mA[1] = ma.y; t.mA[2] = ma.z; t.mB[0] = mb.x; t.mB[1] = mb.y; t.mB[2] = mb.z; t.mC[0] = mc.x; t.mC[1] = mc.y; t.mC[2] = mc.z;
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+            { // uniform values, kept in VGPRs: they are operands of v_mad_i32_i24
+              const int bias = c == 0 ? (kTermBias << 8) : 0;
+              const int loA = blk[b].rec[c], hiA = blk[b].rec[4 + c], loB = blk[b].rec[8 + c], hiB = blk[b].rec[12 + c], loC = blk[b].rec[16 + c], hiC = blk[b].rec[20 + c];
+              t.nA[c] = hiA - loA; t.nB[c] = hiB - loB; t.nC[c] = hiC - loC;
+              t.mA[c] = (loA << 8) + 128 + bias; t.mB[c] = (loB << 8) + 128 + bias; t.mC[c] = (loC << 8) + 128 + bias;
             }
             t.cA = t.cB = t.cC = 0xFFu;
             t.tA_RG = t.tB_RG = t.tC_RG = 0; t.tA_B = t.tB_B = t.tC_B = 0;
@@ -1374,7 +1369,7 @@ namespace limg_hip
     // F task: dither + stores + decode of one work strip from the parked per-block results.
     // PERSIST == false: the strip's chain position comes from k_strip_scan (p.stripBase);
     // PERSIST == true : from the look-back over the descriptors, and the strip's inclusive count is published first thing.
-    static_assert(kPhaseFBytes + kStripBlocks * 48 <= kLdsTotal - kLdsStrip - 16, "the F step's LDS overlays everything of the E step but the rsqrt table");
+    static_assert(kPhaseFBytes + kStripBlocks * 48 <= kLdsTotal - kLdsStrip - 16, "the F step's LDS overlays the E step's");
 
     template <int CH, bool PERSIST>
     __device__ __forceinline__ void dither_store_strip(const EncodeParams &p, const uint32_t id, uint8_t *fbase, const uint8_t *park, const int tid)
@@ -1463,7 +1458,6 @@ namespace limg_hip
     __global__ __launch_bounds__(kThreads) void k_fit_search(const EncodeParams p)
     {
       __shared__ __attribute__((aligned(16))) uint8_t s_lds[kLdsTotal];
-      load_rsqrt_table(s_lds, (int)threadIdx.x);
       fit_search_strip<CH, false>(p, blockIdx.x, s_lds, nullptr, (int)threadIdx.x);
     }
 
@@ -1485,12 +1479,11 @@ namespace limg_hip
     // drift apart, E and F steps of different workgroups overlap on every CU.
     // Progress: a look-back only waits for strips with smaller tickets; those were drawn earlier, and an E step never waits.
     template <int CH>
-    __global__ __launch_bounds__(kThreads, 4) void k_encode_persistent(const EncodeParams p)
+    __global__ __launch_bounds__(kThreads, 5) void k_encode_persistent(const EncodeParams p)
     {
       __shared__ __attribute__((aligned(16))) uint8_t s_lds[kLdsTotal];
       __shared__ uint32_t s_ticket;
       const int tid = (int)threadIdx.x;
-      load_rsqrt_table(s_lds, tid);
       const uint32_t S = p.stripsX * p.blocksY;
       uint8_t *park = p.park + (size_t)blockIdx.x * 2 * kParkBytes;
       uint32_t prev = 0xFFFFFFFFu, slot = 0;
