@@ -87,7 +87,9 @@ limg_hip_result limg_hip_encode3d_perf(limg_hip_context *pCtx, const uint32_t *p
 
 /* Device-resident variant of `limg_encode3d_test`: every pointer (pIn, the 11 planes inside *pInfo, pCompact members)
  * is a DEVICE pointer; pInfo / pCompact themselves are host structs.  Asynchronous on `stream` (a hipStream_t passed
- * as void*; NULL = default stream).  pInfo == NULL gives the `_perf` behaviour (fit + search only). */
+ * as void*; NULL = default stream).  pInfo == NULL gives the `_perf` behaviour (fit + search only).
+ * Compact mode (SURVEY.md 8(d), 8.05 B/px): pInfo with the eight uint32 plane pointers all NULL and the three factor planes set
+ * writes only the crushed factor bytes; together with pCompact (records + shift words) that is everything a decoder needs. */
 limg_hip_result limg_hip_encode3d_device(limg_hip_context *pCtx, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha,
                                          const limg_hip_encode3d_info *pInfo, const limg_hip_compact_out *pCompact, uint32_t errorFactor, int poolThreads,
                                          int fastBitCrushing, void *stream);

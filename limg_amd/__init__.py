@@ -176,7 +176,7 @@ class LimgHip:
         h, w = img.shape
         info = None
         if planes is not None:
-            info = Info(*[planes[k].data_ptr() for k in PLANES])
+            info = Info(*[(planes[k].data_ptr() if k in planes else None) for k in PLANES])  # compact mode: only the factor planes
         comp = None
         if records is not None or shifts is not None:
             comp = CompactOut(records.data_ptr() if records is not None else None, shifts.data_ptr() if shifts is not None else None)

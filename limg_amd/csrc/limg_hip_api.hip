@@ -134,11 +134,17 @@ namespace
   {
     if (!c || !dIn) return limg_hip_error_ArgumentNull;
     if (sizeX == 0 || sizeY == 0 || sizeX > 0x7FFFFFF8ull || sizeY > 0x7FFFFFF8ull) return limg_hip_error_InvalidParameter;
+    bool fullPlanes = true;
     if (dInfo)
     {
+      // either all 11 planes, or (compact mode) only the three factor planes with the eight uint32 planes all NULL
       const void *const *pp = reinterpret_cast<const void *const *>(dInfo);
-      for (int i = 0; i < 11; i++)
+      int n32 = 0;
+      for (int i = 0; i < 8; i++) n32 += pp[i] != nullptr;
+      for (int i = 8; i < 11; i++)
         if (!pp[i]) return limg_hip_error_ArgumentNull;
+      if (n32 != 0 && n32 != 8) return limg_hip_error_ArgumentNull;
+      fullPlanes = n32 == 8;
     }
     HIP_TRY(hipSetDevice(c->device));
 
@@ -172,6 +178,7 @@ namespace
     if ((r = c->stripBase.ensure(strips * 4)) != limg_hip_success) return r;
     p.stripCalls = (uint32_t *)c->stripCalls.p; p.stripBase = (uint32_t *)c->stripBase.p;
     p.storePlanes = dInfo != nullptr;
+    p.fullPlanes = fullPlanes;
     if (dInfo) p.info = *dInfo;
     const int channels = hasAlpha ? 4 : 3;
     const bool ragged = (sizeX % kBlock) != 0 || (sizeY % kBlock) != 0;

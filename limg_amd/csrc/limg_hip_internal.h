@@ -33,6 +33,7 @@ namespace limg_hip
     // pre-dither factor bytes live in the caller's factor planes between the two kernels
     limg_hip_encode3d_info info;
     int32_t storePlanes;   // 0: _perf behaviour
+    int32_t fullPlanes;    // 0: compact mode -- only the three factor planes (+ records / shift words) are written
     // dither noise: byte p of call k = low byte of the 16-bit lane the reference ANDs with ditherSize for pixel p
     const uint8_t *noise;
     // fused single-kernel path: per-strip look-back descriptors (status << 32 | value), work ticket, error word

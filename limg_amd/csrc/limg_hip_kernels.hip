@@ -557,6 +557,15 @@ namespace limg_hip
           f[k] = v;
         }
 
+        if (!p.fullPlanes)
+        { // compact mode: only the crushed factor bytes are wanted
+          if (active)
+          {
+#pragma unroll
+            for (int k = 0; k < 3; k++) out[k * 2048 + o] = (uint8_t)(f[k] << shift[k]);
+          }
+          continue;
+        }
         // decode: dec_k = byte * mul_k, est_c = sum_k (dec_k * n_k[c] + m_k[c]) >> 8, clamp.  24-bit multiplies are exact here:
         // dec <= 255 * 256 and |n| <= 65535 (difference of two int16), and v_mad_i32_i24 keeps the low 32 bits like PMULLD.
         const int *nm = L.nm + sb * 24;
@@ -584,7 +593,7 @@ namespace limg_hip
       wave_lds_fence();
 
       const uint32_t wx0 = x0 + wave * 64;
-      if (wx0 < p.sizeX)
+      if (wx0 < p.sizeX && p.fullPlanes)
       {
         const uint32_t ww = min(p.sizeX - wx0, 64u);
         if ((uint32_t)lane < ww)
@@ -1422,7 +1431,7 @@ namespace limg_hip
       __syncthreads();
       phase_f_prepare<CH>(L, lane, wave);
       wave_lds_fence();
-      phase_f_store_const(p, L, x0, y0, ry, lane, wave); // base-independent: 28 of the 35 output bytes per pixel
+      if (p.fullPlanes) phase_f_store_const(p, L, x0, y0, ry, lane, wave); // base-independent: 28 of the 35 output bytes per pixel
       if (wave == 0)
       {
         uint32_t base;

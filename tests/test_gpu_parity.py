@@ -267,3 +267,25 @@ def test_repeatability_and_context_reuse(gpu, oracle):
         for k in PLANES:
             assert np.array_equal(a[k], b[k]), k
         assert oracle.fnv(a["pDecoded"]) == oracle.fnv(oracle.encode3d(img, True)["pDecoded"])
+
+
+def test_compact_mode(gpu, oracle):
+    """Compact outputs (SURVEY 8(d), 8.05 B/px): factor planes + records + shift words only; identical to the full run's."""
+    import torch
+    import limg_amd
+    img = oracle.photo_noise(512, 64, 43)
+    want = oracle.encode3d(img, True, extras=True)
+    d_img = torch.from_numpy(img.view(np.int32)).cuda()
+    fac = {k: torch.zeros((64, 512), dtype=torch.uint8, device="cuda") for k in limg_amd.P8}
+    rec = torch.zeros((8 * 64, 16), dtype=torch.int32, device="cuda")
+    sh = torch.zeros(8 * 64, dtype=torch.int32, device="cuda")
+    gpu.encode3d_device(d_img, True, fac, records=rec, shifts=sh)
+    torch.cuda.synchronize()
+    for k in limg_amd.P8:
+        assert np.array_equal(fac[k].cpu().numpy(), want[k]), k
+    grec = rec.cpu().numpy().view(REC_DTYPE).reshape(8, 64)
+    for f in REC_DTYPE.names:
+        assert np.array_equal(grec[f], want["records"][f]), f
+    gsh = sh.cpu().numpy().astype(np.uint32).reshape(8, 64)
+    for i in range(3):
+        assert np.array_equal((gsh >> (8 * i)) & 0xFF, want["shifts"][:, :, i])
