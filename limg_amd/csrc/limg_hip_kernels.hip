@@ -655,8 +655,8 @@ namespace limg_hip
     };
     struct BlkE
     {
-      float nrm[3][4]; // 48: float normals (max - min) of A, B, C
-      float off[3][4]; // 96: float dirA_min, dirB_offset, dirC_offset
+      float nrm[3][4]; // 48: float normals (max - min) of A, B, C            (slot order x0 x2 x1 x3)
+      float off[3][4]; // 96: float dirA_min, dirB_offset, dirC_offset         (slot order)
       float invN[3];   // 108
     };
     static_assert(sizeof(BlkE) <= 120, "BlkE must fit the dead float-stage fields");
@@ -1143,7 +1143,7 @@ namespace limg_hip
           {
             const int b = idx / 12, fc = idx - b * 12, f = fc >> 2, c = fc & 3;
             BlkE *e = reinterpret_cast<BlkE *>(&blk[b]);
-            e->nrm[f][c] = nrm[r]; e->off[f][c] = off[r];
+            e->nrm[f][slot_of(c)] = nrm[r]; e->off[f][slot_of(c)] = off[r]; // slot order x0 x2 x1 x3, see V4
             if (c == 0) e->invN[f] = invn[r];
           }
         }
@@ -1168,31 +1168,22 @@ namespace limg_hip
         uint32_t px = s_strip[ly * kRowDw + sb * kBlock + lx];
         const bool active = (uint32_t)lane < n;
         px = active ? px : 0u;
-        float pf[4];
-        px_to_float(px, pf);
         const BlkE *be = reinterpret_cast<const BlkE *>(&blk[b]);
 
         uint32_t fA, fB, fC;
-        {
-          float t[4], est[4];
-          const float4 nA4 = *reinterpret_cast<const float4 *>(be->nrm[0]), oA4 = *reinterpret_cast<const float4 *>(be->off[0]);
-          const float nA[4] = { nA4.x, nA4.y, nA4.z, nA4.w }, mnA[4] = { oA4.x, oA4.y, oA4.z, oA4.w };
-#pragma unroll
-          for (int c = 0; c < 4; c++) t[c] = pf[c] - mnA[c];
-          const float fa = dpps<CH>(t, nA) * be->invN[0];
-          int q = cvt_rne(255.0f * fa); q = q < 255 ? q : 255; q = q > 0 ? q : 0; fA = (uint32_t)q;
-          const float4 nB4 = *reinterpret_cast<const float4 *>(be->nrm[1]), oB4 = *reinterpret_cast<const float4 *>(be->off[1]);
-          const float nB[4] = { nB4.x, nB4.y, nB4.z, nB4.w }, ofB[4] = { oB4.x, oB4.y, oB4.z, oB4.w };
-#pragma unroll
-          for (int c = 0; c < 4; c++) { est[c] = mnA[c] + nA[c] * fa; t[c] = (pf[c] - est[c]) - ofB[c]; }
-          const float fb = dpps<CH>(t, nB) * be->invN[1];
-          q = cvt_rne(255.0f * fb); q = q < 255 ? q : 255; q = q > 0 ? q : 0; fB = (uint32_t)q;
-          const float4 nC4 = *reinterpret_cast<const float4 *>(be->nrm[2]), oC4 = *reinterpret_cast<const float4 *>(be->off[2]);
-          const float nC[4] = { nC4.x, nC4.y, nC4.z, nC4.w }, ofC[4] = { oC4.x, oC4.y, oC4.z, oC4.w };
-#pragma unroll
-          for (int c = 0; c < 4; c++) { est[c] = est[c] + nB[c] * fb; t[c] = (pf[c] - est[c]) - ofC[c]; }
-          const float fc = dpps<CH>(t, nC) * be->invN[2];
-          q = cvt_rne(255.0f * fc); q = q < 255 ? q : 255; q = q > 0 ? q : 0; fC = (uint32_t)q;
+        { // a8 (src/limg_factorization.h:149-197): fa = ((px - Amin) . nA) * invA, est = Amin + nA * fa, fb from px - est - Boff, ...
+          const V4 pv = px_to_v4(px);
+          const V4 nA = ld4(be->nrm[0]), mnA = ld4(be->off[0]);
+          const float fa = dp4<CH>(pv - mnA, nA) * be->invN[0];
+          int q = cvt_rne(255.0f * fa); fA = (uint32_t)med3_i32(q, 0, 255);
+          const V4 nB = ld4(be->nrm[1]), ofB = ld4(be->off[1]);
+          V4 est = mnA + nA * fa;
+          const float fb = dp4<CH>((pv - est) - ofB, nB) * be->invN[1];
+          q = cvt_rne(255.0f * fb); fB = (uint32_t)med3_i32(q, 0, 255);
+          const V4 nC = ld4(be->nrm[2]), ofC = ld4(be->off[2]);
+          est = est + nB * fb;
+          const float fc = dp4<CH>((pv - est) - ofC, nC) * be->invN[2];
+          q = cvt_rne(255.0f * fc); fC = (uint32_t)med3_i32(q, 0, 255);
         }
 
         uint32_t shift[3] = { 0, 0, 0 };
