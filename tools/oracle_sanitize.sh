@@ -1,0 +1,26 @@
+#!/usr/bin/env bash
+# Builds the CPU oracle with AddressSanitizer + UndefinedBehaviorSanitizer and replays the golden cases through it
+# (GPU sanitizers are not available on the pool; the CPU restatement is the place to catch UB such as bad shifts).
+set -euo pipefail
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+OUT=$(mktemp -d)
+trap 'rm -rf "$OUT"' EXIT
+gcc -std=c11 -O1 -g -fPIC -ffp-contract=off -fsanitize=address,undefined -fno-sanitize-recover=undefined -shared -o "$OUT/liblimg_oracle_asan.so" "$ROOT/oracle/limg_oracle.c" -lm -lpthread
+LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 python3 - "$ROOT" "$OUT/liblimg_oracle_asan.so" <<'PY'
+import sys
+root, lib = sys.argv[1], sys.argv[2]
+sys.path.insert(0, root); sys.path.insert(0, root + "/tests")
+import numpy as np
+from oracle.bind import Oracle, PLANES
+import golden_util as gu
+o = Oracle(lib)
+idx, z = gu.cases()
+for i, m in enumerate(idx):
+    r = o.encode3d(z["c%02d_in" % i], m["alpha"], error_factor=m["ef"], pool_threads=m["pool"], fast=m["fast"], dither_mode=m["dither"])
+    for k in PLANES:
+        assert np.array_equal(r[k], z["c%02d_%s" % (i, k)]), (i, k)
+rng = np.random.default_rng(0)
+img = rng.integers(0, 2**32, (40, 61), dtype=np.uint32)
+o.encode3d(img, True); o.encode3d(img, False, pool_threads=3, worker_threads=2)
+print("oracle clean under ASan+UBSan on %d golden cases + random bytes" % len(idx))
+PY
