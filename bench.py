@@ -71,6 +71,127 @@ def cpu_baseline(width, seed, budget_s=25.0):
                       "(best of %d); single-thread: %.2f Mpixels/s" % (rows, width, rows, px / 1e6, pool, reps, px / t1 / 1e6)}
 
 
+def run_sharded(args, g, dist, rank, world):
+    """BASELINE configs[3] / configs[4] (SURVEY.md 8(d) configs 4 and 5, 8(e)): the multi-GPU shapes of the path.  Same JSON contract;
+    the plane reassembly on rank 0 is timed apart from the encode and reported in `config` (it is not part of `value`)."""
+    import torch
+    import numpy as np
+    from limg_amd import shard
+    if args.config == 4:
+        W = H = 4096 if args.size == 8192 else args.size
+        kind = "random_gradient" if args.workload == "photo_noise" and args.size == 8192 else args.workload
+        mine = shard.batch_assignment(args.images, world, rank)
+        units = [(g.synth_device(kind, W, H, seed=1 + i), g.alloc_planes_device(W, H)) for i in mine]
+        total_px = args.images * W * H
+        name = "batch of %d synthetic %dx%d RGBA %s images (seeds 1..%d), image i -> rank i %% %d" % (args.images, W, H, kind, args.images, world)
+        rows = None
+    else:
+        W = H = 16384 if args.size == 8192 else args.size
+        kind = args.workload
+        strips = shard.strip_rows(H, 8)   # the reference's partition for a pool of 2 threads (2 * 4 strips), src/limg.cpp:2114-2134
+        if 8 % world:
+            raise SystemExit("--config 5 needs a world size that divides 8")
+        per = 8 // world
+        rows = strips
+        units = []
+        for sidx in range(rank * per, (rank + 1) * per):
+            y0, y1 = strips[sidx]
+            units.append((g.synth_device(kind, W, y1 - y0, seed=1, y0=y0), g.alloc_planes_device(W, y1 - y0)))
+        total_px = W * H
+        name = ("one synthetic %dx%d RGBA %s image as 8 strips of whole block rows with restarted dither chains (== reference with a pool of 2 threads), "
+                "%d strips per rank" % (W, H, kind, per))
+    torch.cuda.synchronize()
+
+    def step():
+        for img, planes in units:
+            g.encode3d_device(img, True, planes, error_factor=args.error_factor, pool_threads=0, fast=True)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    g.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernels = g.profile_end(args.steps * max(len(units), 1))
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    torch.cuda.synchronize()
+    g.check()
+
+    # reassembly on rank 0 (config 5: the strips of the one image; config 4: every image's planes), timed apart
+    gather_ms = None
+    gathered_bytes = 0
+    if dist is not None and not args.no_gather:
+        on_gpu = dist.get_backend() == "nccl"
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if args.config == 5:
+            per = 8 // world
+            for k in range(per):   # strip k of every rank; rows of the gathered pieces come from the strip table
+                planes = units[k][1] if on_gpu else {n: v.cpu() for n, v in units[k][1].items()}
+                piece_rows = [rows[r * per + k] for r in range(world)]
+                full = shard.gather_planes(planes, piece_rows, W, dist, dst=0)
+                if rank == 0:
+                    gathered_bytes += sum(v.numel() * v.element_size() for v in full.values())
+                del full
+        else:
+            n_round = (args.images + world - 1) // world
+            for k in range(n_round):
+                have = k < len(units)
+                src_ranks = [r for r in range(world) if k * world + r < args.images]
+                for n in limg_planes():
+                    tsr = units[k][1][n] if have else None
+                    if tsr is not None and not on_gpu:
+                        tsr = tsr.cpu()
+                    if rank == 0:
+                        bufs = [torch.empty_like(tsr) for r in src_ranks if r != 0]
+                        reqs = [dist.irecv(b, src=r) for b, r in zip(bufs, [r for r in src_ranks if r != 0])]
+                        for q in reqs:
+                            q.wait()
+                        gathered_bytes += sum(b.numel() * b.element_size() for b in bufs)
+                    elif rank in src_ranks:
+                        dist.send(tsr.contiguous(), dst=0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        gather_ms = (time.perf_counter() - t0) * 1e3
+
+    if rank == 0:
+        kavg = kernels.mean(axis=0) if len(kernels) else np.zeros(3)
+        ksum = float(kavg.sum())
+        px_per_launch = units[0][0].numel() if units else 0
+        achieved = ALGO_BYTES_PER_PX * px_per_launch / (ksum * 1e-3) / 1e9 if ksum > 0 else 0.0
+        line = {
+            "metric": "encode Mpixels/s, RGBA (limg_encode3d_test-equivalent: all 11 planes stored), BASELINE configs[%d]" % (args.config - 1),
+            "value": round(total_px * args.steps / elapsed / 1e6, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u8/i32 integer stage + f32 float stage (bit-exact vs the reference's strict SSE build)", "data": "synthetic",
+            "config": {"workload": name + ", errorFactor %d, fast bit-crush" % args.error_factor,
+                       "parallelism": "no data-path collective; plane reassembly on rank 0 timed apart",
+                       "gather_ms": None if gather_ms is None else round(gather_ms, 3), "gathered_bytes_rank0": gathered_bytes,
+                       "gather_backend": None if dist is None else dist.get_backend()},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": None, "algorithmic_bytes_per_launch": int(ALGO_BYTES_PER_PX * px_per_launch),
+                         "kernels_ms": {"k_encode_persistent": round(float(kavg[0]), 4)},
+                         "note": "per launch = one image (config 4) / one strip (config 5) on rank 0; HIP events on the launch stream"},
+        }
+        print(json.dumps(line), flush=True)
+
+
+def limg_planes():
+    import limg_amd
+    return limg_amd.PLANES
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +204,11 @@ def main():
     ap.add_argument("--split", action="store_true", help="three-launch path instead of the fused kernel")
     ap.add_argument("--compact", action="store_true", help="compact mode: factor planes + records + shift words only (8.05 B/px)")
     ap.add_argument("--forced-shift", type=int, default=-1, help="bypass the shift search with this shift on all three factors (bit-crush sweep)")
+    ap.add_argument("--config", type=int, default=3, choices=[3, 4, 5],
+                    help="BASELINE.json configs, 1-based: 3 = headline (default), 4 = batch of 64 x 4096^2 images over the ranks + gather, "
+                         "5 = one 16384^2 image as 8 reference strips over the ranks + gather")
+    ap.add_argument("--images", type=int, default=64, help="--config 4: images in the batch")
+    ap.add_argument("--no-gather", action="store_true", help="--config 4/5: skip the reassembly of the planes on rank 0")
     args = ap.parse_args()
 
     import torch
@@ -116,6 +242,12 @@ def main():
 
     W = H = args.size
     g = limg_amd.LimgHip(dev)
+    if args.config != 3:
+        run_sharded(args, g, dist, rank, n_gpus)
+        g.close()
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if args.forced_shift >= 0 or args.split:
         g.set_options(forced_shift=(args.forced_shift,) * 3 if args.forced_shift >= 0 else None, force_split=args.split)
     img = g.synth_device(args.workload, W, H, seed=1 + rank)
