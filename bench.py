@@ -187,6 +187,67 @@ def run_sharded(args, g, dist, rank, world):
         print(json.dumps(line), flush=True)
 
 
+def run_stream(args, g, dist, rank, world, W, H):
+    """`limg_encode` / `limg_decode` over the compact stream: value = encode-to-stream throughput; the decode kernel (HBM-bound: reads
+    the stream, writes 4 B/px) gets the roofline object.  Same barrier / max-over-ranks timing as the headline mode."""
+    import torch
+    import numpy as np
+    img = g.synth_device(args.workload, W, H, seed=1 + rank)
+    st, nbytes = g.encode_stream_device(img, True, error_factor=args.error_factor)
+    dec = g.decode_stream_device(st, nbytes, W, H)
+    planes = g.alloc_planes_device(W, H)
+    g.encode3d_device(img, True, planes, error_factor=args.error_factor)
+    torch.cuda.synchronize()
+    same = bool(torch.equal(dec, planes["pDecoded"]))
+    del planes
+
+    def timed(fn):
+        for _ in range(args.warmup):
+            fn()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        g.profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        k = g.profile_end(args.steps * 2)
+        if dist is not None:
+            dist.barrier()
+            t = torch.tensor([el], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, k
+
+    el_e, k_e = timed(lambda: g.encode_stream_device(img, True, out=st, error_factor=args.error_factor, want_size=False))
+    el_d, k_d = timed(lambda: g.decode_stream_device(st, nbytes, W, H, out=dec))
+    g.check()
+    if rank == 0:
+        px = W * H
+        enc_ms = float(k_e[0::2, 0].mean()) if len(k_e) else 0.0
+        pack_ms = float(k_e[1::2, 0].mean()) if len(k_e) > 1 else 0.0
+        dec_ms = float(k_d[:, 0].mean()) if len(k_d) else 0.0
+        dec_bytes = nbytes + 4 * px
+        achieved = dec_bytes / (dec_ms * 1e-3) / 1e9 if dec_ms > 0 else 0.0
+        line = {
+            "metric": "encode-to-stream Mpixels/s, RGBA (compact LMG3 stream: limg_encode equivalent)", "value": round(world * px * args.steps / el_e / 1e6, 1),
+            "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el_e * 1e3 / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/i32 integer stage + f32 float stage", "data": "synthetic",
+            "config": {"workload": "synthetic %dx%d RGBA %s (seed 1+rank) per GPU, errorFactor %d" % (W, H, args.workload, args.error_factor),
+                       "stream_bytes": int(nbytes), "stream_bytes_per_px": round(nbytes / px, 4), "roundtrip_equals_pDecoded": same,
+                       "decode_Mpixels_per_s": round(world * px * args.steps / el_d / 1e6, 1), "decode_ms_per_step": round(el_d * 1e3 / args.steps, 4)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(dec_bytes),
+                         "kernels_ms": {"k_encode_persistent": round(enc_ms, 4), "k_stream_count+scan+pack": round(pack_ms, 4), "k_stream_decode": round(dec_ms, 4)},
+                         "note": "roofline object = k_stream_decode: (stream bytes + 4 B/px written) / its average duration"},
+        }
+        print(json.dumps(line), flush=True)
+
+
 def limg_planes():
     import limg_amd
     return limg_amd.PLANES
@@ -207,6 +268,7 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=[3, 4, 5],
                     help="BASELINE.json configs, 1-based: 3 = headline (default), 4 = batch of 64 x 4096^2 images over the ranks + gather, "
                          "5 = one 16384^2 image as 8 reference strips over the ranks + gather")
+    ap.add_argument("--stream", action="store_true", help="compact LMG3 stream instead of the planes: encode + pack, then decode (SURVEY 8(f) #2)")
     ap.add_argument("--images", type=int, default=64, help="--config 4: images in the batch")
     ap.add_argument("--no-gather", action="store_true", help="--config 4/5: skip the reassembly of the planes on rank 0")
     args = ap.parse_args()
@@ -242,6 +304,12 @@ def main():
 
     W = H = args.size
     g = limg_amd.LimgHip(dev)
+    if args.stream:
+        run_stream(args, g, dist, rank, n_gpus, W, H)
+        g.close()
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if args.config != 3:
         run_sharded(args, g, dist, rank, n_gpus)
         g.close()

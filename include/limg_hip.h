@@ -127,6 +127,58 @@ limg_hip_result limg_hip_host_noise_table(uint8_t *pOut, size_t calls);
 uint64_t limg_hip_host_chain_call(uint64_t chainValue, size_t pixelCount, uint8_t *pNoise64, int forceSoftwareAes);
 limg_hip_result limg_hip_host_partition(size_t sizeY, int poolThreads, uint32_t *pChainCount, uint32_t *pChainBlockRows);
 
+/* ---- compact stream ("LMG3") -----------------------------------------------------------------------------------------------
+ * The north-star names `limg_encode()` / `limg_decode()` and a bitstream; upstream has neither (src/limg.h:27-48 is the whole API,
+ * SURVEY.md 0.1 / 8(f) #2).  These entry points are the build-defined pair over a container that holds exactly what the reference's
+ * decoder (`limg_decode_block_from_factors_3d`, src/limg_decode.h:36-236, called at src/limg.cpp:2093) consumes, so that
+ * decode(encode(image)) equals the reference's pDecoded plane bit for bit.  Layout, little endian, sections 8-byte aligned:
+ *   limg_hip_stream_header | limg_hip_stream_block[blocksX * blocksY] (raster order) | payload (8-byte words)
+ * Block payload at `payloadWord`: factor A field, B field, C field; a field of b = 8 - shift bits per pixel is b words, pixel
+ * (row r, column x) of the 8x8 grid at bit (8 r + x) b (pixels outside the image are 0).  shift 8 => no field, except the
+ * raw-byte escape (bit 24 + k of `shift`): 4-channel blocks whose factor-k alpha normal is non-zero keep the raw 8-bit factor,
+ * because the reference multiplies it into the alpha lane even at shift 8. */
+#define LIMG_HIP_STREAM_MAGIC 0x33474D4Cu /* "LMG3" */
+#define LIMG_HIP_STREAM_VERSION 1u
+
+typedef struct limg_hip_stream_header
+{
+  uint32_t magic, version;
+  uint32_t sizeX, sizeY;
+  uint32_t channels;    /* 3 or 4 (hasAlpha) */
+  uint32_t errorFactor; /* informational */
+  uint32_t blocksX, blocksY;
+  uint64_t payloadWords; /* 8-byte words after the block table */
+  uint64_t totalBytes;   /* header + table + payload */
+  uint32_t flags;        /* bit 0: fast bit crushing, bit 1: PCG dither (informational) */
+  uint32_t reserved[3];
+} limg_hip_stream_header; /* 64 bytes */
+
+typedef struct limg_hip_stream_block
+{
+  int16_t dirA_min[4], dirA_max[4], dirB_offset[4], dirB_mag[4], dirC_offset[4], dirC_mag[4]; /* `limg_encode_3d_output` minus avg */
+  uint32_t shift;       /* shiftA | shiftB << 8 | shiftC << 16 | rawEscapeMask << 24 */
+  uint32_t payloadWord; /* first payload word of this block */
+} limg_hip_stream_block; /* 56 bytes */
+
+/* Worst-case stream size for an image (what `capacity` must be at least); 0 if the image is too large for 32-bit payload offsets. */
+size_t limg_hip_stream_bound(size_t sizeX, size_t sizeY);
+
+/* "limg_encode": the encode hot path (same parameters as limg_hip_encode3d_device) followed by the stream packer.  DEVICE pointers,
+ * asynchronous on `stream`; the stream's size lands in its header (`totalBytes`).  pBytes (host, may be NULL) receives it too,
+ * which makes the call wait for the stream. */
+limg_hip_result limg_hip_encode_stream_device(limg_hip_context *pCtx, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, uint8_t *pStream,
+                                              size_t capacity, size_t *pBytes, uint32_t errorFactor, int poolThreads, int fastBitCrushing, void *stream);
+/* "limg_decode" (a16 for every block): DEVICE pointers, asynchronous.  sizeX / sizeY must match the header (the kernel checks and
+ * reports a mismatch or inconsistent offsets through limg_hip_check_device_status as limg_hip_error_InvalidParameter). */
+limg_hip_result limg_hip_decode_stream_device(limg_hip_context *pCtx, const uint8_t *pStream, size_t streamBytes, uint32_t *pOut, size_t sizeX, size_t sizeY,
+                                              void *stream);
+/* HOST-pointer variants (blocking). */
+limg_hip_result limg_hip_encode_stream(limg_hip_context *pCtx, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, uint8_t *pStream, size_t capacity,
+                                       size_t *pBytes, uint32_t errorFactor, int poolThreads, int fastBitCrushing);
+limg_hip_result limg_hip_decode_stream(limg_hip_context *pCtx, const uint8_t *pStream, size_t streamBytes, uint32_t *pOut, size_t outPixels);
+/* Host-only: validates a header (first 64 bytes suffice) and reports the image shape. */
+limg_hip_result limg_hip_stream_info(const uint8_t *pStream, size_t streamBytes, size_t *pSizeX, size_t *pSizeY, int *pHasAlpha, size_t *pTotalBytes);
+
 /* Introspection for the bench: names and launch count of the kernels one encode enqueues, bytes of context-owned HBM. */
 size_t limg_hip_context_device_bytes(const limg_hip_context *pCtx);
 const char *limg_hip_version(void);

@@ -22,7 +22,14 @@ ABI_SYMBOLS = (
     "limg_hip_encode3d_device", "limg_hip_compare", "limg_hip_compare_device", "limg_hip_synth_random_gradient_device",
     "limg_hip_synth_photo_noise_device", "limg_hip_context_device_bytes", "limg_hip_version", "limg_hip_profile_begin", "limg_hip_profile_end",
     "limg_hip_host_noise_table", "limg_hip_host_chain_call", "limg_hip_host_partition", "limg_hip_check_device_status",
+    "limg_hip_stream_bound", "limg_hip_encode_stream_device", "limg_hip_decode_stream_device", "limg_hip_encode_stream", "limg_hip_decode_stream",
+    "limg_hip_stream_info",
 )
+
+STREAM_HEADER_DTYPE = np.dtype([("magic", "<u4"), ("version", "<u4"), ("sizeX", "<u4"), ("sizeY", "<u4"), ("channels", "<u4"), ("errorFactor", "<u4"),
+                                ("blocksX", "<u4"), ("blocksY", "<u4"), ("payloadWords", "<u8"), ("totalBytes", "<u8"), ("flags", "<u4"), ("reserved", "<u4", 3)])
+STREAM_BLOCK_DTYPE = np.dtype([("dirA_min", "<i2", 4), ("dirA_max", "<i2", 4), ("dirB_offset", "<i2", 4), ("dirB_mag", "<i2", 4), ("dirC_offset", "<i2", 4),
+                               ("dirC_mag", "<i2", 4), ("shift", "<u4"), ("payloadWord", "<u4")])
 
 RECORD_DTYPE = np.dtype([("avg", "<f4", 4), ("dirA_min", "<i2", 4), ("dirA_max", "<i2", 4), ("dirB_offset", "<i2", 4),
                          ("dirB_mag", "<i2", 4), ("dirC_offset", "<i2", 4), ("dirC_mag", "<i2", 4)])
@@ -91,6 +98,19 @@ def load_library(path=None):
     L.limg_hip_host_partition.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.limg_hip_context_device_bytes.restype = C.c_size_t
     L.limg_hip_context_device_bytes.argtypes = [C.c_void_p]
+    L.limg_hip_stream_bound.restype = C.c_size_t
+    L.limg_hip_stream_bound.argtypes = [C.c_size_t, C.c_size_t]
+    L.limg_hip_encode_stream_device.restype = C.c_int
+    L.limg_hip_encode_stream_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_uint32, C.c_int, C.c_int,
+                                                C.c_void_p]
+    L.limg_hip_decode_stream_device.restype = C.c_int
+    L.limg_hip_decode_stream_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+    L.limg_hip_encode_stream.restype = C.c_int
+    L.limg_hip_encode_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_uint32, C.c_int, C.c_int]
+    L.limg_hip_decode_stream.restype = C.c_int
+    L.limg_hip_decode_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.limg_hip_stream_info.restype = C.c_int
+    L.limg_hip_stream_info.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
     return L
 
 
@@ -101,6 +121,15 @@ def _check(r, what):
 
 def _np_ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def stream_info(stream, lib=None):
+    """(sizeX, sizeY, hasAlpha, totalBytes) of a stream held in a numpy uint8 array (host-only, no GPU touched)."""
+    lib = lib or load_library()
+    stream = np.ascontiguousarray(stream, dtype=np.uint8)
+    sx, sy, tb, ha = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_int(0)
+    _check(lib.limg_hip_stream_info(_np_ptr(stream), stream.size, C.byref(sx), C.byref(sy), C.byref(ha), C.byref(tb)), "limg_hip_stream_info")
+    return sx.value, sy.value, bool(ha.value), tb.value
 
 
 class LimgHip:
@@ -198,6 +227,47 @@ class LimgHip:
             _check(self.lib.limg_hip_synth_photo_noise_device(C.c_void_p(out.data_ptr()), w, h, seed, y0, self._stream()), "synth")
         else:
             raise ValueError(kind)
+        return out
+
+    # ---- compact stream ("limg_encode" / "limg_decode") ----------------------------------------------------------------------------
+    def stream_bound(self, w, h):
+        return self.lib.limg_hip_stream_bound(w, h)
+
+    def encode_stream(self, img, has_alpha, error_factor=100, pool_threads=0, fast=True):
+        """host uint32 image -> stream bytes (numpy uint8)"""
+        img = np.ascontiguousarray(img, dtype=np.uint32)
+        h, w = img.shape
+        cap = self.stream_bound(w, h)
+        out = np.zeros(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        _check(self.lib.limg_hip_encode_stream(self.ctx, _np_ptr(img), w, h, int(has_alpha), _np_ptr(out), cap, C.byref(n), error_factor, pool_threads, int(fast)), "limg_hip_encode_stream")
+        return out[:n.value].copy()
+
+    def decode_stream(self, stream):
+        stream = np.ascontiguousarray(stream, dtype=np.uint8)
+        w, h, _, _ = stream_info(stream, self.lib)
+        out = np.zeros((h, w), dtype=np.uint32)
+        _check(self.lib.limg_hip_decode_stream(self.ctx, _np_ptr(stream), stream.size, _np_ptr(out), out.size), "limg_hip_decode_stream")
+        return out
+
+    def encode_stream_device(self, img, has_alpha, out=None, error_factor=100, pool_threads=0, fast=True, want_size=True):
+        """img: torch int32 CUDA (h, w) -> (torch uint8 CUDA stream buffer of worst-case size, bytes used or None)"""
+        import torch
+        h, w = img.shape
+        cap = self.stream_bound(w, h)
+        if out is None:
+            out = torch.empty(cap, dtype=torch.uint8, device=img.device)
+        n = C.c_size_t(0)
+        _check(self.lib.limg_hip_encode_stream_device(self.ctx, C.c_void_p(img.data_ptr()), w, h, int(has_alpha), C.c_void_p(out.data_ptr()), out.numel(),
+                                                      C.byref(n) if want_size else None, error_factor, pool_threads, int(fast), self._stream()), "limg_hip_encode_stream_device")
+        return out, (n.value if want_size else None)
+
+    def decode_stream_device(self, stream, nbytes, w, h, out=None):
+        import torch
+        if out is None:
+            out = torch.empty((h, w), dtype=torch.int32, device=stream.device)
+        _check(self.lib.limg_hip_decode_stream_device(self.ctx, C.c_void_p(stream.data_ptr()), int(nbytes), C.c_void_p(out.data_ptr()), w, h, self._stream()),
+               "limg_hip_decode_stream_device")
         return out
 
     def check(self):

@@ -58,6 +58,7 @@ struct limg_hip_context
   DevBuf lookback;                               // fused path: ticket + timeout flag (16 B) then one 8-byte descriptor per work strip
   DevBuf in, planes;                             // staging for the host-pointer entry points
   DevBuf cmp;                                    // 8-byte accumulator of limg_hip_compare
+  DevBuf streamFac, streamTiles, streamStatus, streamBuf; // stream packer: 3 factor planes, per-tile payload words; decode status word; host-entry staging
   // optional per-kernel timing (bench): 4 events per encode, recorded on the caller's stream, read back in one go
   int persistentWorkgroups = 1024; // 4 per CU (LDS-limited), set from the device's CU count at init
   bool forceSplit = false; // options: run the three-kernel path even where the fused kernel applies (A/B, tests)
@@ -130,7 +131,7 @@ namespace
   }
 
   limg_hip_result encode_device(limg_hip_context *c, const uint32_t *dIn, size_t sizeX, size_t sizeY, int hasAlpha, const limg_hip_encode3d_info *dInfo,
-                                const limg_hip_compact_out *compact, uint32_t errorFactor, int poolThreads, int fast, hipStream_t stream)
+                                const limg_hip_compact_out *compact, uint32_t errorFactor, int poolThreads, int fast, hipStream_t stream, bool streamRaw = false)
   {
     if (!c || !dIn) return limg_hip_error_ArgumentNull;
     if (sizeX == 0 || sizeY == 0 || sizeX > 0x7FFFFFF8ull || sizeY > 0x7FFFFFF8ull) return limg_hip_error_InvalidParameter;
@@ -179,6 +180,7 @@ namespace
     p.stripCalls = (uint32_t *)c->stripCalls.p; p.stripBase = (uint32_t *)c->stripBase.p;
     p.storePlanes = dInfo != nullptr;
     p.fullPlanes = fullPlanes;
+    p.streamRaw = streamRaw && !fullPlanes;
     if (dInfo) p.info = *dInfo;
     const int channels = hasAlpha ? 4 : 3;
     const bool ragged = (sizeX % kBlock) != 0 || (sizeY % kBlock) != 0;
@@ -302,7 +304,8 @@ extern "C"
     limg_hip_context *c = *ppCtx;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = { &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->lookback, &c->park, &c->in, &c->planes, &c->cmp };
+    DevBuf *bufs[] = { &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->lookback, &c->park, &c->in, &c->planes, &c->cmp,
+                       &c->streamFac, &c->streamTiles, &c->streamStatus, &c->streamBuf };
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     delete c;
@@ -332,6 +335,17 @@ extern "C"
       {
         fprintf(stderr, "limg_hip: look-back timeout in the fused encode kernel\n");
         return limg_hip_error_Generic;
+      }
+    }
+    if (c->streamStatus.p)
+    {
+      uint32_t word = 0;
+      HIP_TRY(hipMemcpy(&word, c->streamStatus.p, 4, hipMemcpyDeviceToHost));
+      if (word != 0)
+      {
+        HIP_TRY(hipMemset(c->streamStatus.p, 0, 4));
+        fprintf(stderr, "limg_hip: stream refused by the decode kernel (%s)\n", (word & 1u) ? "header mismatch" : "inconsistent payload offsets");
+        return limg_hip_error_InvalidParameter;
       }
     }
     return limg_hip_success;
@@ -389,7 +403,8 @@ extern "C"
   size_t limg_hip_context_device_bytes(const limg_hip_context *c)
   {
     if (!c) return 0;
-    return c->records.cap + c->shifts.cap + c->stripCalls.cap + c->stripBase.cap + c->noise.cap + c->noiseDyn.cap + c->lookback.cap + c->park.cap + c->in.cap + c->planes.cap + c->cmp.cap;
+    return c->records.cap + c->shifts.cap + c->stripCalls.cap + c->stripBase.cap + c->noise.cap + c->noiseDyn.cap + c->lookback.cap + c->park.cap + c->in.cap + c->planes.cap + c->cmp.cap +
+           c->streamFac.cap + c->streamTiles.cap + c->streamStatus.cap + c->streamBuf.cap;
   }
 
   limg_hip_result limg_hip_encode3d_device(limg_hip_context *c, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, const limg_hip_encode3d_info *pInfo,
@@ -484,6 +499,144 @@ extern "C"
     if (!pOut) return limg_hip_error_ArgumentNull;
     launch_synth_photo_noise(pOut, (uint32_t)width, (uint32_t)height, seed, (uint32_t)y0, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
+    return limg_hip_success;
+  }
+  // ---- compact stream --------------------------------------------------------------------------------------------------------
+  size_t limg_hip_stream_bound(size_t sizeX, size_t sizeY)
+  {
+    if (sizeX == 0 || sizeY == 0 || sizeX > 0x7FFFFFF8ull || sizeY > 0x7FFFFFF8ull) return 0;
+    const size_t blocks = ((sizeX + kBlock - 1) / kBlock) * ((sizeY + kBlock - 1) / kBlock);
+    if (blocks * 24 > 0xFFFFFFFFull) return 0; // entry.payloadWord is 32 bits
+    return sizeof(limg_hip_stream_header) + blocks * sizeof(limg_hip_stream_block) + blocks * 192;
+  }
+
+  limg_hip_result limg_hip_encode_stream_device(limg_hip_context *c, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, uint8_t *pStream, size_t capacity,
+                                                size_t *pBytes, uint32_t errorFactor, int poolThreads, int fastBitCrushing, void *stream)
+  {
+    if (!c || !pIn || !pStream) return limg_hip_error_ArgumentNull;
+    const size_t bound = limg_hip_stream_bound(sizeX, sizeY);
+    if (bound == 0) return limg_hip_error_InvalidParameter;
+    if (capacity < bound) return limg_hip_error_OutOfBounds;
+    if (((uintptr_t)pStream & 15u) != 0) return limg_hip_error_InvalidParameter;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t px = sizeX * sizeY, planeStride = (px + 255) & ~(size_t)255;
+    const size_t blocksX = (sizeX + kBlock - 1) / kBlock, blocksY = (sizeY + kBlock - 1) / kBlock, blocks = blocksX * blocksY;
+    const size_t tiles = (blocks + 255) / 256;
+    limg_hip_result r;
+    if ((r = c->streamFac.ensure(planeStride * 3)) != limg_hip_success) return r;
+    if ((r = c->streamTiles.ensure(tiles * 4)) != limg_hip_success) return r;
+    if ((r = c->records.ensure(blocks * sizeof(limg_hip_block_record))) != limg_hip_success) return r;
+    if ((r = c->shifts.ensure(blocks * 4)) != limg_hip_success) return r;
+    limg_hip_encode3d_info info;
+    memset(&info, 0, sizeof(info));
+    info.pFactorsA = (uint8_t *)c->streamFac.p; info.pFactorsB = info.pFactorsA + planeStride; info.pFactorsC = info.pFactorsB + planeStride;
+    limg_hip_compact_out comp = { (limg_hip_block_record *)c->records.p, (uint32_t *)c->shifts.p };
+    if ((r = encode_device(c, pIn, sizeX, sizeY, hasAlpha, &info, &comp, errorFactor, poolThreads, fastBitCrushing, s, true)) != limg_hip_success) return r;
+
+    StreamParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.sizeX = (uint32_t)sizeX; sp.sizeY = (uint32_t)sizeY; sp.blocksX = (uint32_t)blocksX; sp.blocksY = (uint32_t)blocksY;
+    sp.nBlocks = (uint32_t)blocks; sp.nTiles = (uint32_t)tiles; sp.channels = hasAlpha ? 4 : 3; sp.errorFactor = errorFactor;
+    sp.flags = (fastBitCrushing ? 1u : 0u) | (c->opt.dither_pcg ? 2u : 0u);
+    sp.fac[0] = info.pFactorsA; sp.fac[1] = info.pFactorsB; sp.fac[2] = info.pFactorsC;
+    sp.records = comp.pRecords; sp.shifts = comp.pShifts;
+    sp.stream = pStream; sp.tileBase = (uint32_t *)c->streamTiles.p;
+    mark(c, s);
+    launch_stream_pack(sp, s);
+    mark(c, s); mark(c, s); mark(c, s);
+    HIP_TRY(hipGetLastError());
+    if (pBytes)
+    {
+      limg_hip_stream_header h;
+      HIP_TRY(hipMemcpyAsync(&h, pStream, sizeof(h), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      *pBytes = (size_t)h.totalBytes;
+    }
+    return limg_hip_success;
+  }
+
+  limg_hip_result limg_hip_decode_stream_device(limg_hip_context *c, const uint8_t *pStream, size_t streamBytes, uint32_t *pOut, size_t sizeX, size_t sizeY, void *stream)
+  {
+    if (!c || !pStream || !pOut) return limg_hip_error_ArgumentNull;
+    if (limg_hip_stream_bound(sizeX, sizeY) == 0 || streamBytes < sizeof(limg_hip_stream_header)) return limg_hip_error_InvalidParameter;
+    if (((uintptr_t)pStream & 15u) != 0 || ((uintptr_t)pOut & 15u) != 0) return limg_hip_error_InvalidParameter;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    limg_hip_result r;
+    if (!c->streamStatus.p)
+    {
+      if ((r = c->streamStatus.ensure(8)) != limg_hip_success) return r;
+      HIP_TRY(hipMemsetAsync(c->streamStatus.p, 0, 8, s));
+    }
+    DecodeParams dp;
+    memset(&dp, 0, sizeof(dp));
+    dp.sizeX = (uint32_t)sizeX; dp.sizeY = (uint32_t)sizeY;
+    dp.blocksX = (uint32_t)((sizeX + kBlock - 1) / kBlock); dp.blocksY = (uint32_t)((sizeY + kBlock - 1) / kBlock);
+    dp.nBlocks = dp.blocksX * dp.blocksY;
+    if (streamBytes < sizeof(limg_hip_stream_header) + (size_t)dp.nBlocks * sizeof(limg_hip_stream_block)) return limg_hip_error_OutOfBounds;
+    dp.stream = pStream; dp.streamBytes = streamBytes; dp.out = pOut; dp.status = (uint32_t *)c->streamStatus.p;
+    mark(c, s);
+    launch_stream_decode(dp, s);
+    mark(c, s); mark(c, s); mark(c, s);
+    HIP_TRY(hipGetLastError());
+    return limg_hip_success;
+  }
+
+  limg_hip_result limg_hip_stream_info(const uint8_t *pStream, size_t streamBytes, size_t *pSizeX, size_t *pSizeY, int *pHasAlpha, size_t *pTotalBytes)
+  {
+    if (!pStream) return limg_hip_error_ArgumentNull;
+    if (streamBytes < sizeof(limg_hip_stream_header)) return limg_hip_error_OutOfBounds;
+    limg_hip_stream_header h;
+    memcpy(&h, pStream, sizeof(h));
+    if (h.magic != LIMG_HIP_STREAM_MAGIC || h.version != LIMG_HIP_STREAM_VERSION || (h.channels != 3 && h.channels != 4)) return limg_hip_error_InvalidParameter;
+    if (limg_hip_stream_bound(h.sizeX, h.sizeY) == 0) return limg_hip_error_InvalidParameter;
+    const uint64_t bx = ((uint64_t)h.sizeX + kBlock - 1) / kBlock, by = ((uint64_t)h.sizeY + kBlock - 1) / kBlock;
+    if (h.blocksX != bx || h.blocksY != by) return limg_hip_error_InvalidParameter;
+    if (h.payloadWords > bx * by * 24 || h.totalBytes != sizeof(h) + bx * by * sizeof(limg_hip_stream_block) + h.payloadWords * 8) return limg_hip_error_InvalidParameter;
+    if (pSizeX) *pSizeX = h.sizeX;
+    if (pSizeY) *pSizeY = h.sizeY;
+    if (pHasAlpha) *pHasAlpha = h.channels == 4;
+    if (pTotalBytes) *pTotalBytes = (size_t)h.totalBytes;
+    return limg_hip_success;
+  }
+
+  limg_hip_result limg_hip_encode_stream(limg_hip_context *c, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, uint8_t *pStream, size_t capacity, size_t *pBytes,
+                                         uint32_t errorFactor, int poolThreads, int fastBitCrushing)
+  {
+    if (!c || !pIn || !pStream || !pBytes) return limg_hip_error_ArgumentNull;
+    const size_t bound = limg_hip_stream_bound(sizeX, sizeY);
+    if (bound == 0) return limg_hip_error_InvalidParameter;
+    HIP_TRY(hipSetDevice(c->device));
+    limg_hip_result r;
+    const size_t px = sizeX * sizeY;
+    if ((r = c->in.ensure(px * 4)) != limg_hip_success) return r;
+    if ((r = c->streamBuf.ensure(bound)) != limg_hip_success) return r;
+    HIP_TRY(hipMemcpy(c->in.p, pIn, px * 4, hipMemcpyHostToDevice));
+    size_t bytes = 0;
+    if ((r = limg_hip_encode_stream_device(c, (const uint32_t *)c->in.p, sizeX, sizeY, hasAlpha, (uint8_t *)c->streamBuf.p, bound, &bytes, errorFactor, poolThreads,
+                                           fastBitCrushing, nullptr)) != limg_hip_success) return r;
+    if ((r = limg_hip_check_device_status(c)) != limg_hip_success) return r;
+    *pBytes = bytes;
+    if (bytes > capacity) return limg_hip_error_OutOfBounds; // *pBytes tells the caller what it takes
+    HIP_TRY(hipMemcpy(pStream, c->streamBuf.p, bytes, hipMemcpyDeviceToHost));
+    return limg_hip_success;
+  }
+
+  limg_hip_result limg_hip_decode_stream(limg_hip_context *c, const uint8_t *pStream, size_t streamBytes, uint32_t *pOut, size_t outPixels)
+  {
+    if (!c || !pStream || !pOut) return limg_hip_error_ArgumentNull;
+    size_t sizeX = 0, sizeY = 0, total = 0;
+    limg_hip_result r;
+    if ((r = limg_hip_stream_info(pStream, streamBytes, &sizeX, &sizeY, nullptr, &total)) != limg_hip_success) return r;
+    if (total > streamBytes || sizeX * sizeY > outPixels) return limg_hip_error_OutOfBounds;
+    HIP_TRY(hipSetDevice(c->device));
+    if ((r = c->streamBuf.ensure(total + 16)) != limg_hip_success) return r;
+    if ((r = c->planes.ensure(sizeX * sizeY * 4)) != limg_hip_success) return r;
+    HIP_TRY(hipMemcpy(c->streamBuf.p, pStream, total, hipMemcpyHostToDevice));
+    if ((r = limg_hip_decode_stream_device(c, (const uint8_t *)c->streamBuf.p, total, (uint32_t *)c->planes.p, sizeX, sizeY, nullptr)) != limg_hip_success) return r;
+    if ((r = limg_hip_check_device_status(c)) != limg_hip_success) return r;
+    HIP_TRY(hipMemcpy(pOut, c->planes.p, sizeX * sizeY * 4, hipMemcpyDeviceToHost));
     return limg_hip_success;
   }
 }

@@ -41,12 +41,36 @@ namespace limg_hip
     uint32_t *ticket;   // [0] = next strip id, [1] = look-back timeout flag
     uint8_t *park;      // persistent kernel: per workgroup two 8 KiB slots holding a strip's parked results between its E and F steps
     int32_t compactOut; // persistent kernel: also write records / shift words to the raster-order arrays
+    int32_t streamRaw;  // compact mode only: factors with shift 8 store their raw byte instead of 0 (input of the stream packer)
+  };
+
+  // stream pack (limg_hip_stream.hip): from the compact outputs of an encode (factor planes, records, shift words)
+  struct StreamParams
+  {
+    uint32_t sizeX, sizeY, blocksX, blocksY, nBlocks, nTiles, channels, errorFactor, flags;
+    const uint8_t *fac[3];
+    const limg_hip_block_record *records;
+    const uint32_t *shifts;
+    uint8_t *stream;
+    uint32_t *tileBase; // per tile of 256 blocks: payload words, then (after the scan) the tile's first payload word
+  };
+
+  struct DecodeParams
+  {
+    uint32_t sizeX, sizeY, blocksX, blocksY, nBlocks;
+    const uint8_t *stream;
+    unsigned long long streamBytes;
+    uint32_t *out;
+    uint32_t *status; // bit 0: header mismatch, bit 1: inconsistent payload offsets
   };
 
   void launch_fit_search(const EncodeParams &p, int channels, hipStream_t s);
   void launch_encode_persistent(const EncodeParams &p, int channels, int workgroups, hipStream_t s);
   void launch_strip_scan(const EncodeParams &p, hipStream_t s);
   void launch_dither_store(const EncodeParams &p, int channels, hipStream_t s);
+
+  void launch_stream_pack(const StreamParams &p, hipStream_t s);
+  void launch_stream_decode(const DecodeParams &p, hipStream_t s);
 
   void launch_synth_random_gradient(uint32_t *out, uint32_t w, uint32_t h, uint64_t seed, int opaque, uint32_t y0, hipStream_t s);
   void launch_synth_photo_noise(uint32_t *out, uint32_t w, uint32_t h, uint64_t seed, uint32_t y0, hipStream_t s);

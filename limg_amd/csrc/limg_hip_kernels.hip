@@ -562,7 +562,7 @@ namespace limg_hip
           if (active)
           {
 #pragma unroll
-            for (int k = 0; k < 3; k++) out[k * 2048 + o] = (uint8_t)(f[k] << shift[k]);
+            for (int k = 0; k < 3; k++) out[k * 2048 + o] = (uint8_t)(f[k] << ((p.streamRaw && shift[k] == 8) ? 0u : shift[k]));
           }
           continue;
         }

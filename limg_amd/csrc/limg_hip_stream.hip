@@ -1,0 +1,394 @@
+// limg_hip_stream.hip -- the compact "LMG3" stream: pack (after a compact-mode encode) and decode kernels.
+//
+// Upstream has no serialised format and no limg_encode()/limg_decode(): `limg_encode3d_test` hands back
+// debug planes.  This container holds exactly what the reference's decoder (a16, src/limg_decode.h:36-236) consumes -- the six
+// int16 vectors of the block record, the shift triple and the crushed factor values at (8 - shift) bits each -- so that
+//   decode_stream(encode_stream(image)) == the reference's pDecoded, bit for bit.
+// One escape keeps that exact: with 4 channels the reference zeroes only the RGB normals of a factor whose shift is 8
+// (src/limg_bit_crush_simd.h:589-609, src/limg_decode.h:150-170) and then multiplies the *raw* factor byte into the alpha lane
+// (SURVEY.md 0.7); where that alpha normal is non-zero the raw byte is kept at 8 bits and flagged in the entry.
+//
+// Layout (little endian, every section 8-byte aligned):
+//   limg_hip_stream_header (64 B) | limg_hip_stream_block[blocksX*blocksY] (56 B each, raster order) | payload words (8 B each)
+// Payload of one block, at entry.payloadWord: factor A field, then B, then C; a field of b bits/pixel takes b words and stores
+// pixel (row r, column x) of the 8x8 grid at bit (r*8 + x) * b -- i.e. every block row is exactly b bytes.  Pixels outside the
+// image (partial edge blocks) are stored as 0.
+//
+// Work mapping: tile = 256 consecutive blocks (raster order) per 256-thread workgroup.  Thread t prepares block t's entry; then
+// each wave walks its 64 blocks in groups of 8 with lane = (block j = lane & 7, block row r = lane >> 3), so a lane owns the
+// 8 pixels of one block row: 8 B of each factor plane, 32 B of the decoded image, b bytes of each payload field.
+#include "limg_hip_internal.h"
+
+namespace limg_hip
+{
+  namespace
+  {
+    constexpr int kTile = 256;
+    constexpr int kEntry = 56;
+    constexpr int kGroupBytes = 8 * 192; // payload of 8 blocks, worst case
+
+    __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+    __device__ __forceinline__ int mad_i24(int a, int b, int c) { int r; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+    __device__ __forceinline__ void wave_lds_fence()
+    {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    // (1 << s) + bias(s), src/limg_bit_crush_simd.h:611-619 / src/limg_decode.h:172-178
+    __device__ __forceinline__ uint32_t shift_mul(uint32_t s)
+    {
+      return s < 4 ? (1u << s) : (s == 4 ? 17u : (s == 5 ? 36u : (s == 6 ? 85u : (s == 7 ? 255u : 256u))));
+    }
+
+    // bits per pixel of the three factor fields + raw-escape mask: bA | bB << 8 | bC << 16 | rawMask << 24.
+    // mn3 / mx3: lane 3 (alpha) of dir{A,B,C}_{min|offset} / _{max|mag}.
+    __device__ __forceinline__ uint32_t field_bits(uint32_t shiftWord, const int mn3[3], const int mx3[3], int channels)
+    {
+      uint32_t r = 0;
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+      {
+        const uint32_t s = (shiftWord >> (8 * k)) & 0xFF;
+        uint32_t b = s >= 8 ? 0u : 8u - s;
+        if (s >= 8 && channels == 4 && mn3[k] != mx3[k]) { b = 8; r |= 1u << (24 + k); }
+        r |= b << (8 * k);
+      }
+      return r;
+    }
+
+    __device__ __forceinline__ uint32_t words_of(uint32_t bits) { return (bits & 0xFF) + ((bits >> 8) & 0xFF) + ((bits >> 16) & 0xFF); }
+
+    // ---- pack ------------------------------------------------------------------------------------------------------------
+
+    // per tile: payload words
+    __global__ __launch_bounds__(kTile) void k_stream_count(const StreamParams p)
+    {
+      __shared__ uint32_t sWave[4];
+      const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+      const uint32_t g = blockIdx.x * kTile + tid;
+      uint32_t words = 0;
+      if (g < p.nBlocks)
+      {
+        const limg_hip_block_record &rec = p.records[g];
+        const int mn3[3] = { rec.dirA_min[3], rec.dirB_offset[3], rec.dirC_offset[3] }, mx3[3] = { rec.dirA_max[3], rec.dirB_mag[3], rec.dirC_mag[3] };
+        words = words_of(field_bits(p.shifts[g] & 0xFFFFFFu, mn3, mx3, (int)p.channels));
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) words += (uint32_t)__shfl_xor((int)words, off, 64);
+      if (lane == 0) sWave[wave] = words;
+      __syncthreads();
+      if (tid == 0) p.tileBase[blockIdx.x] = sWave[0] + sWave[1] + sWave[2] + sWave[3];
+    }
+
+    // exclusive scan of the tile totals in place (one workgroup) + the header
+    __global__ __launch_bounds__(1024) void k_stream_scan(const StreamParams p)
+    {
+      __shared__ unsigned long long sWave[16];
+      __shared__ unsigned long long sCarry;
+      const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+      if (tid == 0) sCarry = 0;
+      __syncthreads();
+      for (uint32_t base = 0; base < p.nTiles; base += 1024)
+      {
+        const uint32_t i = base + tid;
+        const unsigned long long v = i < p.nTiles ? p.tileBase[i] : 0u;
+        unsigned long long incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1)
+        {
+          const unsigned long long up = (unsigned long long)__shfl_up((long long)incl, off, 64);
+          if (lane >= off) incl += up;
+        }
+        if (lane == 63) sWave[wave] = incl;
+        __syncthreads();
+        unsigned long long pre = sCarry;
+        for (int w = 0; w < wave; w++) pre += sWave[w];
+        // entry.payloadWord is 32 bits: the host refuses images whose worst-case payload would not fit (limg_hip_stream_bound)
+        if (i < p.nTiles) p.tileBase[i] = (uint32_t)(pre + incl - v);
+        __syncthreads();
+        if (tid == 1023) sCarry = pre + incl;
+        __syncthreads();
+      }
+      if (tid == 0)
+      {
+        limg_hip_stream_header h;
+        h.magic = LIMG_HIP_STREAM_MAGIC; h.version = LIMG_HIP_STREAM_VERSION;
+        h.sizeX = p.sizeX; h.sizeY = p.sizeY; h.channels = p.channels; h.errorFactor = p.errorFactor;
+        h.blocksX = p.blocksX; h.blocksY = p.blocksY;
+        h.payloadWords = sCarry;
+        h.totalBytes = sizeof(limg_hip_stream_header) + (unsigned long long)p.nBlocks * kEntry + sCarry * 8ull;
+        h.flags = p.flags; h.reserved[0] = h.reserved[1] = h.reserved[2] = 0;
+        *reinterpret_cast<limg_hip_stream_header *>(p.stream) = h;
+      }
+    }
+
+    __global__ __launch_bounds__(kTile) void k_stream_pack(const StreamParams p)
+    {
+      __shared__ uint32_t sBits[kTile], sOff[kTile], sWave[4];
+      __shared__ __align__(16) uint32_t sEntry[kTile * kEntry / 4];
+      __shared__ __align__(16) uint8_t sStage[4][kGroupBytes];
+      const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+      const uint32_t tile = blockIdx.x, g = tile * kTile + tid;
+
+      uint32_t bits = 0, words = 0;
+      if (g < p.nBlocks)
+      {
+        const uint4 *rp = reinterpret_cast<const uint4 *>(p.records + g) + 1; // skip avg[4]
+        const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2];                        // {dirA_min, dirA_max}, {dirB_offset, dirB_mag}, {dirC_offset, dirC_mag}
+        const int mn3[3] = { (int)(int16_t)(r0.y >> 16), (int)(int16_t)(r1.y >> 16), (int)(int16_t)(r2.y >> 16) };
+        const int mx3[3] = { (int)(int16_t)(r0.w >> 16), (int)(int16_t)(r1.w >> 16), (int)(int16_t)(r2.w >> 16) };
+        const uint32_t sw = p.shifts[g] & 0xFFFFFFu;
+        bits = field_bits(sw, mn3, mx3, (int)p.channels);
+        words = words_of(bits);
+        uint32_t *e = sEntry + tid * (kEntry / 4);
+        e[0] = r0.x; e[1] = r0.y; e[2] = r0.z; e[3] = r0.w; e[4] = r1.x; e[5] = r1.y; e[6] = r1.z; e[7] = r1.w;
+        e[8] = r2.x; e[9] = r2.y; e[10] = r2.z; e[11] = r2.w;
+        e[12] = sw | (bits & 0xFF000000u);
+      }
+      uint32_t incl = words;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1)
+      {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+        if (lane >= off) incl += up;
+      }
+      if (lane == 63) sWave[wave] = incl;
+      __syncthreads();
+      uint32_t off = p.tileBase[tile] + incl - words;
+      for (int w = 0; w < wave; w++) off += sWave[w];
+      sBits[tid] = bits; sOff[tid] = off;
+      if (g < p.nBlocks) sEntry[tid * (kEntry / 4) + 13] = off;
+      __syncthreads();
+
+      const uint32_t inTile = min((uint32_t)kTile, p.nBlocks - tile * kTile);
+      {
+        uint2 *dst = reinterpret_cast<uint2 *>(p.stream + sizeof(limg_hip_stream_header) + (size_t)tile * kTile * kEntry);
+        const uint2 *src = reinterpret_cast<const uint2 *>(sEntry);
+        for (uint32_t i = tid; i < inTile * (kEntry / 8); i += kTile) dst[i] = src[i];
+      }
+
+      uint2 *payload = reinterpret_cast<uint2 *>(p.stream + sizeof(limg_hip_stream_header) + (size_t)p.nBlocks * kEntry);
+      const int j = lane & 7, r = lane >> 3;
+      const bool aligned = (p.sizeX & 7u) == 0;
+      uint8_t *stage = sStage[wave];
+      for (int grp = 0; grp < 8; grp++)
+      {
+        const uint32_t jb = wave * 64 + grp * 8;
+        if (jb >= inTile) break; // wave-uniform
+        const uint32_t nValid = min(8u, inTile - jb);
+        const uint32_t t = jb + j;
+        const bool valid = (uint32_t)j < nValid;
+        const uint32_t bw = valid ? sBits[t] : 0u, myOff = valid ? sOff[t] : 0u;
+        const uint32_t off0 = sOff[jb];
+        const uint32_t endWord = (uint32_t)__shfl((int)(myOff + words_of(bw)), (int)nValid - 1, 64);
+        if (valid)
+        {
+          const uint32_t gg = tile * kTile + t, by = gg / p.blocksX, bx = gg - by * p.blocksX;
+          const uint32_t y = by * 8 + r, x0 = bx * 8;
+          uint32_t fieldByte = (myOff - off0) * 8;
+#pragma unroll
+          for (int k = 0; k < 3; k++)
+          {
+            const uint32_t b = (bw >> (8 * k)) & 0xFF;
+            if (b == 0) continue;
+            uint2 raw = make_uint2(0, 0);
+            if (y < p.sizeY)
+            {
+              const uint8_t *src = p.fac[k] + (size_t)y * p.sizeX + x0;
+              if (aligned) raw = *reinterpret_cast<const uint2 *>(src);
+              else
+              {
+                const uint32_t nx = min(8u, p.sizeX - x0);
+                unsigned long long acc = 0;
+                for (uint32_t i = 0; i < nx; i++) acc |= (unsigned long long)src[i] << (8 * i);
+                raw = make_uint2((uint32_t)acc, (uint32_t)(acc >> 32));
+              }
+            }
+            // the planes hold (v << shift); raw-escaped fields hold the raw byte (stream mode of the encode kernel)
+            const uint32_t sh = 8 - b;
+            const unsigned long long bytes = ((unsigned long long)raw.y << 32) | raw.x;
+            unsigned long long packed = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) packed |= (unsigned long long)(((uint32_t)(bytes >> (8 * i)) & 0xFFu) >> sh) << (i * b);
+            uint8_t *dst = stage + fieldByte + r * b;
+            for (uint32_t i = 0; i < b; i++) dst[i] = (uint8_t)(packed >> (8 * i));
+            fieldByte += b * 8;
+          }
+        }
+        wave_lds_fence();
+        {
+          const uint2 *src = reinterpret_cast<const uint2 *>(stage);
+          const uint32_t n = endWord - off0;
+          for (uint32_t i = lane; i < n; i += 64) payload[(size_t)off0 + i] = src[i];
+        }
+        wave_lds_fence();
+      }
+    }
+
+    // ---- decode ----------------------------------------------------------------------------------------------------------
+
+    __global__ __launch_bounds__(kTile) void k_stream_decode(const DecodeParams p)
+    {
+      __shared__ __align__(16) int sNm[kTile][24];
+      __shared__ uint32_t sBits[kTile], sOff[kTile], sMul[kTile];
+      __shared__ __align__(16) uint8_t sStage[4][kGroupBytes + 16];
+      const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+      const uint32_t tile = blockIdx.x, g = tile * kTile + tid;
+
+      // every workgroup validates the header it is about to trust (scalar loads; a mismatch raises the context's status word)
+      const limg_hip_stream_header *h = reinterpret_cast<const limg_hip_stream_header *>(p.stream);
+      const unsigned long long payloadWords = h->payloadWords;
+      const bool ok = h->magic == LIMG_HIP_STREAM_MAGIC && h->version == LIMG_HIP_STREAM_VERSION && h->sizeX == p.sizeX && h->sizeY == p.sizeY &&
+                      h->blocksX == p.blocksX && h->blocksY == p.blocksY && (h->channels == 3 || h->channels == 4) &&
+                      sizeof(limg_hip_stream_header) + (unsigned long long)p.nBlocks * kEntry + payloadWords * 8ull <= p.streamBytes;
+      if (!ok)
+      {
+        if (tid == 0) atomicOr(p.status, 1u);
+        return;
+      }
+      const int channels = (int)h->channels;
+
+      if (g < p.nBlocks)
+      {
+        const uint2 *ep = reinterpret_cast<const uint2 *>(p.stream + sizeof(limg_hip_stream_header) + (size_t)g * kEntry);
+        uint32_t e[14];
+#pragma unroll
+        for (int i = 0; i < 7; i++) { const uint2 v = ep[i]; e[2 * i] = v.x; e[2 * i + 1] = v.y; }
+        const uint32_t sw = e[12];
+        uint32_t bits = 0, mul = 0;
+#pragma unroll
+        for (int f = 0; f < 3; f++)
+        {
+          const uint32_t s = min((sw >> (8 * f)) & 0xFFu, 8u);
+          const bool raw = (sw >> (24 + f)) & 1u;
+          bits |= (s == 8 ? (raw ? 8u : 0u) : 8u - s) << (8 * f);
+          mul |= shift_mul(s) << (10 * f);
+#pragma unroll
+          for (int c = 0; c < 4; c++)
+          {
+            // vector f: min/offset at int16 index f*8 + c, max/mag at f*8 + 4 + c
+            const int mnv = (int)(int16_t)(e[f * 4 + (c >> 1)] >> (16 * (c & 1)));
+            const int mxv = (int)(int16_t)(e[f * 4 + 2 + (c >> 1)] >> (16 * (c & 1)));
+            int n = mxv - mnv, m = mnv;
+            if (c < 3)
+            {
+              if (s > 7) { n = 0; if (f > 0) m = 0; } // src/limg_decode.h:150-170
+            }
+            else if (channels == 3) { n = 0; m = 0xFFFF; } // src/limg_decode.h:95-97
+            sNm[tid][f * 4 + c] = n;
+            sNm[tid][12 + f * 4 + c] = (int)(((uint32_t)m << 8) + 128u);
+          }
+        }
+        sBits[tid] = bits; sMul[tid] = mul; sOff[tid] = e[13];
+      }
+      __syncthreads();
+
+      const uint32_t inTile = min((uint32_t)kTile, p.nBlocks - tile * kTile);
+      const uint2 *payload = reinterpret_cast<const uint2 *>(p.stream + sizeof(limg_hip_stream_header) + (size_t)p.nBlocks * kEntry);
+      const int j = lane & 7, r = lane >> 3;
+      uint8_t *stage = sStage[wave];
+      const bool rowAligned = (p.sizeX & 3u) == 0;
+      for (int grp = 0; grp < 8; grp++)
+      {
+        const uint32_t jb = wave * 64 + grp * 8;
+        if (jb >= inTile) break; // wave-uniform
+        const uint32_t nValid = min(8u, inTile - jb);
+        const uint32_t t = jb + j;
+        const bool valid = (uint32_t)j < nValid;
+        const uint32_t bw = valid ? sBits[t] : 0u, myOff = valid ? sOff[t] : 0u;
+        const uint32_t off0 = sOff[jb];
+        // the group's payload is one contiguous run in a stream this library wrote; anything else (corrupt offsets) is refused
+        const uint32_t endWord = (uint32_t)__shfl((int)(myOff + words_of(bw)), (int)nValid - 1, 64);
+        const bool sane = myOff >= off0 && myOff + words_of(bw) <= endWord && endWord - off0 <= (uint32_t)(kGroupBytes / 8) && (unsigned long long)endWord <= payloadWords;
+        if (__builtin_amdgcn_ballot_w64(valid && !sane) != 0)
+        {
+          if (lane == 0) atomicOr(p.status, 2u);
+          continue;
+        }
+        {
+          uint2 *dst = reinterpret_cast<uint2 *>(stage);
+          const uint32_t n = endWord - off0;
+          for (uint32_t i = lane; i < n; i += 64) dst[i] = payload[(size_t)off0 + i];
+        }
+        wave_lds_fence();
+        if (valid)
+        {
+          const uint32_t gg = tile * kTile + t, by = gg / p.blocksX, bx = gg - by * p.blocksX;
+          const uint32_t y = by * 8 + r, x0 = bx * 8;
+          uint32_t fieldByte = (myOff - off0) * 8;
+          unsigned long long packed[3];
+          uint32_t bb[3];
+#pragma unroll
+          for (int k = 0; k < 3; k++)
+          {
+            const uint32_t b = (bw >> (8 * k)) & 0xFF;
+            bb[k] = b;
+            const uint32_t o = fieldByte + r * b;
+            const uint32_t *wp = reinterpret_cast<const uint32_t *>(stage + (o & ~3u));
+            const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2];
+            const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, o & 3u), hi = __builtin_amdgcn_alignbyte(d2, d1, o & 3u);
+            packed[k] = ((unsigned long long)hi << 32) | lo;
+            fieldByte += b * 8;
+          }
+          const uint32_t mulw = sMul[t];
+          const int mulA = (int)(mulw & 0x3FF), mulB = (int)((mulw >> 10) & 0x3FF), mulC = (int)((mulw >> 20) & 0x3FF);
+          const int *nm = sNm[t];
+          const int4 nA = *reinterpret_cast<const int4 *>(nm), nB = *reinterpret_cast<const int4 *>(nm + 4), nC = *reinterpret_cast<const int4 *>(nm + 8);
+          const int4 mA = *reinterpret_cast<const int4 *>(nm + 12), mB = *reinterpret_cast<const int4 *>(nm + 16), mC = *reinterpret_cast<const int4 *>(nm + 20);
+          const int nAa[4] = { nA.x, nA.y, nA.z, nA.w }, nBa[4] = { nB.x, nB.y, nB.z, nB.w }, nCa[4] = { nC.x, nC.y, nC.z, nC.w };
+          const int mAa[4] = { mA.x, mA.y, mA.z, mA.w }, mBa[4] = { mB.x, mB.y, mB.z, mB.w }, mCa[4] = { mC.x, mC.y, mC.z, mC.w };
+          const uint32_t maskA = (1u << bb[0]) - 1u, maskB = (1u << bb[1]) - 1u, maskC = (1u << bb[2]) - 1u;
+          uint32_t px[8];
+#pragma unroll
+          for (int i = 0; i < 8; i++)
+          {
+            // a16: dec_k = value * mul_k; est_c = sum_k (dec_k * n_k[c] + (m_k[c] << 8) + 128) >> 8; clamp.  24-bit multiplies are exact
+            // here (dec <= 255 * 256, |n| <= 65535) and v_mad_i32_i24 keeps the low 32 bits like PMULLD.
+            const int dA = (int)((uint32_t)(packed[0] >> (i * bb[0])) & maskA) * mulA;
+            const int dB = (int)((uint32_t)(packed[1] >> (i * bb[1])) & maskB) * mulB;
+            const int dC = (int)((uint32_t)(packed[2] >> (i * bb[2])) & maskC) * mulC;
+            uint32_t v = 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+            {
+              int est = (mad_i24(dA, nAa[c], mAa[c]) >> 8) + (mad_i24(dB, nBa[c], mBa[c]) >> 8) + (mad_i24(dC, nCa[c], mCa[c]) >> 8);
+              est = est < 0 ? 0 : (est > 255 ? 255 : est);
+              v |= (uint32_t)est << (8 * c);
+            }
+            px[i] = v;
+          }
+          if (y < p.sizeY)
+          {
+            uint32_t *dst = p.out + (size_t)y * p.sizeX + x0;
+            if (rowAligned && x0 + 8 <= p.sizeX)
+            {
+              reinterpret_cast<uint4 *>(dst)[0] = make_uint4(px[0], px[1], px[2], px[3]);
+              reinterpret_cast<uint4 *>(dst)[1] = make_uint4(px[4], px[5], px[6], px[7]);
+            }
+            else
+            {
+#pragma unroll
+              for (int i = 0; i < 8; i++)
+                if (x0 + i < p.sizeX) dst[i] = px[i];
+            }
+          }
+        }
+        wave_lds_fence();
+      }
+    }
+  }
+
+  void launch_stream_pack(const StreamParams &p, hipStream_t s)
+  {
+    hipLaunchKernelGGL(k_stream_count, dim3(p.nTiles), dim3(kTile), 0, s, p);
+    hipLaunchKernelGGL(k_stream_scan, dim3(1), dim3(1024), 0, s, p);
+    hipLaunchKernelGGL(k_stream_pack, dim3(p.nTiles), dim3(kTile), 0, s, p);
+  }
+
+  void launch_stream_decode(const DecodeParams &p, hipStream_t s)
+  {
+    hipLaunchKernelGGL(k_stream_decode, dim3((p.nBlocks + kTile - 1) / kTile), dim3(kTile), 0, s, p);
+  }
+}
