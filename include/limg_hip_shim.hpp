@@ -71,4 +71,32 @@ inline double limg_compare(const uint32_t *pImageA, const uint32_t *pImageB, con
   return limg_hip_compare(c, pImageA, pImageB, sizeX, sizeY, hasAlpha ? 1 : 0, pMeanSquaredError, pMaxPossibleSquaredError);
 }
 
+// `limg_encode` / `limg_decode`: named by the north-star, absent upstream (src/limg.h declares no such pair).  Build-defined wrappers over the
+// compact "LMG3" stream of limg_hip.h: limg_decode(limg_encode(image)) == the pDecoded plane of limg_encode3d_test, bit for bit.
+inline size_t limg_encode_bound(const size_t sizeX, const size_t sizeY) { return limg_hip_stream_bound(sizeX, sizeY); }
+
+inline limg_result limg_encode(const uint32_t *pIn, const size_t sizeX, const size_t sizeY, const bool hasAlpha, uint8_t *pOut, const size_t outCapacity, size_t *pOutSize,
+                               const uint32_t errorFactor = 100, limg_thread_pool *pThreadPool = nullptr, const bool fastBitCrushing = true)
+{
+  limg_hip_context *c = limg_hip_shim::context();
+  if (!c) return limg_error_Generic;
+  return (limg_result)limg_hip_encode_stream(c, pIn, sizeX, sizeY, hasAlpha ? 1 : 0, pOut, outCapacity, pOutSize, errorFactor, pThreadPool ? (int)pThreadPool->threads : 0,
+                                             fastBitCrushing ? 1 : 0);
+}
+
+inline limg_result limg_decode_info(const uint8_t *pIn, const size_t size, size_t *pSizeX, size_t *pSizeY, bool *pHasAlpha)
+{
+  int alpha = 0;
+  const limg_result r = (limg_result)limg_hip_stream_info(pIn, size, pSizeX, pSizeY, &alpha, nullptr);
+  if (pHasAlpha) *pHasAlpha = alpha != 0;
+  return r;
+}
+
+inline limg_result limg_decode(const uint8_t *pIn, const size_t size, uint32_t *pOut, const size_t outPixelCapacity)
+{
+  limg_hip_context *c = limg_hip_shim::context();
+  if (!c) return limg_error_Generic;
+  return (limg_result)limg_hip_decode_stream(c, pIn, size, pOut, outPixelCapacity);
+}
+
 #endif // LIMG_HIP_SHIM_HPP

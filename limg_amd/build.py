@@ -43,5 +43,25 @@ def build(force=False, verbose=False, extra_flags=()):
     return OUT
 
 
+CLI_SRC = os.path.join(HERE, "..", "tools", "limg_hip_cli.cpp")
+CLI_OUT = os.path.join(HERE, "limg_hip_cli")
+
+
+def build_cli(force=False, verbose=False):
+    """tools/limg_hip_cli.cpp -> limg_amd/limg_hip_cli: plain g++ host program on the C ABI (through include/limg_hip_shim.hpp)."""
+    build(force=force, verbose=verbose)
+    deps = [CLI_SRC, OUT, os.path.join(HERE, "..", "include", "limg_hip.h"), os.path.join(HERE, "..", "include", "limg_hip_shim.hpp")]
+    if not force and _newer(CLI_OUT, deps):
+        return CLI_OUT
+    rocm_lib = os.environ.get("ROCM_LIB", "/opt/rocm/lib")
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(HERE, "..", "include"), CLI_SRC, "-o", CLI_OUT, "-L", HERE, "-llimg_hip", "-lz", "-lpthread",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + rocm_lib, "-Wl,-rpath," + rocm_lib]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return CLI_OUT
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_cli(force="--force" in sys.argv, verbose=True))

@@ -29,6 +29,11 @@ namespace limg_hip
 
     __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
     __device__ __forceinline__ int mad_i24(int a, int b, int c) { int r; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+    __device__ __forceinline__ uint32_t mul_u24(uint32_t a, uint32_t b) { uint32_t r; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+    __device__ __forceinline__ int med3_i32(int a, int b, int c) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+    __device__ __forceinline__ int add3(int a, int b, int c) { int r; asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+    __device__ __forceinline__ uint32_t bfe(uint32_t v, uint32_t off, uint32_t width) { uint32_t r; asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(off), "v"(width)); return r; }
+    __device__ __forceinline__ uint32_t lshl_or(uint32_t a, uint32_t sh, uint32_t b) { uint32_t r; asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(sh), "v"(b)); return r; }
     __device__ __forceinline__ void wave_lds_fence()
     {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -229,10 +234,10 @@ namespace limg_hip
 
     // ---- decode ----------------------------------------------------------------------------------------------------------
 
-    __global__ __launch_bounds__(kTile) void k_stream_decode(const DecodeParams p)
+    __global__ __launch_bounds__(kTile, 4) void k_stream_decode(const DecodeParams p)
     {
       __shared__ __align__(16) int sNm[kTile][24];
-      __shared__ uint32_t sBits[kTile], sOff[kTile], sMul[kTile];
+      __shared__ uint32_t sBits[kTile], sOff[kTile], sMul[kTile], sBx[kTile], sBy[kTile];
       __shared__ __align__(16) uint8_t sStage[4][kGroupBytes + 16];
       const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
       const uint32_t tile = blockIdx.x, g = tile * kTile + tid;
@@ -282,6 +287,8 @@ namespace limg_hip
           }
         }
         sBits[tid] = bits; sMul[tid] = mul; sOff[tid] = e[13];
+        const uint32_t by = g / p.blocksX;
+        sBy[tid] = by; sBx[tid] = g - by * p.blocksX;
       }
       __syncthreads();
 
@@ -290,33 +297,61 @@ namespace limg_hip
       const int j = lane & 7, r = lane >> 3;
       uint8_t *stage = sStage[wave];
       const bool rowAligned = (p.sizeX & 3u) == 0;
+      // Per group of 8 blocks: where its payload run lies.  The run of group g + 1 is requested (into registers) before group g
+      // is decoded, so the HBM round trip hides behind ~400 VALU instructions.
+      struct Group { uint32_t t, bw, myOff, off0, n; bool valid, any, ok; };
+      auto group_info = [&](int grp) {
+        Group G;
+        const uint32_t jb = wave * 64 + grp * 8;
+        G.any = grp < 8 && jb < inTile; // wave-uniform
+        G.t = jb + j; G.bw = 0; G.myOff = 0; G.off0 = 0; G.n = 0; G.valid = false; G.ok = false;
+        if (!G.any) return G;
+        const uint32_t nValid = min(8u, inTile - jb);
+        G.valid = (uint32_t)j < nValid;
+        G.bw = G.valid ? sBits[G.t] : 0u;
+        G.myOff = G.valid ? sOff[G.t] : 0u;
+        G.off0 = sOff[jb];
+        // the group's payload is one contiguous run in a stream this library wrote; anything else (corrupt offsets) is refused
+        const uint32_t endWord = (uint32_t)__shfl((int)(G.myOff + words_of(G.bw)), (int)nValid - 1, 64);
+        const bool sane = G.myOff >= G.off0 && G.myOff + words_of(G.bw) <= endWord && endWord - G.off0 <= (uint32_t)(kGroupBytes / 8) && (unsigned long long)endWord <= payloadWords;
+        G.ok = __builtin_amdgcn_ballot_w64(G.valid && !sane) == 0;
+        G.n = G.ok ? endWord - G.off0 : 0u;
+        return G;
+      };
+      auto fetch = [&](const Group &G, uint2 buf[3]) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+        {
+          buf[i] = make_uint2(0, 0);
+          if ((uint32_t)(lane + 64 * i) < G.n) buf[i] = payload[(size_t)G.off0 + lane + 64 * i];
+        }
+      };
+      Group cur = group_info(0);
+      uint2 buf[3];
+      fetch(cur, buf);
       for (int grp = 0; grp < 8; grp++)
       {
-        const uint32_t jb = wave * 64 + grp * 8;
-        if (jb >= inTile) break; // wave-uniform
-        const uint32_t nValid = min(8u, inTile - jb);
-        const uint32_t t = jb + j;
-        const bool valid = (uint32_t)j < nValid;
-        const uint32_t bw = valid ? sBits[t] : 0u, myOff = valid ? sOff[t] : 0u;
-        const uint32_t off0 = sOff[jb];
-        // the group's payload is one contiguous run in a stream this library wrote; anything else (corrupt offsets) is refused
-        const uint32_t endWord = (uint32_t)__shfl((int)(myOff + words_of(bw)), (int)nValid - 1, 64);
-        const bool sane = myOff >= off0 && myOff + words_of(bw) <= endWord && endWord - off0 <= (uint32_t)(kGroupBytes / 8) && (unsigned long long)endWord <= payloadWords;
-        if (__builtin_amdgcn_ballot_w64(valid && !sane) != 0)
+        if (!cur.any) break; // wave-uniform
+        const Group G = cur;
+        {
+          uint2 *dst = reinterpret_cast<uint2 *>(stage);
+#pragma unroll
+          for (int i = 0; i < 3; i++)
+            if ((uint32_t)(lane + 64 * i) < G.n) dst[lane + 64 * i] = buf[i];
+        }
+        cur = group_info(grp + 1);
+        fetch(cur, buf);
+        if (!G.ok)
         {
           if (lane == 0) atomicOr(p.status, 2u);
           continue;
         }
-        {
-          uint2 *dst = reinterpret_cast<uint2 *>(stage);
-          const uint32_t n = endWord - off0;
-          for (uint32_t i = lane; i < n; i += 64) dst[i] = payload[(size_t)off0 + i];
-        }
+        const uint32_t t = G.t, bw = G.bw, myOff = G.myOff, off0 = G.off0;
+        const bool valid = G.valid;
         wave_lds_fence();
         if (valid)
         {
-          const uint32_t gg = tile * kTile + t, by = gg / p.blocksX, bx = gg - by * p.blocksX;
-          const uint32_t y = by * 8 + r, x0 = bx * 8;
+          const uint32_t y = sBy[t] * 8 + r, x0 = sBx[t] * 8;
           uint32_t fieldByte = (myOff - off0) * 8;
           unsigned long long packed[3];
           uint32_t bb[3];
@@ -339,25 +374,24 @@ namespace limg_hip
           const int4 mA = *reinterpret_cast<const int4 *>(nm + 12), mB = *reinterpret_cast<const int4 *>(nm + 16), mC = *reinterpret_cast<const int4 *>(nm + 20);
           const int nAa[4] = { nA.x, nA.y, nA.z, nA.w }, nBa[4] = { nB.x, nB.y, nB.z, nB.w }, nCa[4] = { nC.x, nC.y, nC.z, nC.w };
           const int mAa[4] = { mA.x, mA.y, mA.z, mA.w }, mBa[4] = { mB.x, mB.y, mB.z, mB.w }, mCa[4] = { mC.x, mC.y, mC.z, mC.w };
-          const uint32_t maskA = (1u << bb[0]) - 1u, maskB = (1u << bb[1]) - 1u, maskC = (1u << bb[2]) - 1u;
+          // values 0..3 of a row sit in the low dword (4 b <= 32 bits), values 4..7 in the low dword of (packed >> 4 b)
+          uint32_t lo[3], hi[3];
+#pragma unroll
+          for (int k = 0; k < 3; k++) { lo[k] = (uint32_t)packed[k]; hi[k] = (uint32_t)(packed[k] >> (4 * bb[k])); }
           uint32_t px[8];
 #pragma unroll
           for (int i = 0; i < 8; i++)
           {
             // a16: dec_k = value * mul_k; est_c = sum_k (dec_k * n_k[c] + (m_k[c] << 8) + 128) >> 8; clamp.  24-bit multiplies are exact
             // here (dec <= 255 * 256, |n| <= 65535) and v_mad_i32_i24 keeps the low 32 bits like PMULLD.
-            const int dA = (int)((uint32_t)(packed[0] >> (i * bb[0])) & maskA) * mulA;
-            const int dB = (int)((uint32_t)(packed[1] >> (i * bb[1])) & maskB) * mulB;
-            const int dC = (int)((uint32_t)(packed[2] >> (i * bb[2])) & maskC) * mulC;
-            uint32_t v = 0;
+            const int dA = (int)mul_u24(bfe(i < 4 ? lo[0] : hi[0], (i & 3) * bb[0], bb[0]), (uint32_t)mulA);
+            const int dB = (int)mul_u24(bfe(i < 4 ? lo[1] : hi[1], (i & 3) * bb[1], bb[1]), (uint32_t)mulB);
+            const int dC = (int)mul_u24(bfe(i < 4 ? lo[2] : hi[2], (i & 3) * bb[2], bb[2]), (uint32_t)mulC);
+            int e[4];
 #pragma unroll
             for (int c = 0; c < 4; c++)
-            {
-              int est = (mad_i24(dA, nAa[c], mAa[c]) >> 8) + (mad_i24(dB, nBa[c], mBa[c]) >> 8) + (mad_i24(dC, nCa[c], mCa[c]) >> 8);
-              est = est < 0 ? 0 : (est > 255 ? 255 : est);
-              v |= (uint32_t)est << (8 * c);
-            }
-            px[i] = v;
+              e[c] = med3_i32(add3(mad_i24(dA, nAa[c], mAa[c]) >> 8, mad_i24(dB, nBa[c], mBa[c]) >> 8, mad_i24(dC, nCa[c], mCa[c]) >> 8), 0, 255);
+            px[i] = lshl_or((uint32_t)e[3], 24, lshl_or((uint32_t)e[2], 16, lshl_or((uint32_t)e[1], 8, (uint32_t)e[0])));
           }
           if (y < p.sizeY)
           {

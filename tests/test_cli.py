@@ -1,0 +1,71 @@
+"""limg_hip_cli (tools/limg_hip_cli.cpp): the counterpart of the reference's command-line tool (src/main.cpp), written against
+include/limg_hip_shim.hpp -- so these tests also cover the C++ shim with the reference's own signatures."""
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PNG = os.path.join(ROOT, "tests", "golden", "original.png")
+
+
+@pytest.fixture(scope="module")
+def cli():
+    from limg_amd import build
+    return build.build_cli()
+
+
+def _read_tga(path):
+    raw = np.fromfile(path, dtype=np.uint8)
+    w, h, bpp = int(raw[12]) | (int(raw[13]) << 8), int(raw[14]) | (int(raw[15]) << 8), int(raw[16]) // 8
+    body = raw[18:18 + w * h * bpp].reshape(h, w, bpp)
+    assert raw[17] & 0x20, "top-down expected"
+    if bpp == 1:
+        return body[:, :, 0].copy()
+    rgba = body[:, :, [2, 1, 0, 3]].copy()
+    return rgba.view(np.uint32).reshape(h, w)
+
+
+def test_usage_and_loud_failure_without_gpu(cli):
+    r = subprocess.run([cli], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("Usage:")
+    r = subprocess.run([cli, PNG, "--bogus"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Invalid Parameter: '--bogus'. Aborting." in r.stdout
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([cli, PNG, "--no-output"], capture_output=True, text=True)
+        assert r.returncode == 1 and "no CPU fallback" in r.stderr and "1024 x 618 pixels." in r.stdout
+
+
+@pytest.mark.gpu
+def test_single_file_matches_reference(cli, oracle, tmp_path):
+    """config #1: original.png, RGB, single dither chain -- PSNR line and every written plane against the real reference's hashes."""
+    r = subprocess.run([cli, PNG, "--single-thread", "--out-dir", str(tmp_path), "--stream", str(tmp_path / "o.lmg3")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "1024 x 618 pixels." in r.stdout and "limg_encode_test completed with exit code 0x0." in r.stdout
+    m = re.search(r"Image Perceptual RGB\(A\) PSNR: ([0-9.]+) dB \(mean: ([0-9.]+)", r.stdout)
+    assert m and m.group(1) == "40.70" and m.group(2) == "49.818"  # 40.6994 dB, mse 49.8179
+    assert "decoding it reproduces the decoded image" in r.stdout and "Wrote decoded file." in r.stdout
+    want = gu.hashes()["original_rgb"]
+    names = {"limg_out": "pDecoded", "limg_bits": "pShiftABCX", "limg_col_a_min": "pColAMin", "limg_col_a_max": "pColAMax", "limg_col_b_min": "pColBMin",
+             "limg_col_b_max": "pColBMax", "limg_col_c_min": "pColCMin", "limg_col_c_max": "pColCMax", "limg_fac_a": "pFactorsA", "limg_fac_b": "pFactorsB",
+             "limg_fac_c": "pFactorsC"}
+    for f, k in names.items():
+        assert oracle.fnv(_read_tga(str(tmp_path / (f + ".tga")))) == want[k], (f, k)
+    import limg_amd
+    st = np.fromfile(str(tmp_path / "o.lmg3"), dtype=np.uint8)
+    assert limg_amd.stream_info(st) == (1024, 618, False, st.size)
+
+
+@pytest.mark.gpu
+def test_benchmark_modes(cli):
+    r = subprocess.run([cli, "--", "--count", "3", "--error-factor", "50", "--", PNG], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert re.search(r"Mean Elapsed Time:\s+[0-9.]+ ms \(", r.stdout) and re.search(r"Throughput: [0-9.]+ Mpx/s \(", r.stdout)
+    r = subprocess.run([cli, "--", "--count", "2", "--", PNG, PNG], capture_output=True, text=True)
+    assert r.returncode == 0 and "Complete." in r.stdout and re.search(r"Processed 2\.531 Mpx in", r.stdout)
