@@ -9,6 +9,12 @@ P32 = ("pDecoded", "pShiftABCX", "pColAMin", "pColAMax", "pColBMin", "pColBMax",
 P8 = ("pFactorsA", "pFactorsB", "pFactorsC")
 PLANES = P32 + P8
 
+# limg_blocked_encode3d_info (src/limg.h:39-44), member order
+BLOCKED_PLANES = (("pDecoded", np.uint32), ("pFactorsA", np.uint8), ("pFactorsB", np.uint8), ("pFactorsC", np.uint8), ("pBlockError", np.uint8), ("pBitsPerPixel", np.uint8),
+                  ("pShiftABCX", np.uint32), ("pColAMin", np.uint32), ("pColAMax", np.uint32), ("pColBMin", np.uint32), ("pColBMax", np.uint32), ("pColCMin", np.uint32),
+                  ("pColCMax", np.uint32), ("pBlockIndex", np.uint32))
+BLOCKED_WRITTEN = tuple(k for k, _ in BLOCKED_PLANES if k != "pBlockError")  # upstream never writes pBlockError
+
 FLOAT_X86, FLOAT_TREE = 0, 1
 DITHER_AES, DITHER_PCG = 0, 1
 
@@ -40,6 +46,14 @@ class Config(C.Structure):
                 ("pool_threads", C.c_int32), ("worker_threads", C.c_int32), ("forced_shift", C.c_int32 * 3)]
 
 
+REGION_DTYPE = np.dtype([("ox", "<u4"), ("oy", "<u4"), ("rx", "<u4"), ("ry", "<u4"), ("shift", "u1", 3), ("calls", "u1"), ("keep", "<u4"), ("rec", REC_DTYPE)])
+assert REGION_DTYPE.itemsize == 88
+
+
+def alloc_blocked_planes(w, h):
+    return {k: np.zeros((h, w), dtype=t) for k, t in BLOCKED_PLANES}
+
+
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -69,6 +83,10 @@ class Oracle:
         L.limg_oracle_fnv1a64.argtypes = [C.c_void_p, C.c_size_t]
         L.limg_oracle_synth_random_gradient.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint64, C.c_int]
         L.limg_oracle_synth_photo_noise.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint64]
+        L.limg_oracle_blocked_encode3d.restype = C.c_int
+        L.limg_oracle_blocked_encode3d.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.limg_oracle_blocked_matches.restype = C.c_int
+        L.limg_oracle_blocked_matches.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
 
     def config(self, error_factor=100, fast=True, float_mode=FLOAT_X86, dither_mode=DITHER_AES, pool_threads=0, worker_threads=1, forced_shift=None):
         cfg = Config()
@@ -102,6 +120,26 @@ class Oracle:
             out.update(records=rec.reshape(by, bx), shifts=sh, preA=pa, preB=pb, preC=pc)
         out["trials"] = trials.value
         return out
+
+    def blocked_encode3d(self, img, has_alpha, planes=True, **kw):
+        """limg_blocked_encode3d_test.  Returns the 14 planes (+ 'pass1' records, 'regions' in creation order)."""
+        img = np.ascontiguousarray(img, dtype=np.uint32)
+        h, w = img.shape
+        cfg = self.config(**kw)
+        out = alloc_blocked_planes(w, h) if planes else {}
+        info = (C.c_void_p * 14)(*[out[k].ctypes.data for k, _ in BLOCKED_PLANES]) if planes else None
+        bx, by = (w + 7) // 8, (h + 7) // 8
+        pass1 = np.zeros(bx * by, dtype=REC_DTYPE)
+        regions = np.zeros(bx * by, dtype=REGION_DTYPE)
+        n = C.c_size_t(0)
+        r = self.lib.limg_oracle_blocked_encode3d(_ptr(img), w, h, int(has_alpha), info, C.byref(cfg), _ptr(pass1), _ptr(regions), regions.size, C.byref(n))
+        assert r == 0, r
+        out.update(pass1=pass1.reshape(by, bx), regions=regions[:n.value].copy())
+        return out
+
+    def blocked_matches(self, channels, a, b):
+        a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+        return bool(self.lib.limg_oracle_blocked_matches(channels, _ptr(a), _ptr(b)))
 
     def compare(self, a, b, has_alpha):
         a = np.ascontiguousarray(a, dtype=np.uint32); b = np.ascontiguousarray(b, dtype=np.uint32)
@@ -186,6 +224,11 @@ class Ref:
         L.ref_dither.restype = C.c_uint64
         L.ref_dither.argtypes = [C.c_int, C.c_size_t, C.c_uint64, C.c_void_p, C.c_int]
         L.ref_block_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int] + [C.c_void_p] * 5
+        if hasattr(L, "ref_blocked_encode3d"):
+            L.ref_blocked_encode3d.restype = C.c_int
+            L.ref_blocked_encode3d.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int]
+            L.ref_blocked_matches.restype = C.c_int
+            L.ref_blocked_matches.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
 
     @staticmethod
     def _rec_in(rec, channels):
@@ -215,6 +258,20 @@ class Ref:
         r = self.lib.ref_encode3d(_ptr(img), w, h, int(has_alpha), p32, p8, error_factor, pool_threads, int(fast), dither_mode)
         assert r == 0, r
         return out
+
+    def blocked_encode3d(self, img, has_alpha, error_factor=100, pool_threads=0, fast=True, dither_mode=DITHER_AES):
+        img = np.ascontiguousarray(img, dtype=np.uint32)
+        h, w = img.shape
+        out = alloc_blocked_planes(w, h)
+        planes = (C.c_void_p * 14)(*[out[k].ctypes.data for k, _ in BLOCKED_PLANES])
+        r = self.lib.ref_blocked_encode3d(_ptr(img), w, h, int(has_alpha), planes, error_factor, pool_threads, int(fast), dither_mode)
+        assert r == 0, r
+        return out
+
+    def blocked_matches(self, channels, a, b):
+        ra = np.concatenate([self._rec_in(a, channels).view(np.uint8), np.zeros(32, np.uint8)])
+        rb = np.concatenate([self._rec_in(b, channels).view(np.uint8), np.zeros(32, np.uint8)])
+        return bool(self.lib.ref_blocked_matches(channels, _ptr(ra), _ptr(rb)))
 
     def encode3d_perf(self, img, has_alpha, error_factor=100, pool_threads=0, fast=True):
         img = np.ascontiguousarray(img, dtype=np.uint32)

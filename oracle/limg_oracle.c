@@ -83,9 +83,9 @@ static int unit_contribution(const float d[4], int channels, float out[4])
 /* Sum of the per-pixel contributions of one direction pass.
  * X86: pixel order, skipped pixels really skipped (src/limg_factorization.h:402-431).
  * TREE: balanced binary tree over the pixel index, index bit 0 combined first, skipped / missing pixels are +0.0f. */
-static void sum_contributions(float v[64][4], const int valid[64], size_t n, int float_mode, float out[4])
+static void sum_contributions(float (*v)[4], const int *valid, size_t n, int float_mode, float out[4])
 {
-  if (float_mode == LIMG_ORACLE_FLOAT_X86)
+  if (float_mode == LIMG_ORACLE_FLOAT_X86 || n > 64) /* the tree what-if is defined for 8x8 blocks only */
   {
     for (int c = 0; c < 4; c++)
     {
@@ -122,10 +122,12 @@ void limg_oracle_block_fit(const uint32_t *px, size_t n, int channels, int float
   for (int c = 0; c < 4; c++) avg[c] = (float)(int32_t)sum[c] * inv_count;
   if (channels == 3) avg[3] = 0.0f; /* lane 3 is stack garbage upstream and never observable (:396-402) */
 
-  float contrib[64][4];
-  int valid[64];
-  float pxf[64][4];
-  float est[64][4];
+  /* any pixel count: the merged-block encoder fits whole regions with the same function (src/limg.cpp:1752-1760) */
+  const size_t cap = n > 64 ? n : 64;
+  float (*contrib)[4] = (float (*)[4])malloc(cap * sizeof(float[4]));
+  float (*pxf)[4] = (float (*)[4])malloc(cap * sizeof(float[4]));
+  float (*est)[4] = (float (*)[4])malloc(cap * sizeof(float[4]));
+  int *valid = (int *)malloc(cap * sizeof(int));
   float dirA[4] = { 0, 0, 0, 0 }, dirB[4] = { 0, 0, 0, 0 }, dirC[4] = { 0, 0, 0, 0 };
   float minA = 0, maxA = 0, minB = 0, maxB = 0, minC = 0, maxC = 0;
 
@@ -234,6 +236,7 @@ void limg_oracle_block_fit(const uint32_t *px, size_t n, int channels, int float
     out->dirC_offset[c] = (int16_t)cvtps(minC * dirC[c]);
     out->dirC_mag[c] = (int16_t)cvtps(maxC * dirC[c]);
   }
+  free(contrib); free(pxf); free(est); free(valid);
 }
 
 /* a7: src/limg_internal.h:426-452;  a8: src/limg_factorization.h:149-197 (4 ch) / :98-147 (3 ch) */

@@ -78,6 +78,36 @@ extern "C"
     return r;
   }
 
+  // limg_blocked_encode3d_test (src/limg.h:46).  planes in the member order of limg_blocked_encode3d_info (src/limg.h:39-44).
+  int ref_blocked_encode3d(const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, void **planes /* 14 */, uint32_t errorFactor, int poolThreads, int fast, int dither_mode)
+  {
+    set_features(dither_mode);
+    limg_blocked_encode3d_info info;
+    info.pDecoded = (uint32_t *)planes[0];
+    info.pFactorsA = (uint8_t *)planes[1]; info.pFactorsB = (uint8_t *)planes[2]; info.pFactorsC = (uint8_t *)planes[3];
+    info.pBlockError = (uint8_t *)planes[4]; info.pBitsPerPixel = (uint8_t *)planes[5];
+    info.pShiftABCX = (uint32_t *)planes[6]; info.pColAMin = (uint32_t *)planes[7]; info.pColAMax = (uint32_t *)planes[8];
+    info.pColBMin = (uint32_t *)planes[9]; info.pColBMax = (uint32_t *)planes[10]; info.pColCMin = (uint32_t *)planes[11]; info.pColCMax = (uint32_t *)planes[12];
+    info.pBlockIndex = (uint32_t *)planes[13];
+    limg_thread_pool *pPool = poolThreads > 0 ? limg_thread_pool_new((size_t)poolThreads) : nullptr;
+    int r;
+    {
+      stdout_silencer s;
+      r = (int)limg_blocked_encode3d_test(pIn, sizeX, sizeY, hasAlpha != 0, &info, errorFactor, pPool, fast != 0);
+    }
+    if (pPool) limg_thread_pool_destroy(&pPool);
+    return r;
+  }
+
+  // limg_encode_3d_matches (src/limg.cpp:1264-1268): records in the reference's own <3>/<4> layouts
+  int ref_blocked_matches(int channels, void *a, const void *b)
+  {
+    limg_encode_context ctx;
+    memset(&ctx, 0, sizeof(ctx));
+    if (channels == 4) return limg_encode_3d_matches<4>(&ctx, *reinterpret_cast<limg_encode_3d_output<4> *>(a), *reinterpret_cast<const limg_encode_3d_output<4> *>(b)) ? 1 : 0;
+    return limg_encode_3d_matches<3>(&ctx, *reinterpret_cast<limg_encode_3d_output<3> *>(a), *reinterpret_cast<const limg_encode_3d_output<3> *>(b)) ? 1 : 0;
+  }
+
   int ref_encode3d_perf(const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, uint32_t errorFactor, int poolThreads, int fast, int dither_mode)
   {
     set_features(dither_mode);
