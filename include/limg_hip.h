@@ -127,6 +127,38 @@ limg_hip_result limg_hip_host_noise_table(uint8_t *pOut, size_t calls);
 uint64_t limg_hip_host_chain_call(uint64_t chainValue, size_t pixelCount, uint8_t *pNoise64, int forceSoftwareAes);
 limg_hip_result limg_hip_host_partition(size_t sizeY, int poolThreads, uint32_t *pChainCount, uint32_t *pChainBlockRows);
 
+/* ---- merged-block encoder ----------------------------------------------------------------------------------------------------------
+ * Replaces `limg_blocked_encode3d_test` (src/limg.h:46, src/limg.cpp:2329-2453), what the reference's CLI runs on a single file
+ * (src/main.cpp:255): per-8x8 fit, greedy merge of similar neighbouring blocks into rectangles, re-fit + bit crush + dither + decode
+ * per rectangle.  Struct = `limg_blocked_encode3d_info` (src/limg.h:39-44), same member order.  pBlockError is never written (it is not
+ * upstream either) and may be NULL.  The pool argument of the reference only splits its first pass and has no effect on the result, so it
+ * has no counterpart here.  Division of labour: fits, the block-similarity predicate, the per-rectangle work and all plane
+ * stores run on the GPU; the greedy raster scan over precomputed similarity bits and the (inherently serial) dither chain walk run on the host. */
+typedef struct limg_hip_blocked_encode3d_info
+{
+  uint32_t *pDecoded;
+  uint8_t *pFactorsA, *pFactorsB, *pFactorsC, *pBlockError, *pBitsPerPixel;
+  uint32_t *pShiftABCX, *pColAMin, *pColAMax, *pColBMin, *pColBMax, *pColCMin, *pColCMax, *pBlockIndex;
+} limg_hip_blocked_encode3d_info;
+
+typedef struct limg_hip_region { uint32_t ox, oy, rx, ry; } limg_hip_region; /* in 8x8 blocks, creation (= block index) order */
+
+/* HOST pointers, blocking. */
+limg_hip_result limg_hip_blocked_encode3d(limg_hip_context *pCtx, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, limg_hip_blocked_encode3d_info *pInfo,
+                                          uint32_t errorFactor, int fastBitCrushing);
+/* DEVICE pointers (pIn and the planes inside *pInfo); returns when everything has been enqueued on `stream` -- the call itself waits for
+ * the intermediate device results its host stages need. */
+limg_hip_result limg_hip_blocked_encode3d_device(limg_hip_context *pCtx, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha,
+                                                 const limg_hip_blocked_encode3d_info *pInfo, uint32_t errorFactor, int fastBitCrushing, void *stream);
+/* The rectangles of the context's last merged-block encode (copies up to `capacity`, always reports the count). */
+limg_hip_result limg_hip_blocked_regions(limg_hip_context *pCtx, limg_hip_region *pRegions, size_t capacity, size_t *pCount);
+/* Milliseconds of the stages of the last merged-block encode: [0] pass 1 + similarity bits (GPU, incl. their copy to the host), [1] greedy merge (host),
+ * [2] per-rectangle fit + search (GPU), [3] dither chain walk + noise upload (host), [4] dither + decode + stores (GPU), [5] total. */
+limg_hip_result limg_hip_blocked_timing(limg_hip_context *pCtx, double *pMs6);
+/* Host-only (no GPU touched): the block-similarity predicate `limg_encode_3d_matches` (src/limg.cpp:1137-1268) as the host merge evaluates it
+ * for candidates outside the precomputed window; records in `limg_hip_block_record` layout. */
+int limg_hip_host_blocked_matches(int channels, const limg_hip_block_record *pSeed, const limg_hip_block_record *pCandidate);
+
 /* ---- compact stream ("LMG3") -----------------------------------------------------------------------------------------------
  * The north-star names `limg_encode()` / `limg_decode()` and a bitstream; upstream has neither (src/limg.h:27-48 is the whole API,
  * SURVEY.md 0.1 / 8(f) #2).  These entry points are the build-defined pair over a container that holds exactly what the reference's

@@ -24,7 +24,14 @@ ABI_SYMBOLS = (
     "limg_hip_host_noise_table", "limg_hip_host_chain_call", "limg_hip_host_partition", "limg_hip_check_device_status",
     "limg_hip_stream_bound", "limg_hip_encode_stream_device", "limg_hip_decode_stream_device", "limg_hip_encode_stream", "limg_hip_decode_stream",
     "limg_hip_stream_info",
+    "limg_hip_blocked_encode3d", "limg_hip_blocked_encode3d_device", "limg_hip_blocked_regions", "limg_hip_blocked_timing", "limg_hip_host_blocked_matches",
 )
+
+# limg_blocked_encode3d_info (src/limg.h:39-44), member order
+BLOCKED_PLANES = (("pDecoded", np.uint32), ("pFactorsA", np.uint8), ("pFactorsB", np.uint8), ("pFactorsC", np.uint8), ("pBlockError", np.uint8), ("pBitsPerPixel", np.uint8),
+                  ("pShiftABCX", np.uint32), ("pColAMin", np.uint32), ("pColAMax", np.uint32), ("pColBMin", np.uint32), ("pColBMax", np.uint32), ("pColCMin", np.uint32),
+                  ("pColCMax", np.uint32), ("pBlockIndex", np.uint32))
+REGION_DTYPE = np.dtype([("ox", "<u4"), ("oy", "<u4"), ("rx", "<u4"), ("ry", "<u4")])
 
 STREAM_HEADER_DTYPE = np.dtype([("magic", "<u4"), ("version", "<u4"), ("sizeX", "<u4"), ("sizeY", "<u4"), ("channels", "<u4"), ("errorFactor", "<u4"),
                                 ("blocksX", "<u4"), ("blocksY", "<u4"), ("payloadWords", "<u8"), ("totalBytes", "<u8"), ("flags", "<u4"), ("reserved", "<u4", 3)])
@@ -98,6 +105,16 @@ def load_library(path=None):
     L.limg_hip_host_partition.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.limg_hip_context_device_bytes.restype = C.c_size_t
     L.limg_hip_context_device_bytes.argtypes = [C.c_void_p]
+    L.limg_hip_blocked_encode3d.restype = C.c_int
+    L.limg_hip_blocked_encode3d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_uint32, C.c_int]
+    L.limg_hip_blocked_encode3d_device.restype = C.c_int
+    L.limg_hip_blocked_encode3d_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+    L.limg_hip_blocked_regions.restype = C.c_int
+    L.limg_hip_blocked_regions.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.limg_hip_blocked_timing.restype = C.c_int
+    L.limg_hip_blocked_timing.argtypes = [C.c_void_p, C.c_void_p]
+    L.limg_hip_host_blocked_matches.restype = C.c_int
+    L.limg_hip_host_blocked_matches.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
     L.limg_hip_stream_bound.restype = C.c_size_t
     L.limg_hip_stream_bound.argtypes = [C.c_size_t, C.c_size_t]
     L.limg_hip_encode_stream_device.restype = C.c_int
@@ -130,6 +147,13 @@ def stream_info(stream, lib=None):
     sx, sy, tb, ha = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_int(0)
     _check(lib.limg_hip_stream_info(_np_ptr(stream), stream.size, C.byref(sx), C.byref(sy), C.byref(ha), C.byref(tb)), "limg_hip_stream_info")
     return sx.value, sy.value, bool(ha.value), tb.value
+
+
+def host_blocked_matches(channels, seed, cand, lib=None):
+    """The similarity predicate as the host merge evaluates it (records: numpy RECORD_DTYPE items); no GPU touched."""
+    lib = lib or load_library()
+    a = np.ascontiguousarray(seed); b = np.ascontiguousarray(cand)
+    return bool(lib.limg_hip_host_blocked_matches(channels, _np_ptr(a), _np_ptr(b)))
 
 
 class LimgHip:
@@ -228,6 +252,39 @@ class LimgHip:
         else:
             raise ValueError(kind)
         return out
+
+    # ---- merged-block encoder (limg_blocked_encode3d_test) --------------------------------------------------------------------------
+    def blocked_encode3d(self, img, has_alpha, error_factor=100, fast=True):
+        img = np.ascontiguousarray(img, dtype=np.uint32)
+        h, w = img.shape
+        out = {k: np.zeros((h, w), dtype=t) for k, t in BLOCKED_PLANES}
+        info = (C.c_void_p * 14)(*[out[k].ctypes.data for k, _ in BLOCKED_PLANES])
+        _check(self.lib.limg_hip_blocked_encode3d(self.ctx, _np_ptr(img), w, h, int(has_alpha), info, error_factor, int(fast)), "limg_hip_blocked_encode3d")
+        out["regions"] = self.blocked_regions()
+        return out
+
+    def blocked_encode3d_device(self, img, has_alpha, planes, error_factor=100, fast=True):
+        """img: torch int32 CUDA (h, w); planes: dict name -> torch CUDA tensor for every BLOCKED_PLANES name except pBlockError."""
+        h, w = img.shape
+        info = (C.c_void_p * 14)(*[(planes[k].data_ptr() if k in planes else None) for k, _ in BLOCKED_PLANES])
+        _check(self.lib.limg_hip_blocked_encode3d_device(self.ctx, C.c_void_p(img.data_ptr()), w, h, int(has_alpha), info, error_factor, int(fast), self._stream()),
+               "limg_hip_blocked_encode3d_device")
+
+    def alloc_blocked_planes_device(self, w, h, device="cuda"):
+        import torch
+        return {k: torch.empty((h, w), dtype=(torch.int32 if t == np.uint32 else torch.uint8), device=device) for k, t in BLOCKED_PLANES if k != "pBlockError"}
+
+    def blocked_regions(self):
+        n = C.c_size_t(0)
+        _check(self.lib.limg_hip_blocked_regions(self.ctx, None, 0, C.byref(n)), "limg_hip_blocked_regions")
+        out = np.zeros(n.value, dtype=REGION_DTYPE)
+        _check(self.lib.limg_hip_blocked_regions(self.ctx, _np_ptr(out), out.size, C.byref(n)), "limg_hip_blocked_regions")
+        return out
+
+    def blocked_timing(self):
+        ms = np.zeros(6, dtype=np.float64)
+        _check(self.lib.limg_hip_blocked_timing(self.ctx, _np_ptr(ms)), "limg_hip_blocked_timing")
+        return dict(zip(("pass1_match_gpu", "merge_host", "fit_search_gpu", "chain_host", "store_gpu", "total"), ms.tolist()))
 
     # ---- compact stream ("limg_encode" / "limg_decode") ----------------------------------------------------------------------------
     def stream_bound(self, w, h):

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liblimg_hip.so")
-SOURCES = ["limg_hip_kernels.hip", "limg_hip_stream.hip", "limg_hip_synth.hip", "limg_hip_api.hip", "limg_hip_noise.cpp"]
+SOURCES = ["limg_hip_kernels.hip", "limg_hip_stream.hip", "limg_hip_blocked.hip", "limg_hip_synth.hip", "limg_hip_api.hip", "limg_hip_noise.cpp", "limg_hip_blocked_host.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 
@@ -31,7 +31,8 @@ def build(force=False, verbose=False, extra_flags=()):
         obj = os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o")
         cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if src.endswith(".cpp"):
-            cmd = [hipcc, "-O3", "-fPIC", "-std=c++17", "-Wall", "-x", "c++", "-c", os.path.join(CSRC, src), "-o", obj]
+            # host-only translation units; the merge's similarity predicate is float code that must round like the kernels: no contraction
+            cmd = [hipcc, "-O3", "-fPIC", "-std=c++17", "-Wall", "-ffp-contract=off", "-fno-fast-math", "-x", "c++", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

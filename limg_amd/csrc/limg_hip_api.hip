@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <chrono>
 #include <vector>
 
 namespace limg_hip
@@ -58,6 +59,9 @@ struct limg_hip_context
   DevBuf lookback;                               // fused path: ticket + timeout flag (16 B) then one 8-byte descriptor per work strip
   DevBuf in, planes;                             // staging for the host-pointer entry points
   DevBuf cmp;                                    // 8-byte accumulator of limg_hip_compare
+  DevBuf bMatch, bRegions, bOut, bPx, bV, bFac, bNoise, bNoiseBase; // merged-block encoder: similarity bits, region table / results, scratch, noise
+  std::vector<HostRegion> lastRegions;
+  double blockedMs[6] = { 0, 0, 0, 0, 0, 0 };
   DevBuf streamFac, streamTiles, streamStatus, streamBuf; // stream packer: 3 factor planes, per-tile payload words; decode status word; host-entry staging
   // optional per-kernel timing (bench): 4 events per encode, recorded on the caller's stream, read back in one go
   int persistentWorkgroups = 1024; // 4 per CU (LDS-limited), set from the device's CU count at init
@@ -131,7 +135,7 @@ namespace
   }
 
   limg_hip_result encode_device(limg_hip_context *c, const uint32_t *dIn, size_t sizeX, size_t sizeY, int hasAlpha, const limg_hip_encode3d_info *dInfo,
-                                const limg_hip_compact_out *compact, uint32_t errorFactor, int poolThreads, int fast, hipStream_t stream, bool streamRaw = false)
+                                const limg_hip_compact_out *compact, uint32_t errorFactor, int poolThreads, int fast, hipStream_t stream, bool streamRaw = false, bool fitOnly = false)
   {
     if (!c || !dIn) return limg_hip_error_ArgumentNull;
     if (sizeX == 0 || sizeY == 0 || sizeX > 0x7FFFFFF8ull || sizeY > 0x7FFFFFF8ull) return limg_hip_error_InvalidParameter;
@@ -181,6 +185,7 @@ namespace
     p.storePlanes = dInfo != nullptr;
     p.fullPlanes = fullPlanes;
     p.streamRaw = streamRaw && !fullPlanes;
+    p.fitOnly = fitOnly && !dInfo;
     if (dInfo) p.info = *dInfo;
     const int channels = hasAlpha ? 4 : 3;
     const bool ragged = (sizeX % kBlock) != 0 || (sizeY % kBlock) != 0;
@@ -305,7 +310,8 @@ extern "C"
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     DevBuf *bufs[] = { &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->lookback, &c->park, &c->in, &c->planes, &c->cmp,
-                       &c->streamFac, &c->streamTiles, &c->streamStatus, &c->streamBuf };
+                       &c->streamFac, &c->streamTiles, &c->streamStatus, &c->streamBuf,
+                       &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bV, &c->bFac, &c->bNoise, &c->bNoiseBase };
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     delete c;
@@ -404,7 +410,8 @@ extern "C"
   {
     if (!c) return 0;
     return c->records.cap + c->shifts.cap + c->stripCalls.cap + c->stripBase.cap + c->noise.cap + c->noiseDyn.cap + c->lookback.cap + c->park.cap + c->in.cap + c->planes.cap + c->cmp.cap +
-           c->streamFac.cap + c->streamTiles.cap + c->streamStatus.cap + c->streamBuf.cap;
+           c->streamFac.cap + c->streamTiles.cap + c->streamStatus.cap + c->streamBuf.cap + c->bMatch.cap + c->bRegions.cap + c->bOut.cap + c->bPx.cap + c->bV.cap +
+           c->bFac.cap + c->bNoise.cap + c->bNoiseBase.cap;
   }
 
   limg_hip_result limg_hip_encode3d_device(limg_hip_context *c, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, const limg_hip_encode3d_info *pInfo,
@@ -637,6 +644,169 @@ extern "C"
     if ((r = limg_hip_decode_stream_device(c, (const uint8_t *)c->streamBuf.p, total, (uint32_t *)c->planes.p, sizeX, sizeY, nullptr)) != limg_hip_success) return r;
     if ((r = limg_hip_check_device_status(c)) != limg_hip_success) return r;
     HIP_TRY(hipMemcpy(pOut, c->planes.p, sizeX * sizeY * 4, hipMemcpyDeviceToHost));
+    return limg_hip_success;
+  }
+  // ---- merged-block encoder ------------------------------------------------------------------------------------------------------
+  int limg_hip_host_blocked_matches(int channels, const limg_hip_block_record *pSeed, const limg_hip_block_record *pCandidate)
+  {
+    if (!pSeed || !pCandidate || (channels != 3 && channels != 4)) return -1;
+    return blocked_matches_host(channels, *pSeed, *pCandidate) ? 1 : 0;
+  }
+
+  limg_hip_result limg_hip_blocked_encode3d_device(limg_hip_context *c, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, const limg_hip_blocked_encode3d_info *pInfo,
+                                                   uint32_t errorFactor, int fastBitCrushing, void *stream)
+  {
+    if (!c || !pIn || !pInfo) return limg_hip_error_ArgumentNull;
+    if (!pInfo->pDecoded || !pInfo->pFactorsA || !pInfo->pFactorsB || !pInfo->pFactorsC || !pInfo->pBitsPerPixel || !pInfo->pShiftABCX || !pInfo->pColAMin || !pInfo->pColAMax ||
+        !pInfo->pColBMin || !pInfo->pColBMax || !pInfo->pColCMin || !pInfo->pColCMax || !pInfo->pBlockIndex)
+      return limg_hip_error_ArgumentNull;
+    if (sizeX == 0 || sizeY == 0 || sizeX > 0x7FFFFFF8ull || sizeY > 0x7FFFFFF8ull || sizeX * sizeY > 0x60000000ull) return limg_hip_error_InvalidParameter;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    using clk = std::chrono::steady_clock;
+    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const clk::time_point t0 = clk::now();
+    const int channels = hasAlpha ? 4 : 3;
+    const uint32_t blocksX = (uint32_t)((sizeX + kBlock - 1) / kBlock), blocksY = (uint32_t)((sizeY + kBlock - 1) / kBlock);
+    const size_t blocks = (size_t)blocksX * blocksY;
+    limg_hip_result r;
+
+    // pass 1 (src/limg.cpp:1088-1119): every block's own fit = the 8x8 path's E step, records only
+    if ((r = encode_device(c, pIn, sizeX, sizeY, hasAlpha, nullptr, nullptr, errorFactor, 0, fastBitCrushing, s, false, true)) != limg_hip_success) return r;
+
+    BlockedParams bp;
+    memset(&bp, 0, sizeof(bp));
+    bp.in = pIn; bp.sizeX = (uint32_t)sizeX; bp.sizeY = (uint32_t)sizeY; bp.blocksX = blocksX; bp.blocksY = blocksY; bp.channels = (uint32_t)channels;
+    const uint64_t maxPixel = (uint64_t)0x6 * (errorFactor / 2) * 7, maxBlock = (uint64_t)0x4 * (errorFactor / 2) * 7; // src/limg.cpp:2343-2368, same values as the 8x8 path
+    bp.maxPixel32 = maxPixel > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)maxPixel;
+    bp.maxBlock = maxBlock;
+    bp.crushBits = errorFactor != 0; bp.fast = fastBitCrushing != 0;
+    const bool forced = c->opt.forced_shift[0] >= 0 && c->opt.forced_shift[0] <= 8 && c->opt.forced_shift[1] >= 0 && c->opt.forced_shift[1] <= 8 &&
+                        c->opt.forced_shift[2] >= 0 && c->opt.forced_shift[2] <= 8;
+    for (int i = 0; i < 3; i++) bp.forced[i] = forced ? c->opt.forced_shift[i] : -1;
+    bp.pass1 = (const limg_hip_block_record *)c->records.p;
+    if ((r = c->bMatch.ensure(blocks * kMatchWords * 8)) != limg_hip_success) return r;
+    bp.matchBits = (unsigned long long *)c->bMatch.p;
+    bp.info = *pInfo;
+    launch_blocked_match(bp, s);
+    HIP_TRY(hipGetLastError());
+
+    std::vector<limg_hip_block_record> hRec(blocks);
+    std::vector<unsigned long long> hBits(blocks * kMatchWords);
+    HIP_TRY(hipMemcpyAsync(hRec.data(), c->records.p, blocks * sizeof(limg_hip_block_record), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(hBits.data(), c->bMatch.p, hBits.size() * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const clk::time_point t1 = clk::now();
+
+    // the greedy raster merge (host, serial by construction; it only looks the similarity bits up)
+    blocked_merge(hRec.data(), hBits.data(), blocksX, blocksY, channels, c->lastRegions);
+    const std::vector<HostRegion> &regs = c->lastRegions;
+    const size_t nRegions = regs.size();
+    std::vector<RegionDesc> desc(nRegions);
+    std::vector<uint32_t> npx(nRegions);
+    uint64_t cap = 0;
+    for (size_t i = 0; i < nRegions; i++)
+    {
+      const HostRegion &h = regs[i];
+      size_t xpx = (size_t)h.rx * kBlock, ypx = (size_t)h.ry * kBlock;
+      if (h.ox + h.rx == blocksX && (sizeX % kBlock)) xpx = xpx - kBlock + sizeX % kBlock;
+      if (h.oy + h.ry == blocksY && (sizeY % kBlock)) ypx = ypx - kBlock + sizeY % kBlock;
+      npx[i] = (uint32_t)(xpx * ypx);
+      desc[i] = { h.ox, h.oy, h.rx, h.ry, h.keep, (uint32_t)cap, { 0, 0 } };
+      cap += ((uint64_t)npx[i] + 3) & ~3ull;
+    }
+    if (cap > 0xFFFFFFF0ull) return limg_hip_error_InvalidParameter;
+    const clk::time_point t2 = clk::now();
+
+    if ((r = c->bRegions.ensure(nRegions * sizeof(RegionDesc))) != limg_hip_success) return r;
+    if ((r = c->bOut.ensure(nRegions * sizeof(RegionOut))) != limg_hip_success) return r;
+    if ((r = c->bPx.ensure(cap * 4)) != limg_hip_success) return r;
+    if ((r = c->bV.ensure(cap * 16)) != limg_hip_success) return r;
+    if ((r = c->bFac.ensure(cap * 3)) != limg_hip_success) return r;
+    HIP_TRY(hipMemcpyAsync(c->bRegions.p, desc.data(), nRegions * sizeof(RegionDesc), hipMemcpyHostToDevice, s));
+    bp.regions = (const RegionDesc *)c->bRegions.p; bp.nRegions = (uint32_t)nRegions; bp.out = (RegionOut *)c->bOut.p;
+    bp.scratchPx = (uint32_t *)c->bPx.p; bp.scratchV = (float *)c->bV.p; bp.scratchFac = (uint8_t *)c->bFac.p; bp.scratchCap = (uint32_t)cap;
+    launch_blocked_fit_search(bp, s);
+    HIP_TRY(hipGetLastError());
+    std::vector<RegionOut> hOut(nRegions);
+    HIP_TRY(hipMemcpyAsync(hOut.data(), c->bOut.p, nRegions * sizeof(RegionOut), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s)); // also keeps `desc` alive until its upload is done
+    const clk::time_point t3 = clk::now();
+
+    // the dither chain (src/limg_internal.h:711, src/limg.cpp:1541-1551): one chain through all regions in creation order; a call over N pixels
+    // advances it by floor(N / 8) AES rounds + N % 8 PCG steps, so it is walked here, producing the byte every pixel adds
+    std::vector<unsigned long long> noiseBase(nRegions);
+    uint64_t total = 0;
+    for (size_t i = 0; i < nRegions; i++) { noiseBase[i] = total; total += (uint64_t)(hOut[i].shiftWord >> 24) * npx[i]; }
+    std::vector<uint8_t> noise(total + 64);
+    {
+      uint64_t h = kDitherSeed;
+      const bool pcg = c->opt.dither_pcg != 0;
+      for (size_t i = 0; i < nRegions; i++)
+      {
+        const uint32_t calls = hOut[i].shiftWord >> 24;
+        for (uint32_t k = 0; k < calls; k++) h = chain_call_n(h, npx[i], noise.data() + noiseBase[i] + (uint64_t)k * npx[i], pcg);
+      }
+    }
+    if ((r = c->bNoise.ensure(noise.size())) != limg_hip_success) return r;
+    if ((r = c->bNoiseBase.ensure(nRegions * 8 + 8)) != limg_hip_success) return r;
+    HIP_TRY(hipMemcpyAsync(c->bNoise.p, noise.data(), noise.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->bNoiseBase.p, noiseBase.data(), nRegions * 8, hipMemcpyHostToDevice, s));
+    bp.noise = (const uint8_t *)c->bNoise.p; bp.noiseBase = (const unsigned long long *)c->bNoiseBase.p;
+    const clk::time_point t4 = clk::now();
+    launch_blocked_store(bp, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s)); // the host vectors above die with this scope
+    const clk::time_point t5 = clk::now();
+    c->blockedMs[0] = ms(t0, t1); c->blockedMs[1] = ms(t1, t2); c->blockedMs[2] = ms(t2, t3); c->blockedMs[3] = ms(t3, t4); c->blockedMs[4] = ms(t4, t5); c->blockedMs[5] = ms(t0, t5);
+    return limg_hip_success;
+  }
+
+  limg_hip_result limg_hip_blocked_regions(limg_hip_context *c, limg_hip_region *pRegions, size_t capacity, size_t *pCount)
+  {
+    if (!c || !pCount) return limg_hip_error_ArgumentNull;
+    *pCount = c->lastRegions.size();
+    if (pRegions)
+      for (size_t i = 0; i < c->lastRegions.size() && i < capacity; i++) pRegions[i] = { c->lastRegions[i].ox, c->lastRegions[i].oy, c->lastRegions[i].rx, c->lastRegions[i].ry };
+    return limg_hip_success;
+  }
+
+  limg_hip_result limg_hip_blocked_timing(limg_hip_context *c, double *pMs6)
+  {
+    if (!c || !pMs6) return limg_hip_error_ArgumentNull;
+    memcpy(pMs6, c->blockedMs, sizeof(c->blockedMs));
+    return limg_hip_success;
+  }
+
+  limg_hip_result limg_hip_blocked_encode3d(limg_hip_context *c, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, limg_hip_blocked_encode3d_info *pInfo, uint32_t errorFactor,
+                                            int fastBitCrushing)
+  {
+    if (!c || !pIn || !pInfo) return limg_hip_error_ArgumentNull;
+    if (sizeX == 0 || sizeY == 0) return limg_hip_error_InvalidParameter;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t px = sizeX * sizeY, stride = (px * 4 + 255) & ~(size_t)255;
+    limg_hip_result r;
+    if ((r = c->in.ensure(px * 4)) != limg_hip_success) return r;
+    if ((r = c->planes.ensure(stride * 13)) != limg_hip_success) return r;
+    HIP_TRY(hipMemcpy(c->in.p, pIn, px * 4, hipMemcpyHostToDevice));
+    uint8_t *base = (uint8_t *)c->planes.p;
+    limg_hip_blocked_encode3d_info d;
+    memset(&d, 0, sizeof(d));
+    // 13 written planes, one `stride` each (the uint8 ones use a quarter of theirs)
+    void **hostp[13] = { (void **)&pInfo->pDecoded, (void **)&pInfo->pFactorsA, (void **)&pInfo->pFactorsB, (void **)&pInfo->pFactorsC, (void **)&pInfo->pBitsPerPixel,
+                         (void **)&pInfo->pShiftABCX, (void **)&pInfo->pColAMin, (void **)&pInfo->pColAMax, (void **)&pInfo->pColBMin, (void **)&pInfo->pColBMax,
+                         (void **)&pInfo->pColCMin, (void **)&pInfo->pColCMax, (void **)&pInfo->pBlockIndex };
+    void **devp[13] = { (void **)&d.pDecoded, (void **)&d.pFactorsA, (void **)&d.pFactorsB, (void **)&d.pFactorsC, (void **)&d.pBitsPerPixel, (void **)&d.pShiftABCX,
+                        (void **)&d.pColAMin, (void **)&d.pColAMax, (void **)&d.pColBMin, (void **)&d.pColBMax, (void **)&d.pColCMin, (void **)&d.pColCMax, (void **)&d.pBlockIndex };
+    const bool is8[13] = { false, true, true, true, true, false, false, false, false, false, false, false, false };
+    for (int i = 0; i < 13; i++)
+    {
+      if (!*hostp[i]) return limg_hip_error_ArgumentNull;
+      *devp[i] = base + stride * i;
+    }
+    if ((r = limg_hip_blocked_encode3d_device(c, (const uint32_t *)c->in.p, sizeX, sizeY, hasAlpha, &d, errorFactor, fastBitCrushing, nullptr)) != limg_hip_success) return r;
+    if ((r = limg_hip_check_device_status(c)) != limg_hip_success) return r;
+    for (int i = 0; i < 13; i++) HIP_TRY(hipMemcpy(*hostp[i], *devp[i], is8[i] ? px : px * 4, hipMemcpyDeviceToHost));
     return limg_hip_success;
   }
 }

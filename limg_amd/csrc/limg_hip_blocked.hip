@@ -1,0 +1,565 @@
+// limg_hip_blocked.hip -- GPU stages of the merged-block encoder (reference: limg_blocked_encode3d_test, src/limg.cpp:1774-1885, :2329-2453).
+//
+//   k_blocked_match        the block-similarity predicate `limg_encode_3d_matches` (src/limg.cpp:1137-1268) for every block as seed against
+//                          the (2 W + 1)^2 blocks around it: one wave per seed, lane = candidate, 64 pairs per step, results as ballot masks.
+//                          The host's greedy raster merge (limg_hip_blocked_host.cpp) only looks these bits up.
+//   k_blocked_fit_search   one wave per rectangle ("region") of the merge: gather (src/limg.cpp:1747-1748), channel sums, direction fit
+//                          over all N pixels of the region in row-major order (same functions as for an 8x8 block, src/limg_factorization.h
+//                          :578-794 / :382-576 with N = 64 rx ry), per-pixel factors, shift search (a7-a12 on N pixels).
+//   k_blocked_store        one wave per region: dither (noise bytes of the host's chain walk), planes (src/limg.cpp:1604-1700), decode (a16).
+//
+// Lane = pixel of a 64-pixel chunk; a region of N pixels is a loop over ceil(N / 64) chunks.  The three direction sums are serial in pixel
+// order upstream; here the per-pixel unit vectors of a pass are parked in global scratch (slot-planar, so the walkers read float4s) and
+// 4 lanes -- one per channel -- walk the N-term chains.  All arithmetic helpers are the ones of the 8x8 kernels (limg_hip_device.h).
+// Pass-1 (every 8x8 block's own fit, src/limg.cpp:1088-1119) is the 8x8 path's E step in `fitOnly` mode (limg_hip_kernels.hip).
+#include "limg_hip_device.h"
+
+namespace limg_hip
+{
+  namespace
+  {
+    __device__ __forceinline__ void scratch_fence()
+    { // a wave re-reads global scratch it (and only it) wrote: make the writes visible to its own later loads through the vector L1
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+
+    // ---- similarity predicate ---------------------------------------------------------------------------------------------------------
+    struct MState { float nA[4], nB[4], nC[4], invA, invB, invC; };
+
+    template <int CH>
+    __device__ __forceinline__ float dot_seq(const float *a, const float *b)
+    { // limg_dot (src/limg_internal.h:357-366): sum = 0; sum += a[i] * b[i]
+      float sum = 0.0f;
+#pragma unroll
+      for (int i = 0; i < CH; i++) sum += a[i] * b[i];
+      return sum;
+    }
+
+    template <int CH>
+    __device__ __forceinline__ void m_init(const limg_hip_block_record &r, MState &s)
+    { // src/limg_internal.h:426-452
+      bool nzA = false, nzB = false, nzC = false;
+#pragma unroll
+      for (int i = 0; i < 4; i++) { s.nA[i] = 0.0f; s.nB[i] = 0.0f; s.nC[i] = 0.0f; }
+#pragma unroll
+      for (int i = 0; i < CH; i++)
+      {
+        s.nA[i] = (float)((int)r.dirA_max[i] - (int)r.dirA_min[i]);
+        s.nB[i] = (float)((int)r.dirB_mag[i] - (int)r.dirB_offset[i]);
+        s.nC[i] = (float)((int)r.dirC_mag[i] - (int)r.dirC_offset[i]);
+        nzA |= s.nA[i] != 0; nzB |= s.nB[i] != 0; nzC |= s.nC[i] != 0;
+      }
+      s.invA = nzA ? 1.0f / dot_seq<CH>(s.nA, s.nA) : 0.0f;
+      s.invB = nzB ? 1.0f / dot_seq<CH>(s.nB, s.nB) : 0.0f;
+      s.invC = nzC ? 1.0f / dot_seq<CH>(s.nC, s.nC) : 0.0f;
+    }
+
+    template <int CH>
+    __device__ __forceinline__ void m_factors(const float *color, const limg_hip_block_record &in, const MState &s, float f[3])
+    { // src/limg_factorization.h:9-42
+      float t[4], est[4];
+#pragma unroll
+      for (int i = 0; i < CH; i++) t[i] = color[i] - (float)in.dirA_min[i];
+      f[0] = dot_seq<CH>(t, s.nA) * s.invA;
+#pragma unroll
+      for (int i = 0; i < CH; i++) { est[i] = (float)in.dirA_min[i] + f[0] * s.nA[i]; t[i] = (color[i] - est[i]) - (float)in.dirB_offset[i]; }
+      f[1] = dot_seq<CH>(t, s.nB) * s.invB;
+#pragma unroll
+      for (int i = 0; i < CH; i++) { est[i] = est[i] + f[1] * s.nB[i]; t[i] = (color[i] - est[i]) - (float)in.dirC_offset[i]; }
+      f[2] = dot_seq<CH>(t, s.nC) * s.invC;
+    }
+
+    // src/limg.cpp:1137-1268; same operations in the same order as blocked_matches_host
+    template <int CH>
+    __device__ bool m_matches(const limg_hip_block_record &a, const limg_hip_block_record &b)
+    {
+      MState sa, sb;
+      m_init<CH>(a, sa);
+      m_init<CH>(b, sb);
+      const float w[4] = { 2, 4, 3, 3 };
+      float avgDiffSq = 0, lenA[3] = { 3, 3, 3 }, lenB[3] = { 3, 3, 3 };
+#pragma unroll
+      for (int i = 0; i < CH; i++)
+      {
+        const float d = a.avg[i] - b.avg[i];
+        avgDiffSq += d * d * w[i];
+        lenA[0] += (sa.nA[i] * sa.nA[i]) * w[i]; lenB[0] += (sb.nA[i] * sb.nA[i]) * w[i];
+        lenA[1] += (sa.nB[i] * sa.nB[i]) * w[i]; lenB[1] += (sb.nB[i] * sb.nB[i]) * w[i];
+        lenA[2] += (sa.nC[i] * sa.nC[i]) * w[i]; lenB[2] += (sb.nC[i] * sb.nC[i]) * w[i];
+      }
+      const float sumA = lenA[0] + lenA[1] + lenA[2], sumB = lenB[0] + lenB[1] + lenB[2];
+      const float ratio = (sumA + 1) / (sumB + 1);
+      const float maxAvg = (float)(16 * 3 * CH), maxRange = (float)(200 * 3 * CH);
+      if (avgDiffSq < maxAvg && sumA < maxRange && sumB < maxRange) return true;
+      if (ratio > 1.375f || ratio < (1.f / 1.375f)) return false;
+      float invA[3], invB[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) { invA[i] = 1.0f / lenA[i]; invB[i] = 1.0f / lenB[i]; }
+#pragma unroll
+      for (int i = 1; i < 3; i++) { invA[i] *= 2.f; invB[i] *= 2.f; }
+      float fb[3];
+      m_factors<CH>(a.avg, b, sb, fb);
+      const float termB = fabsf(fb[0]) * invB[0] + fabsf(0.5f - fb[1]) * invB[1] + fabsf(0.5f - fb[2]) * invB[2];
+      float sum = 0;
+#pragma unroll 1
+      for (int z = 0; z < 3; z++)
+#pragma unroll 1
+        for (int y = 0; y < 3; y++)
+#pragma unroll
+          for (int x = 0; x < 3; x++)
+          {
+            const float xf = x * 0.5f, yf = y * 0.5f, zf = z * 0.5f;
+            float color[4], fa[3];
+#pragma unroll
+            for (int i = 0; i < CH; i++) color[i] = sb.nA[i] * xf + sb.nB[i] * yf + sb.nC[i] * zf;
+            m_factors<CH>(color, a, sa, fa);
+            sum += fabsf(fa[0]) * invA[0] + fabsf(0.5f - fa[1]) * invA[1] + fabsf(0.5f - fa[2]) * invA[2];
+            sum += termB;
+          }
+      return sum * (1.f / 27) < 3.0f;
+    }
+
+    template <int CH>
+    __global__ __launch_bounds__(256) void k_blocked_match(const BlockedParams p)
+    {
+      const uint32_t nBlocks = p.blocksX * p.blocksY;
+      const uint32_t seed = blockIdx.x * 4 + (threadIdx.x >> 6);
+      const int lane = lane_id();
+      if (seed >= nBlocks) return;
+      const uint32_t sy = seed / p.blocksX, sx = seed - sy * p.blocksX;
+      const limg_hip_block_record a = p.pass1[seed];
+      constexpr int side = 2 * kMatchWindow + 1;
+      for (int c = 0; c < kMatchWords; c++)
+      {
+        const int cell = c * 64 + lane;
+        const int dy = cell / side - kMatchWindow, dx = cell - (cell / side) * side - kMatchWindow;
+        const uint32_t cx = sx + (uint32_t)dx, cy = sy + (uint32_t)dy; // wraps for negative offsets => fails the range test
+        bool m = false;
+        if (cell < kMatchCells && (dx | dy) != 0 && cx < p.blocksX && cy < p.blocksY) m = m_matches<CH>(a, p.pass1[(size_t)cy * p.blocksX + cx]);
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(m);
+        if (lane == 0) p.matchBits[(size_t)seed * kMatchWords + c] = mask;
+      }
+    }
+
+    // ---- regions ----------------------------------------------------------------------------------------------------------------------
+    struct Geo { uint32_t px0, py0, xpx, ypx, n; };
+
+    __device__ __forceinline__ Geo region_geo(const BlockedParams &p, const RegionDesc &R)
+    { // src/limg.cpp:1722-1740: the last block column / row may be partial
+      Geo g;
+      g.px0 = R.ox * kBlock; g.py0 = R.oy * kBlock;
+      g.xpx = R.rx * kBlock; g.ypx = R.ry * kBlock;
+      if (R.ox + R.rx == p.blocksX && (p.sizeX % kBlock)) g.xpx = g.xpx - kBlock + p.sizeX % kBlock;
+      if (R.oy + R.ry == p.blocksY && (p.sizeY % kBlock)) g.ypx = g.ypx - kBlock + p.sizeY % kBlock;
+      g.n = g.xpx * g.ypx;
+      return g;
+    }
+
+    __device__ __forceinline__ float bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+    // 64-bit sum over the wave of per-lane 64-bit values whose wave total stays far below 2^63
+    __device__ __forceinline__ uint64_t wave_sum64(uint64_t v)
+    {
+      const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+      return (uint64_t)wave_sum(lo & 0xFFFFu) + ((uint64_t)wave_sum(lo >> 16) << 16) + ((uint64_t)wave_sum(hi) << 32);
+    }
+
+    template <int CH>
+    __global__ __launch_bounds__(64) void k_blocked_fit_search(const BlockedParams p)
+    {
+      const uint32_t r = blockIdx.x;
+      const int lane = lane_id();
+      const RegionDesc R = p.regions[r];
+      const Geo g = region_geo(p, R);
+      const uint32_t n = g.n, cap = p.scratchCap;
+      uint32_t *spx = p.scratchPx + R.scratch;
+      float *sv = p.scratchV + R.scratch;
+      uint8_t *sf = p.scratchFac + R.scratch;
+      const unsigned short *tab = d_rsqrt_x86_tab;
+
+      // ---- gather (row-major inside the region) + channel sums (32-bit lanes like the reference's, src/limg.cpp:466-497) ----------------
+      uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+      for (uint32_t i = lane; i < n; i += 64)
+      {
+        const uint32_t row = i / g.xpx, col = i - row * g.xpx;
+        const uint32_t px = p.in[(size_t)(g.py0 + row) * p.sizeX + g.px0 + col];
+        spx[i] = px;
+        s0 += px & 0xFF; s1 += (px >> 8) & 0xFF; s2 += (px >> 16) & 0xFF; s3 += px >> 24;
+      }
+      scratch_fence();
+
+      limg_hip_block_record rec;
+      memset(&rec, 0, sizeof(rec));
+      if (R.keep)
+      {
+        rec = p.pass1[(size_t)R.oy * p.blocksX + R.ox];
+      }
+      else
+      {
+        s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+        const float inv_count = 1.0f / (float)n;
+        V4 avg;
+        avg.a = float2_t{ (float)(int)s0, (float)(int)s2 } * inv_count;
+        avg.b = float2_t{ (float)(int)s1, CH == 4 ? (float)(int)s3 : 0.0f } * inv_count;
+        const V4 zero4 = { float2_t{ 0.0f, 0.0f }, float2_t{ 0.0f, 0.0f } };
+        V4 dirA = zero4, dirB = zero4, dirC = zero4;
+        float mm[6] = { 0, 0, 0, 0, 0, 0 };
+        bool zeroA = true, zeroB = true, zeroC = true;
+
+        auto park = [&](uint32_t i, const V4 &u) { sv[i] = u.a.x; sv[(size_t)cap + i] = u.a.y; sv[2 * (size_t)cap + i] = u.b.x; sv[3 * (size_t)cap + i] = u.b.y; };
+        // pixel-order sum of the parked vectors: lane s (< 4) walks slot plane s; slot order x0 x2 x1 x3 (see V4)
+        auto serial_sum = [&]() -> V4 {
+          scratch_fence();
+          float s = 0.0f;
+          if (lane < 4)
+          {
+            const float *src = sv + (size_t)lane * cap;
+            uint32_t i = 0;
+            for (; i + 4 <= n; i += 4)
+            {
+              const float4 v = *reinterpret_cast<const float4 *>(src + i); // R.scratch and cap are multiples of 4
+              s = s + v.x; s = s + v.y; s = s + v.z; s = s + v.w;
+            }
+            for (; i < n; i++) s = s + src[i];
+          }
+          s = s * inv_count;
+          V4 d;
+          d.a = float2_t{ bcast(s, 0), bcast(s, 1) };
+          d.b = float2_t{ bcast(s, 2), bcast(s, 3) };
+          return d;
+        };
+        auto is_zero = [](const V4 &d) { return d.a.x == 0.0f && d.a.y == 0.0f && d.b.x == 0.0f && d.b.y == 0.0f; };
+
+        // pass 1 (src/limg_factorization.h:602-628 / :402-431)
+        for (uint32_t base = 0; base < n; base += 64)
+        {
+          const uint32_t i = base + lane;
+          const bool active = i < n;
+          const V4 pf = px_to_v4(active ? spx[i] : 0u);
+          V4 d = pf - avg;
+          mask_alpha<CH>(d);
+          const V4 u = unit4<CH>(tab, d, active);
+          if (active) park(i, u);
+        }
+        dirA = serial_sum();
+        zeroA = is_zero(dirA);
+        if (!zeroA)
+        {
+          const float invA = 1.0f / dp4<CH>(dirA, dirA);
+          // pass 2 (:652-688 / :451-491)
+          float mn = 0.0f, mx = 0.0f;
+          for (uint32_t base = 0; base < n; base += 64)
+          {
+            const uint32_t i = base + lane;
+            const bool active = i < n;
+            const V4 pf = px_to_v4(active ? spx[i] : 0u);
+            const float fA = dp4<CH>(pf - avg, dirA) * invA;
+            if (active) { mn = vmin(mn, fA); mx = vmax(mx, fA); }
+            V4 e = pf - (avg + dirA * fA);
+            mask_alpha<CH>(e);
+            const V4 u = unit4<CH>(tab, e, active);
+            if (active) park(i, u);
+          }
+          wave_min_max(mn, mx);
+          mm[0] = mn; mm[1] = mx;
+          dirB = serial_sum();
+          zeroB = is_zero(dirB);
+          if (!zeroB)
+          {
+            const float invB = 1.0f / dp4<CH>(dirB, dirB);
+            float mnB = FLT_MAX, mxB = -FLT_MAX, mnC = FLT_MAX, mxC = -FLT_MAX;
+            if (CH == 4)
+            {
+              // pass 3 (:701-738)
+              V4 est0 = zero4;
+              for (uint32_t base = 0; base < n; base += 64)
+              {
+                const uint32_t i = base + lane;
+                const bool active = i < n;
+                const V4 pf = px_to_v4(active ? spx[i] : 0u);
+                const float fA = dp4<CH>(pf - avg, dirA) * invA;
+                const V4 est = avg + dirA * fA;
+                const float fB = dp4<CH>(pf - est, dirB) * invB;
+                if (active) { mnB = vmin(mnB, fB); mxB = vmax(mxB, fB); }
+                const V4 est2 = est + dirB * fB;
+                const V4 u = unit4<CH>(tab, pf - est2, active);
+                if (active) park(i, u);
+                if (base == 0) est0 = est2;
+              }
+              wave_min_max(mnB, mxB);
+              est0.a = float2_t{ bcast(est0.a.x, 0), bcast(est0.a.y, 0) };
+              est0.b = float2_t{ bcast(est0.b.x, 0), bcast(est0.b.y, 0) };
+              dirC = serial_sum();
+              zeroC = is_zero(dirC);
+              if (!zeroC)
+              {
+                // pass 4 (:748-758): upstream never advances its estimate pointer -- every pixel is measured against pixel 0's A+B estimate
+                const float invC = 1.0f / dp4<CH>(dirC, dirC);
+                for (uint32_t base = 0; base < n; base += 64)
+                {
+                  const uint32_t i = base + lane;
+                  const bool active = i < n;
+                  const V4 pf = px_to_v4(active ? spx[i] : 0u);
+                  const float fC = dp4<CH>(pf - est0, dirC) * invC;
+                  if (active) { mnC = vmin(mnC, fC); mxC = vmax(mxC, fC); }
+                }
+                wave_min_max(mnC, mxC);
+              }
+            }
+            else
+            {
+              // dirC = dirA x dirB (:498-507); slots: a = (x0, x2), b = (x1, x3); pass 3 (:517-541): B and C extrema together
+              dirC.a.x = dirA.b.x * dirB.a.y - dirA.a.y * dirB.b.x;
+              dirC.b.x = dirA.a.y * dirB.a.x - dirA.a.x * dirB.a.y;
+              dirC.a.y = dirA.a.x * dirB.b.x - dirA.b.x * dirB.a.x;
+              dirC.b.y = 0.0f;
+              zeroC = dirC.a.x == 0.0f && dirC.b.x == 0.0f && dirC.a.y == 0.0f;
+              const float invC = zeroC ? 0.0f : 1.0f / dp4<CH>(dirC, dirC);
+              for (uint32_t base = 0; base < n; base += 64)
+              {
+                const uint32_t i = base + lane;
+                const bool active = i < n;
+                const V4 pf = px_to_v4(active ? spx[i] : 0u);
+                const float fA = dp4<CH>(pf - avg, dirA) * invA;
+                const V4 est = avg + dirA * fA;
+                const float fB = dp4<CH>(pf - est, dirB) * invB;
+                if (active) { mnB = vmin(mnB, fB); mxB = vmax(mxB, fB); }
+                if (!zeroC)
+                {
+                  const V4 e = pf - (est + dirB * fB);
+                  const float fC = dp4<CH>(e, dirC) * invC;
+                  if (active) { mnC = vmin(mnC, fC); mxC = vmax(mxC, fC); }
+                }
+              }
+              wave_min_max(mnB, mxB);
+              if (!zeroC) wave_min_max(mnC, mxC);
+            }
+            mm[2] = mnB; mm[3] = mxB;
+            if (!zeroC) { mm[4] = mnC; mm[5] = mxC; }
+          }
+        }
+        // records (:764-790 / :545-575).  A direction that is exactly zero makes upstream divide by zero: every factor of that pass and of the
+        // later ones is NaN and the x86 conversion yields int16 0; same rule as the 8x8 kernel.
+        const float av[4] = { avg.a.x, avg.b.x, avg.a.y, avg.b.y };
+        const float dA[4] = { dirA.a.x, dirA.b.x, dirA.a.y, dirA.b.y }, dB[4] = { dirB.a.x, dirB.b.x, dirB.a.y, dirB.b.y }, dC[4] = { dirC.a.x, dirC.b.x, dirC.a.y, dirC.b.y };
+        const bool deadA = zeroA, deadB = zeroA || zeroB, deadC = deadB || zeroC;
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+        {
+          rec.avg[c] = (CH == 3 && c == 3) ? 0.0f : av[c];
+          if (CH == 3 && c == 3) continue;
+          rec.dirA_min[c] = (int16_t)cvt_rne(av[c] + (deadA ? 0.0f : mm[0] * dA[c]));
+          rec.dirA_max[c] = (int16_t)cvt_rne(av[c] + (deadA ? 0.0f : mm[1] * dA[c]));
+          rec.dirB_offset[c] = (int16_t)cvt_rne(deadB ? 0.0f : mm[2] * dB[c]);
+          rec.dirB_mag[c] = (int16_t)cvt_rne(deadB ? 0.0f : mm[3] * dB[c]);
+          rec.dirC_offset[c] = (int16_t)cvt_rne(deadC ? 0.0f : mm[4] * dC[c]);
+          rec.dirC_mag[c] = (int16_t)cvt_rne(deadC ? 0.0f : mm[5] * dC[c]);
+        }
+      }
+
+      // ---- a7 (src/limg_internal.h:426-452): float normals, 1 / |n|^2 in limg_dot's serial order ---------------------------------------
+      const int16_t *lo3[3] = { rec.dirA_min, rec.dirB_offset, rec.dirC_offset }, *hi3[3] = { rec.dirA_max, rec.dirB_mag, rec.dirC_mag };
+      V4 nrm[3], off[3];
+      float invN[3];
+      RecU ru;
+#pragma unroll
+      for (int f = 0; f < 3; f++)
+      {
+        float nv[4], ov[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) { nv[c] = (float)((int)hi3[f][c] - (int)lo3[f][c]); ov[c] = (float)lo3[f][c]; }
+        float s = ((0.0f + nv[0] * nv[0]) + nv[1] * nv[1]) + nv[2] * nv[2];
+        if (CH == 4) s = s + nv[3] * nv[3];
+        const bool nz = nv[0] != 0.0f || nv[1] != 0.0f || nv[2] != 0.0f || (CH == 4 && nv[3] != 0.0f);
+        invN[f] = nz ? 1.0f / s : 0.0f;
+        nrm[f].a = float2_t{ nv[0], nv[2] }; nrm[f].b = float2_t{ nv[1], nv[3] };
+        off[f].a = float2_t{ ov[0], ov[2] }; off[f].b = float2_t{ ov[1], ov[3] };
+      }
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+      {
+        ru.nA[c] = (int)rec.dirA_max[c] - (int)rec.dirA_min[c]; ru.nB[c] = (int)rec.dirB_mag[c] - (int)rec.dirB_offset[c]; ru.nC[c] = (int)rec.dirC_mag[c] - (int)rec.dirC_offset[c];
+        ru.mA[c] = (int)(((uint32_t)(int)rec.dirA_min[c] << 8) + 128u); ru.mB[c] = (int)(((uint32_t)(int)rec.dirB_offset[c] << 8) + 128u);
+        ru.mC[c] = (int)(((uint32_t)(int)rec.dirC_offset[c] << 8) + 128u);
+      }
+
+      // ---- a8 (src/limg_factorization.h:98-197): per-pixel factor bytes -> scratch ------------------------------------------------------
+      for (uint32_t base = 0; base < n; base += 64)
+      {
+        const uint32_t i = base + lane;
+        if (i >= n) continue;
+        const V4 pv = px_to_v4(spx[i]);
+        const float fa = dp4<CH>(pv - off[0], nrm[0]) * invN[0];
+        V4 est = off[0] + nrm[0] * fa;
+        const float fb = dp4<CH>((pv - est) - off[1], nrm[1]) * invN[1];
+        est = est + nrm[1] * fb;
+        const float fc = dp4<CH>((pv - est) - off[2], nrm[2]) * invN[2];
+        sf[i] = (uint8_t)med3_i32(cvt_rne(255.0f * fa), 0, 255);
+        sf[(size_t)cap + i] = (uint8_t)med3_i32(cvt_rne(255.0f * fb), 0, 255);
+        sf[2 * (size_t)cap + i] = (uint8_t)med3_i32(cvt_rne(255.0f * fc), 0, 255);
+      }
+      scratch_fence();
+
+      // ---- a9-a12: shift search over the region's N pixels ---------------------------------------------------------------------------------
+      uint32_t shift[3] = { 0, 0, 0 };
+      if (p.forced[0] >= 0)
+      {
+        shift[0] = (uint32_t)p.forced[0]; shift[1] = (uint32_t)p.forced[1]; shift[2] = (uint32_t)p.forced[2];
+      }
+      else if (p.crushBits)
+      {
+        const uint64_t maxBlockN = p.maxBlock * (uint64_t)n;
+        auto T = [&](uint32_t a, uint32_t b, uint32_t c, uint64_t &be) -> bool {
+          uint64_t acc = 0;
+          for (uint32_t base = 0; base < n; base += 64)
+          {
+            const uint32_t i = base + lane;
+            uint32_t err = 0;
+            if (i < n) err = trial_error(spx[i], sf[i], sf[(size_t)cap + i], sf[2 * (size_t)cap + i], ru, a, b, c);
+            if (__builtin_amdgcn_ballot_w64(err > p.maxPixel32) != 0ull) return false; // src/limg_bit_crush_simd.h:772-781: first offending pixel ends the trial
+            acc += err;
+          }
+          be = wave_sum64(acc);
+          return be * 16ull < maxBlockN;
+        };
+        if (p.fast) search_fast<uint64_t>(T, shift);
+        else search_accurate<uint64_t>(T, shift);
+      }
+      const uint32_t calls = (shift[0] && shift[0] != 8 ? 1u : 0u) + (shift[1] && shift[1] != 8 ? 1u : 0u) + (shift[2] && shift[2] != 8 ? 1u : 0u);
+      if (lane == 0)
+      {
+        RegionOut o;
+        o.rec = rec;
+        o.shiftWord = shift[0] | (shift[1] << 8) | (shift[2] << 16) | (calls << 24);
+        o.pad[0] = o.pad[1] = o.pad[2] = 0;
+        p.out[r] = o;
+      }
+    }
+
+    template <int CH>
+    __global__ __launch_bounds__(64) void k_blocked_store(const BlockedParams p)
+    {
+      const uint32_t r = blockIdx.x;
+      const int lane = lane_id();
+      const RegionDesc R = p.regions[r];
+      const Geo g = region_geo(p, R);
+      const uint32_t n = g.n, cap = p.scratchCap;
+      const uint8_t *sf = p.scratchFac + R.scratch;
+      const RegionOut O = p.out[r];
+      const limg_hip_block_record &rec = O.rec;
+      const uint32_t shift[3] = { O.shiftWord & 0xFF, (O.shiftWord >> 8) & 0xFF, (O.shiftWord >> 16) & 0xFF };
+
+      // block-uniform plane values (src/limg.cpp:1604-1627) and the decoder's constants (src/limg_decode.h:139-196 / :40-101)
+      const int16_t *vec[6] = { rec.dirA_min, rec.dirA_max, rec.dirB_offset, rec.dirB_mag, rec.dirC_offset, rec.dirC_mag };
+      uint32_t col[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++)
+      {
+        uint32_t v = 0;
+#pragma unroll
+        for (int c = 0; c < CH; c++)
+        {
+          int q = (int)vec[k][c] + (k >= 2 ? 0x80 : 0);
+          q = q < 0 ? 0 : (q > 255 ? 255 : q);
+          v |= (uint32_t)q << (8 * c);
+        }
+        if (CH == 3) v |= 0xFF000000u;
+        col[k] = v;
+      }
+      const uint32_t pa = shift[0] == 8 ? 0xFFu : shift[0] * 0x22u, pb = shift[1] == 8 ? 0xFFu : shift[1] * 0x22u, pc = shift[2] == 8 ? 0xFFu : shift[2] * 0x22u;
+      const uint32_t shiftVal = 0xFF000000u | (pa << 16) | (pb << 8) | pc;
+      // src/limg.cpp:1629-1636: 110 / 136 header bits + (8 - shift) bits per factor and pixel, per-pixel average rounded to nearest
+      const uint64_t bits = (uint64_t)(CH * 18 + CH * 8 + 32) + (uint64_t)n * ((8 - shift[0]) + (8 - shift[1]) + (8 - shift[2]));
+      const uint8_t bpp = (uint8_t)((bits + n / 2) / n);
+      const uint32_t blockIndex = 0xFF000000u | (r + 1u);
+      int nn[3][4], mc[3][4];
+#pragma unroll
+      for (int f = 0; f < 3; f++)
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+        {
+          int nv = (int)vec[2 * f + 1][c] - (int)vec[2 * f][c], m = (int)vec[2 * f][c];
+          if (c < 3) { if (shift[f] > 7) { nv = 0; if (f > 0) m = 0; } }
+          else if (CH == 3) { nv = 0; m = 0xFFFF; }
+          nn[f][c] = nv;
+          mc[f][c] = (int)(((uint32_t)m << 8) + 128u);
+        }
+      const int mulA = (int)shift_mul(shift[0]), mulB = (int)shift_mul(shift[1]), mulC = (int)shift_mul(shift[2]);
+      // noise: one byte per pixel per dither call, the region's calls back to back in A, B, C order
+      const uint8_t *nz[3];
+      {
+        const uint8_t *q = p.noise + p.noiseBase[r];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+        {
+          nz[k] = q;
+          if (shift[k] != 0 && shift[k] != 8) q += n;
+        }
+      }
+
+      for (uint32_t base = 0; base < n; base += 64)
+      {
+        const uint32_t i = base + lane;
+        if (i >= n) continue;
+        const uint32_t row = i / g.xpx, colx = i - row * g.xpx;
+        const size_t o = (size_t)(g.py0 + row) * p.sizeX + g.px0 + colx;
+        uint32_t v[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+        {
+          uint32_t f = sf[(size_t)k * cap + i];
+          const uint32_t s = shift[k];
+          if (s != 0 && s != 8)
+          { // src/limg.cpp:824-879: (lane16 & ditherSize) - ditherOffset, add, clamp, shift
+            int t = (int)f + ((int)(nz[k][i] & ((1u << s) - 1u)) - (int)(1u << (s - 1)));
+            t = t < 0 ? 0 : (t > 255 ? 255 : t);
+            f = (uint32_t)t >> s;
+          }
+          v[k] = f;
+        }
+        p.info.pFactorsA[o] = (uint8_t)(v[0] << shift[0]); // shift 8 => 0, like the uint8 store upstream
+        p.info.pFactorsB[o] = (uint8_t)(v[1] << shift[1]);
+        p.info.pFactorsC[o] = (uint8_t)(v[2] << shift[2]);
+        p.info.pBitsPerPixel[o] = bpp;
+        p.info.pShiftABCX[o] = shiftVal;
+        p.info.pColAMin[o] = col[0]; p.info.pColAMax[o] = col[1]; p.info.pColBMin[o] = col[2];
+        p.info.pColBMax[o] = col[3]; p.info.pColCMin[o] = col[4]; p.info.pColCMax[o] = col[5];
+        p.info.pBlockIndex[o] = blockIndex;
+        // a16
+        const int dA = (int)v[0] * mulA, dB = (int)v[1] * mulB, dC = (int)v[2] * mulC;
+        uint32_t decoded = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+        {
+          int est = (mad_i24(dA, nn[0][c], mc[0][c]) >> 8) + (mad_i24(dB, nn[1][c], mc[1][c]) >> 8) + (mad_i24(dC, nn[2][c], mc[2][c]) >> 8);
+          est = est < 0 ? 0 : (est > 255 ? 255 : est);
+          decoded |= (uint32_t)est << (8 * c);
+        }
+        p.info.pDecoded[o] = decoded;
+      }
+    }
+  }
+
+  void launch_blocked_match(const BlockedParams &p, hipStream_t s)
+  {
+    const uint32_t nBlocks = p.blocksX * p.blocksY;
+    const dim3 grid((nBlocks + 3) / 4), block(256);
+    if (p.channels == 4) hipLaunchKernelGGL(k_blocked_match<4>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(k_blocked_match<3>, grid, block, 0, s, p);
+  }
+
+  void launch_blocked_fit_search(const BlockedParams &p, hipStream_t s)
+  {
+    if (p.nRegions == 0) return;
+    if (p.channels == 4) hipLaunchKernelGGL(k_blocked_fit_search<4>, dim3(p.nRegions), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(k_blocked_fit_search<3>, dim3(p.nRegions), dim3(64), 0, s, p);
+  }
+
+  void launch_blocked_store(const BlockedParams &p, hipStream_t s)
+  {
+    if (p.nRegions == 0) return;
+    if (p.channels == 4) hipLaunchKernelGGL(k_blocked_store<4>, dim3(p.nRegions), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(k_blocked_store<3>, dim3(p.nRegions), dim3(64), 0, s, p);
+  }
+}

@@ -1,0 +1,219 @@
+// limg_hip_blocked_host.cpp -- host stages of the merged-block encoder (reference: limg_blocked_encode3d_test, src/limg.cpp:1774-1885).
+//
+// The reference merges 8x8 blocks greedily in raster order: a seed block grows a rectangle right / down (and, for a second attempt
+// from the centre third, in all four directions) while every block of the next row / column strip is unused and "matches" the seed
+// (src/limg.cpp:1288-1496).  Which rectangle a seed gets depends on everything claimed before it, so the scan itself is serial; the
+// expensive part -- the similarity predicate, ~2500 flops a pair -- is not: the GPU evaluates it for every block against its
+// (2 W + 1)^2 neighbourhood (k_blocked_match) and this scan only looks bits up.  Pairs farther apart than W blocks are evaluated
+// here, with the same float operations in the same order (built with -ffp-contract=off, like the kernels).
+//
+// Host-only translation unit (no HIP).
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/limg_hip.h"
+
+namespace limg_hip
+{
+  constexpr int kMatchWindow = 8; // keep in sync with limg_hip_internal.h
+  constexpr int kMatchSide = 2 * kMatchWindow + 1;
+  constexpr int kMatchWords = (kMatchSide * kMatchSide + 63) / 64;
+
+  struct HostRegion { uint32_t ox, oy, rx, ry, keep; };
+
+  uint64_t chain_call(uint64_t h, unsigned n, uint8_t *noise, bool forceSoft, bool pcg); // limg_hip_noise.cpp (any n; `noise` holds n bytes)
+
+  namespace
+  {
+    // limg_color_error_state_3d (src/limg_internal.h:426-452) with limg_dot's serial order (:357-366)
+    struct State { float nA[4], nB[4], nC[4], invA, invB, invC; };
+
+    inline float dot(const float *a, const float *b, int ch)
+    {
+      float sum = 0.0f;
+      for (int i = 0; i < ch; i++) sum += a[i] * b[i];
+      return sum;
+    }
+
+    void init_state(const limg_hip_block_record &r, int ch, State &s)
+    {
+      memset(&s, 0, sizeof(s));
+      bool nz[3] = { false, false, false };
+      for (int i = 0; i < ch; i++)
+      {
+        s.nA[i] = (float)((int)r.dirA_max[i] - (int)r.dirA_min[i]);
+        s.nB[i] = (float)((int)r.dirB_mag[i] - (int)r.dirB_offset[i]);
+        s.nC[i] = (float)((int)r.dirC_mag[i] - (int)r.dirC_offset[i]);
+        nz[0] |= s.nA[i] != 0; nz[1] |= s.nB[i] != 0; nz[2] |= s.nC[i] != 0;
+      }
+      if (nz[0]) s.invA = 1.0f / dot(s.nA, s.nA, ch);
+      if (nz[1]) s.invB = 1.0f / dot(s.nB, s.nB, ch);
+      if (nz[2]) s.invC = 1.0f / dot(s.nC, s.nC, ch);
+    }
+
+    // src/limg_factorization.h:9-42
+    void colour_factors(const float *color, const limg_hip_block_record &in, const State &s, int ch, float f[3])
+    {
+      float t[4], est[4];
+      for (int i = 0; i < ch; i++) t[i] = color[i] - (float)in.dirA_min[i];
+      f[0] = dot(t, s.nA, ch) * s.invA;
+      for (int i = 0; i < ch; i++) { est[i] = (float)in.dirA_min[i] + f[0] * s.nA[i]; t[i] = (color[i] - est[i]) - (float)in.dirB_offset[i]; }
+      f[1] = dot(t, s.nB, ch) * s.invB;
+      for (int i = 0; i < ch; i++) { est[i] = est[i] + f[1] * s.nB[i]; t[i] = (color[i] - est[i]) - (float)in.dirC_offset[i]; }
+      f[2] = dot(t, s.nC, ch) * s.invC;
+    }
+  }
+
+  // limg_encode_3d_matches (src/limg.cpp:1137-1268)
+  bool blocked_matches_host(int ch, const limg_hip_block_record &a, const limg_hip_block_record &b)
+  {
+    State sa, sb;
+    init_state(a, ch, sa);
+    init_state(b, ch, sb);
+    const float w[4] = { 2, 4, 3, 3 };
+    float avgDiffSq = 0, lenA[3] = { 3, 3, 3 }, lenB[3] = { 3, 3, 3 };
+    for (int i = 0; i < ch; i++)
+    {
+      const float d = a.avg[i] - b.avg[i];
+      avgDiffSq += d * d * w[i];
+      lenA[0] += (sa.nA[i] * sa.nA[i]) * w[i]; lenB[0] += (sb.nA[i] * sb.nA[i]) * w[i];
+      lenA[1] += (sa.nB[i] * sa.nB[i]) * w[i]; lenB[1] += (sb.nB[i] * sb.nB[i]) * w[i];
+      lenA[2] += (sa.nC[i] * sa.nC[i]) * w[i]; lenB[2] += (sb.nC[i] * sb.nC[i]) * w[i];
+    }
+    const float sumA = lenA[0] + lenA[1] + lenA[2], sumB = lenB[0] + lenB[1] + lenB[2];
+    const float ratio = (sumA + 1) / (sumB + 1);
+    const float maxAvg = (float)(16 * 3 * ch), maxRange = (float)(200 * 3 * ch);
+    if (avgDiffSq < maxAvg && sumA < maxRange && sumB < maxRange) return true;
+    if (ratio > 1.375f || ratio < (1.f / 1.375f)) return false;
+    float invA[3], invB[3];
+    for (int i = 0; i < 3; i++) { invA[i] = 1.0f / lenA[i]; invB[i] = 1.0f / lenB[i]; }
+    for (int i = 1; i < 3; i++) { invA[i] *= 2.f; invB[i] *= 2.f; }
+    float fb[3];
+    colour_factors(a.avg, b, sb, ch, fb); // loop-invariant upstream (:1236-1239 builds a colour it then does not pass)
+    const float termB = fabsf(fb[0]) * invB[0] + fabsf(0.5f - fb[1]) * invB[1] + fabsf(0.5f - fb[2]) * invB[2];
+    float sum = 0, color[4], fa[3];
+    for (int z = 0; z < 3; z++)
+      for (int y = 0; y < 3; y++)
+        for (int x = 0; x < 3; x++)
+        {
+          const float xf = x * 0.5f, yf = y * 0.5f, zf = z * 0.5f;
+          for (int i = 0; i < ch; i++) color[i] = sb.nA[i] * xf + sb.nB[i] * yf + sb.nC[i] * zf;
+          colour_factors(color, a, sa, ch, fa);
+          sum += fabsf(fa[0]) * invA[0] + fabsf(0.5f - fa[1]) * invA[1] + fabsf(0.5f - fa[2]) * invA[2];
+          sum += termB;
+        }
+    return sum * (1.f / 27) < 3.0f;
+  }
+
+  namespace
+  {
+    struct Merge
+    {
+      const limg_hip_block_record *rec;
+      const unsigned long long *bits;
+      uint32_t bx, by;
+      int ch;
+      std::vector<uint8_t> used;
+
+      bool match(size_t sx, size_t sy, size_t cx, size_t cy) const
+      {
+        const long dx = (long)cx - (long)sx, dy = (long)cy - (long)sy;
+        if (bits && dx >= -kMatchWindow && dx <= kMatchWindow && dy >= -kMatchWindow && dy <= kMatchWindow)
+        {
+          const unsigned cell = (unsigned)((dy + kMatchWindow) * kMatchSide + (dx + kMatchWindow));
+          return (bits[(sy * bx + sx) * kMatchWords + (cell >> 6)] >> (cell & 63)) & 1ull;
+        }
+        return blocked_matches_host(ch, rec[sy * bx + sx], rec[cy * bx + cx]);
+      }
+      // src/limg.cpp:1121-1135 and :1271-1286 for one strip of blocks
+      bool strip_ok(size_t sx, size_t sy, size_t ox, size_t oy, size_t rx, size_t ry) const
+      {
+        for (size_t y = 0; y < ry; y++)
+          for (size_t x = 0; x < rx; x++)
+            if (used[(oy + y) * bx + ox + x]) return false;
+        for (size_t y = 0; y < ry; y++)
+          for (size_t x = 0; x < rx; x++)
+            if (!match(sx, sy, ox + x, oy + y)) return false;
+        return true;
+      }
+      // src/limg.cpp:1288-1384
+      void expand(size_t &ox, size_t &oy, size_t &rx, size_t &ry, bool upLeft) const
+      {
+        const size_t sx = ox, sy = oy;
+        bool up = upLeft, down = true, left = upLeft, right = true;
+        while (up || down || left || right)
+        {
+          if (right) { if (ox + rx + 1 < bx && strip_ok(sx, sy, ox + rx, oy, 1, ry)) rx++; else right = false; }
+          if (down) { if (oy + ry + 1 < by && strip_ok(sx, sy, ox, oy + ry, rx, 1)) ry++; else down = false; }
+          if (upLeft)
+          {
+            if (up) { if (oy > 0 && strip_ok(sx, sy, ox, oy - 1, rx, 1)) { oy--; ry++; } else up = false; }
+            if (left) { if (ox > 0 && strip_ok(sx, sy, ox - 1, oy, 1, ry)) { ox--; rx++; } else left = false; }
+          }
+        }
+      }
+      // src/limg.cpp:1386-1496
+      bool find(bool acceptTiny, size_t &staticX, size_t &staticY, HostRegion &out) const
+      {
+        size_t ox = staticX, oy = staticY;
+        for (; oy < by; oy++)
+        {
+          for (; ox < bx; ox++)
+          {
+            if (used[oy * bx + ox]) continue;
+            size_t x = ox, y = oy, rx = 1, ry = 1;
+            expand(x, y, rx, ry, false);
+            if (rx == 1 && ry == 1) continue;
+            if (!acceptTiny)
+            {
+              if (!(rx >= 3 && ry >= 3)) continue;
+              size_t cx = ox + rx / 3, cy = oy + ry / 3, crx = rx / 3, cry = ry / 3;
+              expand(cx, cy, crx, cry, true);
+              if (crx * cry > rx * ry)
+              {
+                out = { (uint32_t)cx, (uint32_t)cy, (uint32_t)crx, (uint32_t)cry, 0u };
+                staticX = ox; staticY = oy;
+                return true;
+              }
+            }
+            out = { (uint32_t)ox, (uint32_t)oy, (uint32_t)rx, (uint32_t)ry, 0u };
+            staticX = ox + rx; staticY = oy;
+            return true;
+          }
+          ox = 0;
+        }
+        staticX = ox; staticY = oy;
+        return false;
+      }
+      void claim(const HostRegion &r)
+      {
+        for (size_t y = r.oy; y < (size_t)r.oy + r.ry; y++) memset(&used[y * bx + r.ox], 1, r.rx);
+      }
+    };
+  }
+
+  // src/limg.cpp:1813-1881: large rectangles, then small ones, then the remaining single blocks
+  void blocked_merge(const limg_hip_block_record *pass1, const unsigned long long *matchBits, uint32_t blocksX, uint32_t blocksY, int channels, std::vector<HostRegion> &out)
+  {
+    Merge m;
+    m.rec = pass1; m.bits = matchBits; m.bx = blocksX; m.by = blocksY; m.ch = channels;
+    m.used.assign((size_t)blocksX * blocksY, 0);
+    out.clear();
+    for (int tiny = 0; tiny < 2; tiny++)
+    {
+      size_t sx = 0, sy = 0;
+      HostRegion r;
+      while (m.find(tiny != 0, sx, sy, r)) { m.claim(r); out.push_back(r); }
+    }
+    for (uint32_t y = 0; y < blocksY; y++)
+      for (uint32_t x = 0; x < blocksX; x++)
+        if (!m.used[(size_t)y * blocksX + x]) out.push_back({ x, y, 1u, 1u, 1u });
+  }
+
+  // One dither call over n pixels (src/limg.cpp:824-879 / :799-822), any n: floor(n / 8) AES rounds on {h, ~h}, then n % 8 PCG steps on the
+  // low 64 bits; writes n noise bytes (the byte pixel i ANDs with its dither mask) and returns the next chain value.
+  uint64_t chain_call_n(uint64_t h, size_t n, uint8_t *noise, bool pcg) { return chain_call(h, (unsigned)n, noise, false, pcg); }
+}

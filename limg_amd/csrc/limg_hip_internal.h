@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../include/limg_hip.h"
 
 namespace limg_hip
@@ -42,6 +44,7 @@ namespace limg_hip
     uint8_t *park;      // persistent kernel: per workgroup two 8 KiB slots holding a strip's parked results between its E and F steps
     int32_t compactOut; // persistent kernel: also write records / shift words to the raster-order arrays
     int32_t streamRaw;  // compact mode only: factors with shift 8 store their raw byte instead of 0 (input of the stream packer)
+    int32_t fitOnly;    // split path: stop after the records (pass 1 of the merged-block encoder, src/limg.cpp:1088-1119)
   };
 
   // stream pack (limg_hip_stream.hip): from the compact outputs of an encode (factor planes, records, shift words)
@@ -68,6 +71,55 @@ namespace limg_hip
   void launch_encode_persistent(const EncodeParams &p, int channels, int workgroups, hipStream_t s);
   void launch_strip_scan(const EncodeParams &p, hipStream_t s);
   void launch_dither_store(const EncodeParams &p, int channels, hipStream_t s);
+
+  // ---- merged-block encoder (limg_hip_blocked.hip; reference: limg_blocked_encode3d_test, src/limg.cpp:1774-1885, :2329-2453) ----
+  constexpr int kMatchWindow = 8;                                            // match bits are precomputed for |dx|, |dy| <= 8 blocks around every seed
+  constexpr int kMatchCells = (2 * kMatchWindow + 1) * (2 * kMatchWindow + 1); // 289
+  constexpr int kMatchWords = (kMatchCells + 63) / 64;                         // 5 x 64 bits per seed
+
+  struct RegionDesc // one rectangle of 8x8 blocks, in creation (= block index = dither chain) order
+  {
+    uint32_t ox, oy, rx, ry; // blocks
+    uint32_t keep;           // 1: single block that keeps its pass-1 fit (src/limg.cpp:1863-1881)
+    uint32_t scratch;        // first element of this region in the scratch arrays (multiple of 4)
+    uint32_t pad[2];
+  };
+  struct RegionOut
+  {
+    limg_hip_block_record rec;
+    uint32_t shiftWord; // sA | sB << 8 | sC << 16 | ditherCalls << 24
+    uint32_t pad[3];
+  };
+  struct BlockedParams
+  {
+    const uint32_t *in;
+    uint32_t sizeX, sizeY, blocksX, blocksY, channels;
+    uint32_t maxPixel32;
+    uint64_t maxBlock;
+    int32_t crushBits, fast, forced[3];
+    const limg_hip_block_record *pass1;
+    unsigned long long *matchBits; // [blocks][kMatchWords]
+    const RegionDesc *regions;
+    uint32_t nRegions;
+    RegionOut *out;
+    uint32_t *scratchPx; // gathered pixels, region-major (src/limg.cpp:1747-1748)
+    float *scratchV;     // 4 slot planes of scratchCap floats: the parked unit vectors of the current direction pass
+    uint8_t *scratchFac; // 3 planes of scratchCap bytes: pre-dither factor bytes
+    uint32_t scratchCap;
+    const uint8_t *noise;              // one byte per pixel per dither call, region after region in chain order
+    const unsigned long long *noiseBase; // per region: offset of its first call's bytes
+    limg_hip_blocked_encode3d_info info;
+  };
+
+  void launch_blocked_match(const BlockedParams &p, hipStream_t s);
+  void launch_blocked_fit_search(const BlockedParams &p, hipStream_t s);
+  void launch_blocked_store(const BlockedParams &p, hipStream_t s);
+
+  // host side of the merged-block encoder (limg_hip_blocked_host.cpp): the greedy raster merge and the dither chain walk
+  struct HostRegion { uint32_t ox, oy, rx, ry, keep; };
+  void blocked_merge(const limg_hip_block_record *pass1, const unsigned long long *matchBits, uint32_t blocksX, uint32_t blocksY, int channels, std::vector<HostRegion> &out);
+  bool blocked_matches_host(int channels, const limg_hip_block_record &seed, const limg_hip_block_record &cand);
+  uint64_t chain_call_n(uint64_t h, size_t n, uint8_t *noise, bool pcg);
 
   void launch_stream_pack(const StreamParams &p, hipStream_t s);
   void launch_stream_decode(const DecodeParams &p, hipStream_t s);

@@ -1,0 +1,110 @@
+"""GPU parity of the merged-block encoder (limg_hip_blocked_encode3d == the reference's limg_blocked_encode3d_test): every plane upstream
+writes, against the CPU oracle (pinned to the real reference by tests/test_oracle_blocked.py) and against the committed reference hashes."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+from oracle.bind import BLOCKED_WRITTEN
+
+pytestmark = pytest.mark.gpu
+GOLD = json.load(open(os.path.join(gu.G, "blocked.json")))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import limg_amd
+    g = limg_amd.LimgHip(0)
+    yield g
+    g.check()
+    g.close()
+
+
+def _input(orc, e):
+    if e["gen"] == "png":
+        return gu.load_png()
+    if e["gen"] == "pn":
+        return orc.photo_noise(e["w"], e["h"], e["seed"])
+    return orc.random_gradient(e["w"], e["h"], e["seed"], e["gen"] == "rg")
+
+
+def test_stagewise_small(gpu, oracle):
+    """Localises a mismatch: rectangles (merge over GPU similarity bits), then the planes."""
+    for kind, alpha, shape in (("pn", True, (256, 128)), ("rg", True, (256, 128)), ("rga", True, (203, 61)), ("pn", False, (131, 77)), ("rg", False, (64, 64)),
+                               ("pn", True, (8, 8)), ("flat", True, (96, 80))):
+        w, h = shape
+        if kind == "flat":
+            img = np.full((h, w), 0xFF336699, dtype=np.uint32)
+        elif kind == "pn":
+            img = oracle.photo_noise(w, h, 5)
+        else:
+            img = oracle.random_gradient(w, h, 5, kind == "rg")
+        want = oracle.blocked_encode3d(img, alpha)
+        got = gpu.blocked_encode3d(img, alpha)
+        wr, gr = want["regions"], got["regions"]
+        assert len(wr) == len(gr), (kind, alpha, len(wr), len(gr))
+        for f in ("ox", "oy", "rx", "ry"):
+            assert np.array_equal(wr[f], gr[f]), (kind, alpha, f, np.argwhere(wr[f] != gr[f])[:4].ravel())
+        bad = [(k, int((got[k] != want[k]).sum())) for k in BLOCKED_WRITTEN if not np.array_equal(got[k], want[k])]
+        assert not bad, (kind, alpha, bad)
+        assert not got["pBlockError"].any()
+
+
+@pytest.mark.parametrize("name", sorted(GOLD))
+def test_reference_hashes(gpu, oracle, name):
+    e = GOLD[name]
+    img = _input(oracle, e)
+    kw = dict(e["kw"])
+    pcg = kw.pop("dither_mode", 0) != 0
+    gpu.set_options(dither_pcg=pcg)
+    try:
+        got = gpu.blocked_encode3d(img, e["alpha"], **kw)
+    finally:
+        gpu.set_options()
+    for k in BLOCKED_WRITTEN:
+        assert oracle.fnv(got[k]) == e["planes"][k], (name, k)
+    assert len(got["regions"]) == e["regions"]
+    psnr, _ = gpu.compare(img, got["pDecoded"], e["alpha"])
+    assert psnr == pytest.approx(e["psnr"], abs=1e-9)
+
+
+def test_window_fallback_and_forced_shifts(gpu, oracle):
+    """Rectangles wider than the precomputed similarity window (8 blocks) make the host evaluate the predicate itself; forced shifts bypass the search."""
+    img = np.zeros((64, 512), dtype=np.uint32)
+    img[:] = 0xFF000000 | (np.arange(512, dtype=np.uint32)[None, :] // 4) * 0x010101  # a slow horizontal ramp: one very wide rectangle
+    want = oracle.blocked_encode3d(img, True)
+    assert int(want["regions"]["rx"].max()) > 8
+    got = gpu.blocked_encode3d(img, True)
+    bad = [k for k in BLOCKED_WRITTEN if not np.array_equal(got[k], want[k])]
+    assert not bad, bad
+    img = oracle.random_gradient(128, 64, 3, False)
+    for shift in ((8, 8, 8), (0, 0, 0), (3, 5, 8)):
+        want = oracle.blocked_encode3d(img, True, forced_shift=shift)
+        gpu.set_options(forced_shift=shift)
+        try:
+            got = gpu.blocked_encode3d(img, True)
+        finally:
+            gpu.set_options()
+        bad = [k for k in BLOCKED_WRITTEN if not np.array_equal(got[k], want[k])]
+        assert not bad, (shift, bad)
+
+
+def test_device_entry_full_size(gpu, oracle):
+    """2048^2 of each generator through the device entry point: plane hashes against the oracle; stage timing is reported."""
+    import torch
+    for kind in ("photo_noise", "random_gradient"):
+        n = 2048
+        img = gpu.synth_device(kind, n, n, seed=1)
+        planes = gpu.alloc_blocked_planes_device(n, n)
+        gpu.blocked_encode3d_device(img, True, planes)
+        torch.cuda.synchronize()
+        himg = img.cpu().numpy().view(np.uint32)
+        want = oracle.blocked_encode3d(himg, True)
+        for k in BLOCKED_WRITTEN:
+            got = planes[k].cpu().numpy()
+            got = got.view(np.uint32) if got.dtype == np.int32 else got
+            assert np.array_equal(got, want[k]), (kind, k)
+        t = gpu.blocked_timing()
+        assert t["total"] > 0 and len(gpu.blocked_regions()) == len(want["regions"])

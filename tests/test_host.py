@@ -172,3 +172,22 @@ def test_pcg_chain_walk(lib, oracle):
         lib.limg_hip_host_chain_call(0xCA7F00D15BADF00D, 64, buf.ctypes.data_as(C.c_void_p), 2)
         t = f.astype(np.int32) + ((buf.astype(np.int32) & ((1 << s) - 1)) - (1 << (s - 1)))
         assert (np.clip(t, 0, 255) >> s).tolist() == c["dither_bytes"]["pcg_s%d" % s]
+
+
+def test_host_blocked_match_predicate_equals_oracle(oracle):
+    """The similarity predicate the host merge evaluates for far-apart pairs (liblimg_hip.so, no GPU) == the oracle's (pinned to the reference)."""
+    import limg_amd
+    lib = limg_amd.load_library()
+    rng = np.random.default_rng(11)
+    for channels, img in ((4, oracle.photo_noise(256, 128, 3)), (4, oracle.random_gradient(256, 128, 3, False)), (3, oracle.photo_noise(256, 128, 4))):
+        recs = oracle.blocked_encode3d(img, channels == 4, planes=False)["pass1"].reshape(-1)
+        seen = set()
+        for _ in range(1500):
+            i, j = rng.integers(0, recs.size, 2)
+            if rng.random() < 0.7:
+                j = min(recs.size - 1, i + int(rng.integers(1, 3)))
+            a, b = recs[i:i + 1].copy(), recs[j:j + 1].copy()
+            want = oracle.blocked_matches(channels, a, b)
+            assert limg_amd.host_blocked_matches(channels, a, b, lib) == want, (channels, i, j)
+            seen.add(want)
+        assert seen == {True, False}
