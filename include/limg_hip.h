@@ -158,6 +158,14 @@ limg_hip_result limg_hip_blocked_timing(limg_hip_context *pCtx, double *pMs6);
 /* Host-only (no GPU touched): the block-similarity predicate `limg_encode_3d_matches` (src/limg.cpp:1137-1268) as the host merge evaluates it
  * for candidates outside the precomputed window; records in `limg_hip_block_record` layout. */
 int limg_hip_host_blocked_matches(int channels, const limg_hip_block_record *pSeed, const limg_hip_block_record *pCandidate);
+/* Host-only: the greedy raster merge (src/limg.cpp:1386-1496, :1813-1881) over per-block fits; pMatchBits = the similarity bits in the layout the
+ * GPU kernel produces (limg_hip_host_blocked_match_words() 64-bit words per block) or NULL (every pair is evaluated on the host).  Writes up to
+ * `capacity` rectangles in creation order, always reports the count. */
+limg_hip_result limg_hip_host_blocked_merge(const limg_hip_block_record *pFits, const uint64_t *pMatchBits, size_t blocksX, size_t blocksY, int channels,
+                                            limg_hip_region *pRegions, size_t capacity, size_t *pCount);
+/* Host-only: the similarity bits of every block against its neighbourhood, computed on the host (tests, benchmarks of the merge). */
+size_t limg_hip_host_blocked_match_words(void);
+limg_hip_result limg_hip_host_blocked_match_bits(const limg_hip_block_record *pFits, size_t blocksX, size_t blocksY, int channels, uint64_t *pMatchBits);
 
 /* ---- compact stream ("LMG3") -----------------------------------------------------------------------------------------------
  * The north-star names `limg_encode()` / `limg_decode()` and a bitstream; upstream has neither (src/limg.h:27-48 is the whole API,

@@ -1,4 +1,4 @@
-// limg_hip_shim.hpp -- header-only C++ shim that re-exposes the reference's own signatures (src/limg.h:27-48) on top of
+// limg_hip_shim.hpp -- header-only C++ shim that re-exposes the reference's own signatures (src/limg.h:27-48, incl. limg_blocked_encode3d_test) on top of
 // the C ABI of liblimg_hip.so, so a caller written against limg.h (e.g. src/main.cpp:282-332) relinks unchanged:
 //
 //     #include "limg_hip_shim.hpp"      // instead of "limg.h"
@@ -35,6 +35,13 @@ struct limg_encode3d_info
   uint8_t *pFactorsA, *pFactorsB, *pFactorsC;
 };
 
+struct limg_blocked_encode3d_info // src/limg.h:39-44
+{
+  uint32_t *pDecoded;
+  uint8_t *pFactorsA, *pFactorsB, *pFactorsC, *pBlockError, *pBitsPerPixel;
+  uint32_t *pShiftABCX, *pColAMin, *pColAMax, *pColBMin, *pColBMax, *pColCMin, *pColCMax, *pBlockIndex;
+};
+
 namespace limg_hip_shim
 {
   inline limg_hip_context *context()
@@ -61,6 +68,16 @@ inline limg_result limg_encode3d_test_perf(const uint32_t *pIn, const size_t siz
   limg_hip_context *c = limg_hip_shim::context();
   if (!c) return limg_error_Generic;
   return (limg_result)limg_hip_encode3d_perf(c, pIn, sizeX, sizeY, hasAlpha ? 1 : 0, errorFactor, pThreadPool ? (int)pThreadPool->threads : 0, fastBitCrushing ? 1 : 0);
+}
+
+// src/limg.h:46.  The pool only splits upstream's first pass and cannot change the result; it is accepted and ignored.
+inline limg_result limg_blocked_encode3d_test(const uint32_t *pIn, const size_t sizeX, const size_t sizeY, const bool hasAlpha, limg_blocked_encode3d_info *pInfo, const uint32_t errorFactor,
+                                              limg_thread_pool * /* pThreadPool */, const bool fastBitCrushing)
+{
+  static_assert(sizeof(limg_blocked_encode3d_info) == sizeof(limg_hip_blocked_encode3d_info), "layout");
+  limg_hip_context *c = limg_hip_shim::context();
+  if (!c) return limg_error_Generic;
+  return (limg_result)limg_hip_blocked_encode3d(c, pIn, sizeX, sizeY, hasAlpha ? 1 : 0, reinterpret_cast<limg_hip_blocked_encode3d_info *>(pInfo), errorFactor, fastBitCrushing ? 1 : 0);
 }
 
 inline double limg_compare(const uint32_t *pImageA, const uint32_t *pImageB, const size_t sizeX, const size_t sizeY, const bool hasAlpha, double *pMeanSquaredError,

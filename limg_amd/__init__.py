@@ -25,6 +25,7 @@ ABI_SYMBOLS = (
     "limg_hip_stream_bound", "limg_hip_encode_stream_device", "limg_hip_decode_stream_device", "limg_hip_encode_stream", "limg_hip_decode_stream",
     "limg_hip_stream_info",
     "limg_hip_blocked_encode3d", "limg_hip_blocked_encode3d_device", "limg_hip_blocked_regions", "limg_hip_blocked_timing", "limg_hip_host_blocked_matches",
+    "limg_hip_host_blocked_merge", "limg_hip_host_blocked_match_words", "limg_hip_host_blocked_match_bits",
 )
 
 # limg_blocked_encode3d_info (src/limg.h:39-44), member order
@@ -115,6 +116,11 @@ def load_library(path=None):
     L.limg_hip_blocked_timing.argtypes = [C.c_void_p, C.c_void_p]
     L.limg_hip_host_blocked_matches.restype = C.c_int
     L.limg_hip_host_blocked_matches.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    L.limg_hip_host_blocked_merge.restype = C.c_int
+    L.limg_hip_host_blocked_merge.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.limg_hip_host_blocked_match_words.restype = C.c_size_t
+    L.limg_hip_host_blocked_match_bits.restype = C.c_int
+    L.limg_hip_host_blocked_match_bits.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
     L.limg_hip_stream_bound.restype = C.c_size_t
     L.limg_hip_stream_bound.argtypes = [C.c_size_t, C.c_size_t]
     L.limg_hip_encode_stream_device.restype = C.c_int
@@ -154,6 +160,22 @@ def host_blocked_matches(channels, seed, cand, lib=None):
     lib = lib or load_library()
     a = np.ascontiguousarray(seed); b = np.ascontiguousarray(cand)
     return bool(lib.limg_hip_host_blocked_matches(channels, _np_ptr(a), _np_ptr(b)))
+
+
+def host_blocked_merge(fits, channels, use_bits=True, lib=None):
+    """fits: (by, bx) array of RECORD_DTYPE -> rectangles (REGION_DTYPE) in creation order; host only.  use_bits: go through the precomputed
+    similarity-bit window (as the GPU pipeline does) instead of evaluating every pair on demand."""
+    lib = lib or load_library()
+    fits = np.ascontiguousarray(fits)
+    by, bx = fits.shape
+    bits = None
+    if use_bits:
+        bits = np.zeros(by * bx * lib.limg_hip_host_blocked_match_words(), dtype=np.uint64)
+        _check(lib.limg_hip_host_blocked_match_bits(_np_ptr(fits), bx, by, channels, _np_ptr(bits)), "limg_hip_host_blocked_match_bits")
+    out = np.zeros(by * bx, dtype=REGION_DTYPE)
+    n = C.c_size_t(0)
+    _check(lib.limg_hip_host_blocked_merge(_np_ptr(fits), _np_ptr(bits) if bits is not None else None, bx, by, channels, _np_ptr(out), out.size, C.byref(n)), "limg_hip_host_blocked_merge")
+    return out[:n.value].copy()
 
 
 class LimgHip:

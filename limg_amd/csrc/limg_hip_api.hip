@@ -45,6 +45,24 @@ struct DevBuf
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// pinned host memory owned by the context (staging of the merged-block encoder's host stages: no zero fill, full-rate PCIe copies)
+struct HostBuf
+{
+  void *p = nullptr;
+  size_t cap = 0;
+  limg_hip_result ensure(size_t bytes)
+  {
+    if (bytes <= cap) return limg_hip_success;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    const size_t want = bytes + bytes / 4; // grow with slack: sizes depend on the image content
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return limg_hip_error_MemoryAllocationFailure; }
+    cap = want;
+    return limg_hip_success;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 struct limg_hip_context
 {
   int device = 0;
@@ -60,6 +78,7 @@ struct limg_hip_context
   DevBuf in, planes;                             // staging for the host-pointer entry points
   DevBuf cmp;                                    // 8-byte accumulator of limg_hip_compare
   DevBuf bMatch, bRegions, bOut, bPx, bV, bFac, bNoise, bNoiseBase; // merged-block encoder: similarity bits, region table / results, scratch, noise
+  HostBuf hRec, hBits, hDesc, hOut, hNoise, hNoiseBase;
   std::vector<HostRegion> lastRegions;
   double blockedMs[6] = { 0, 0, 0, 0, 0, 0 };
   DevBuf streamFac, streamTiles, streamStatus, streamBuf; // stream packer: 3 factor planes, per-tile payload words; decode status word; host-entry staging
@@ -313,6 +332,8 @@ extern "C"
                        &c->streamFac, &c->streamTiles, &c->streamStatus, &c->streamBuf,
                        &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bV, &c->bFac, &c->bNoise, &c->bNoiseBase };
     for (DevBuf *b : bufs) b->release();
+    HostBuf *hbufs[] = { &c->hRec, &c->hBits, &c->hDesc, &c->hOut, &c->hNoise, &c->hNoiseBase };
+    for (HostBuf *b : hbufs) b->release();
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     delete c;
     *ppCtx = nullptr;
@@ -653,6 +674,42 @@ extern "C"
     return blocked_matches_host(channels, *pSeed, *pCandidate) ? 1 : 0;
   }
 
+  limg_hip_result limg_hip_host_blocked_merge(const limg_hip_block_record *pFits, const uint64_t *pMatchBits, size_t blocksX, size_t blocksY, int channels, limg_hip_region *pRegions,
+                                              size_t capacity, size_t *pCount)
+  {
+    if (!pFits || !pCount) return limg_hip_error_ArgumentNull;
+    if (blocksX == 0 || blocksY == 0 || blocksX > 0x0FFFFFFFull || blocksY > 0x0FFFFFFFull || (channels != 3 && channels != 4)) return limg_hip_error_InvalidParameter;
+    std::vector<HostRegion> regs;
+    blocked_merge(pFits, (const unsigned long long *)pMatchBits, (uint32_t)blocksX, (uint32_t)blocksY, channels, regs);
+    *pCount = regs.size();
+    if (pRegions)
+      for (size_t i = 0; i < regs.size() && i < capacity; i++) pRegions[i] = { regs[i].ox, regs[i].oy, regs[i].rx, regs[i].ry };
+    return limg_hip_success;
+  }
+
+  size_t limg_hip_host_blocked_match_words(void) { return kMatchWords; }
+
+  limg_hip_result limg_hip_host_blocked_match_bits(const limg_hip_block_record *pFits, size_t blocksX, size_t blocksY, int channels, uint64_t *pMatchBits)
+  {
+    if (!pFits || !pMatchBits) return limg_hip_error_ArgumentNull;
+    if (channels != 3 && channels != 4) return limg_hip_error_InvalidParameter;
+    constexpr int side = 2 * kMatchWindow + 1;
+    for (size_t sy = 0; sy < blocksY; sy++)
+      for (size_t sx = 0; sx < blocksX; sx++)
+      {
+        uint64_t *w = pMatchBits + (sy * blocksX + sx) * kMatchWords;
+        for (int i = 0; i < kMatchWords; i++) w[i] = 0;
+        for (int cell = 0; cell < kMatchCells; cell++)
+        {
+          const long dy = cell / side - kMatchWindow, dx = cell % side - kMatchWindow;
+          const long cx = (long)sx + dx, cy = (long)sy + dy;
+          if ((dx | dy) == 0 || cx < 0 || cy < 0 || cx >= (long)blocksX || cy >= (long)blocksY) continue;
+          if (blocked_matches_host(channels, pFits[sy * blocksX + sx], pFits[(size_t)cy * blocksX + cx])) w[cell >> 6] |= 1ull << (cell & 63);
+        }
+      }
+    return limg_hip_success;
+  }
+
   limg_hip_result limg_hip_blocked_encode3d_device(limg_hip_context *c, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, const limg_hip_blocked_encode3d_info *pInfo,
                                                    uint32_t errorFactor, int fastBitCrushing, void *stream)
   {
@@ -691,18 +748,21 @@ extern "C"
     launch_blocked_match(bp, s);
     HIP_TRY(hipGetLastError());
 
-    std::vector<limg_hip_block_record> hRec(blocks);
-    std::vector<unsigned long long> hBits(blocks * kMatchWords);
-    HIP_TRY(hipMemcpyAsync(hRec.data(), c->records.p, blocks * sizeof(limg_hip_block_record), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(hBits.data(), c->bMatch.p, hBits.size() * 8, hipMemcpyDeviceToHost, s));
+    if ((r = c->hRec.ensure(blocks * sizeof(limg_hip_block_record))) != limg_hip_success) return r;
+    if ((r = c->hBits.ensure(blocks * kMatchWords * 8)) != limg_hip_success) return r;
+    limg_hip_block_record *hRec = (limg_hip_block_record *)c->hRec.p;
+    unsigned long long *hBits = (unsigned long long *)c->hBits.p;
+    HIP_TRY(hipMemcpyAsync(hRec, c->records.p, blocks * sizeof(limg_hip_block_record), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(hBits, c->bMatch.p, blocks * kMatchWords * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const clk::time_point t1 = clk::now();
 
     // the greedy raster merge (host, serial by construction; it only looks the similarity bits up)
-    blocked_merge(hRec.data(), hBits.data(), blocksX, blocksY, channels, c->lastRegions);
+    blocked_merge(hRec, hBits, blocksX, blocksY, channels, c->lastRegions);
     const std::vector<HostRegion> &regs = c->lastRegions;
     const size_t nRegions = regs.size();
-    std::vector<RegionDesc> desc(nRegions);
+    if ((r = c->hDesc.ensure(nRegions * sizeof(RegionDesc))) != limg_hip_success) return r;
+    RegionDesc *desc = (RegionDesc *)c->hDesc.p;
     std::vector<uint32_t> npx(nRegions);
     uint64_t cap = 0;
     for (size_t i = 0; i < nRegions; i++)
@@ -723,40 +783,43 @@ extern "C"
     if ((r = c->bPx.ensure(cap * 4)) != limg_hip_success) return r;
     if ((r = c->bV.ensure(cap * 16)) != limg_hip_success) return r;
     if ((r = c->bFac.ensure(cap * 3)) != limg_hip_success) return r;
-    HIP_TRY(hipMemcpyAsync(c->bRegions.p, desc.data(), nRegions * sizeof(RegionDesc), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->bRegions.p, desc, nRegions * sizeof(RegionDesc), hipMemcpyHostToDevice, s));
     bp.regions = (const RegionDesc *)c->bRegions.p; bp.nRegions = (uint32_t)nRegions; bp.out = (RegionOut *)c->bOut.p;
     bp.scratchPx = (uint32_t *)c->bPx.p; bp.scratchV = (float *)c->bV.p; bp.scratchFac = (uint8_t *)c->bFac.p; bp.scratchCap = (uint32_t)cap;
     launch_blocked_fit_search(bp, s);
     HIP_TRY(hipGetLastError());
-    std::vector<RegionOut> hOut(nRegions);
-    HIP_TRY(hipMemcpyAsync(hOut.data(), c->bOut.p, nRegions * sizeof(RegionOut), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s)); // also keeps `desc` alive until its upload is done
+    if ((r = c->hOut.ensure(nRegions * sizeof(RegionOut))) != limg_hip_success) return r;
+    const RegionOut *hOut = (const RegionOut *)c->hOut.p;
+    HIP_TRY(hipMemcpyAsync(c->hOut.p, c->bOut.p, nRegions * sizeof(RegionOut), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     const clk::time_point t3 = clk::now();
 
     // the dither chain (src/limg_internal.h:711, src/limg.cpp:1541-1551): one chain through all regions in creation order; a call over N pixels
     // advances it by floor(N / 8) AES rounds + N % 8 PCG steps, so it is walked here, producing the byte every pixel adds
-    std::vector<unsigned long long> noiseBase(nRegions);
+    if ((r = c->hNoiseBase.ensure(nRegions * 8 + 8)) != limg_hip_success) return r;
+    unsigned long long *noiseBase = (unsigned long long *)c->hNoiseBase.p;
     uint64_t total = 0;
     for (size_t i = 0; i < nRegions; i++) { noiseBase[i] = total; total += (uint64_t)(hOut[i].shiftWord >> 24) * npx[i]; }
-    std::vector<uint8_t> noise(total + 64);
+    if ((r = c->hNoise.ensure(total + 64)) != limg_hip_success) return r;
+    uint8_t *noise = (uint8_t *)c->hNoise.p;
     {
       uint64_t h = kDitherSeed;
       const bool pcg = c->opt.dither_pcg != 0;
       for (size_t i = 0; i < nRegions; i++)
       {
         const uint32_t calls = hOut[i].shiftWord >> 24;
-        for (uint32_t k = 0; k < calls; k++) h = chain_call_n(h, npx[i], noise.data() + noiseBase[i] + (uint64_t)k * npx[i], pcg);
+        for (uint32_t k = 0; k < calls; k++) h = chain_call_n(h, npx[i], noise + noiseBase[i] + (uint64_t)k * npx[i], pcg);
       }
     }
-    if ((r = c->bNoise.ensure(noise.size())) != limg_hip_success) return r;
+    if ((r = c->bNoise.ensure(total + 64)) != limg_hip_success) return r;
     if ((r = c->bNoiseBase.ensure(nRegions * 8 + 8)) != limg_hip_success) return r;
-    HIP_TRY(hipMemcpyAsync(c->bNoise.p, noise.data(), noise.size(), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(c->bNoiseBase.p, noiseBase.data(), nRegions * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->bNoise.p, noise, total + 64, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->bNoiseBase.p, noiseBase, nRegions * 8, hipMemcpyHostToDevice, s));
     bp.noise = (const uint8_t *)c->bNoise.p; bp.noiseBase = (const unsigned long long *)c->bNoiseBase.p;
     const clk::time_point t4 = clk::now();
     launch_blocked_store(bp, s);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(s)); // the host vectors above die with this scope
+    HIP_TRY(hipStreamSynchronize(s)); // the pinned staging buffers are reused by the next call
     const clk::time_point t5 = clk::now();
     c->blockedMs[0] = ms(t0, t1); c->blockedMs[1] = ms(t1, t2); c->blockedMs[2] = ms(t2, t3); c->blockedMs[3] = ms(t3, t4); c->blockedMs[4] = ms(t4, t5); c->blockedMs[5] = ms(t0, t5);
     return limg_hip_success;

@@ -19,9 +19,11 @@ namespace limg_hip
   namespace
   {
     __device__ __forceinline__ void scratch_fence()
-    { // a wave re-reads global scratch it (and only it) wrote: make the writes visible to its own later loads through the vector L1
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    { // A wave re-reads global scratch that it alone wrote (other lanes' stores): wait for the stores; the CU's vector L1 is write-through and
+      // coherent for accesses from the same CU, which is what workgroup scope expresses.  (Agent scope would write the whole L2 back: the
+      // per-XCD L2s are not coherent with each other, and that costs ~10x on this kernel.)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 
     // ---- similarity predicate ---------------------------------------------------------------------------------------------------------

@@ -191,3 +191,18 @@ def test_host_blocked_match_predicate_equals_oracle(oracle):
             assert limg_amd.host_blocked_matches(channels, a, b, lib) == want, (channels, i, j)
             seen.add(want)
         assert seen == {True, False}
+
+
+@pytest.mark.parametrize("use_bits", [True, False])
+def test_host_blocked_merge_equals_oracle(oracle, use_bits):
+    """The product's greedy merge (host, no GPU) over the oracle's pass-1 fits == the oracle's rectangles (pinned to the reference), both through the
+    similarity-bit window and with on-demand evaluation."""
+    import limg_amd
+    lib = limg_amd.load_library()
+    for alpha, img in ((True, oracle.photo_noise(512, 256, 3)), (True, oracle.random_gradient(384, 256, 3, True)), (False, oracle.photo_noise(203, 131, 4)),
+                       (True, np.full((96, 160), 0xFF204060, dtype=np.uint32))):
+        want = oracle.blocked_encode3d(img, alpha, planes=False)
+        got = limg_amd.host_blocked_merge(want["pass1"], 4 if alpha else 3, use_bits, lib)
+        assert len(got) == len(want["regions"])
+        for f in ("ox", "oy", "rx", "ry"):
+            assert np.array_equal(got[f], want["regions"][f]), f

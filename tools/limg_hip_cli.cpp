@@ -6,12 +6,12 @@
 //   limg_hip_cli <InputFile> [--no-output] [--error-factor <Factor>] [--accurate-bit-crushing] [--single-thread]
 //   limg_hip_cli -- [--count <Count>] [...] -- <list of files>          (benchmark: limg_encode3d_test_perf, nothing written)
 //
-// Differences, all forced by scope: the single-file mode runs `limg_encode3d_test` (fixed 8x8 blocks, the hot path
-// this library replaces) where upstream's tool runs the merged-block encoder `limg_blocked_encode3d_test` (src/main.cpp:255), so
-// there is no bits-per-pixel / block-index output; images are read by a small built-in PNG (zlib) / TGA / PPM reader instead of
-// stb_image; TGAs are written uncompressed.  Extras: `--threads <T>` (size of the pool whose strip partition is reproduced; default:
-// hardware threads, like limg_threading_max_threads), `--out-dir <dir>`, `--stream <file>` (also write the compact LMG3 stream and
-// verify that decoding it reproduces the decoded image).
+// Like upstream, the single-file mode runs the merged-block encoder `limg_blocked_encode3d_test` (src/main.cpp:255) and the list /
+// benchmark modes run `limg_encode3d_test_perf`.  Differences: images are read by a small built-in PNG (zlib) / TGA / PPM reader instead
+// of stb_image; TGAs are written uncompressed (upstream's stb writer uses RLE); the block-error plane upstream allocates but never
+// fills is not written.  Extras: `--fixed-blocks` (single-file mode with `limg_encode3d_test`, fixed 8x8 blocks, instead), `--threads <T>`
+// (size of the pool whose strip partition the 8x8 path reproduces; default: hardware threads, like limg_threading_max_threads),
+// `--out-dir <dir>`, `--stream <file>` (also write the compact LMG3 stream of the 8x8 path and verify that it decodes to that path's image).
 #include <inttypes.h>
 #include <math.h>
 #include <stdio.h>
@@ -213,15 +213,25 @@ static const char Arg_List[] = "--";
 static const char Arg_Threads[] = "--threads";
 static const char Arg_OutDir[] = "--out-dir";
 static const char Arg_Stream[] = "--stream";
+static const char Arg_FixedBlocks[] = "--fixed-blocks";
+
+// src/main.cpp:46-54: colours the block-index plane for viewing
+static int32_t Hash(const int32_t value)
+{
+  const uint64_t oldstate = value * 6364136223846793005ULL + (value | 1);
+  const uint32_t xorshifted = (uint32_t)(((oldstate >> 18) ^ oldstate) >> 27);
+  const uint32_t rot = (uint32_t)(oldstate >> 59);
+  return (int32_t)((xorshifted >> rot) | (xorshifted << (uint32_t)((-(int32_t)rot) & 31)));
+}
 
 int main(const int argc, const char **pArgv)
 {
   if (argc == 1)
-    FAIL(EXIT_SUCCESS, "Usage:\nlimg_hip_cli [<InputFile> | --] [%s | %s <Factor> | %s | %s | %s <T> | %s <dir> | %s <file>] \n  if input file is --:\n    [%s <Count>] -- <list of files>)\n",
-         Arg_NoWrite, Arg_ErrorFactor, Arg_AccurateBitCrushing, Arg_SingleThreaded, Arg_Threads, Arg_OutDir, Arg_Stream, Arg_ListCount);
+    FAIL(EXIT_SUCCESS, "Usage:\nlimg_hip_cli [<InputFile> | --] [%s | %s <Factor> | %s | %s | %s | %s <T> | %s <dir> | %s <file>] \n  if input file is --:\n    [%s <Count>] -- <list of files>)\n",
+         Arg_NoWrite, Arg_ErrorFactor, Arg_AccurateBitCrushing, Arg_SingleThreaded, Arg_FixedBlocks, Arg_Threads, Arg_OutDir, Arg_Stream, Arg_ListCount);
 
   const char *sourceImagePath = pArgv[1];
-  bool writeEncodedImages = true, fastBitCrushing = true, useThreadPool = true;
+  bool writeEncodedImages = true, fastBitCrushing = true, useThreadPool = true, fixedBlocks = false;
   uint32_t errorFactor = 100;
   size_t listCount = 1, threads = std::thread::hardware_concurrency();
   std::string outDir = ".", streamPath;
@@ -235,6 +245,7 @@ int main(const int argc, const char **pArgv)
     if (!strcmp(a, Arg_NoWrite)) { argIndex++; writeEncodedImages = false; }
     else if (!strcmp(a, Arg_AccurateBitCrushing)) { argIndex++; fastBitCrushing = false; }
     else if (!strcmp(a, Arg_SingleThreaded)) { argIndex++; useThreadPool = false; }
+    else if (!strcmp(a, Arg_FixedBlocks)) { argIndex++; fixedBlocks = true; }
     else if (remaining >= 2 && !strcmp(a, Arg_ErrorFactor)) { errorFactor = (uint32_t)ParseUInt(pArgv[argIndex + 1]); argIndex += 2; }
     else if (remaining >= 2 && !strcmp(a, Arg_Threads)) { threads = (size_t)ParseUInt(pArgv[argIndex + 1]); argIndex += 2; if (!threads) useThreadPool = false; }
     else if (remaining >= 2 && !strcmp(a, Arg_OutDir)) { outDir = pArgv[argIndex + 1]; argIndex += 2; }
@@ -280,26 +291,45 @@ int main(const int argc, const char **pArgv)
 
     if (sourceImagePath != nullptr)
     {
-      std::vector<uint32_t> target(count), planes32[7];
-      std::vector<uint8_t> fac[3];
+      std::vector<uint32_t> target(count), planes32[7], blockIndex(count);
+      std::vector<uint8_t> fac[3], bitsPerPixel(count);
       for (auto &p : planes32) p.assign(count, 0);
       for (auto &p : fac) p.assign(count, 0);
       printf("%" PRIu64 " x %" PRIu64 " pixels.\n", (uint64_t)sizeX, (uint64_t)sizeY);
 
-      limg_encode3d_info info;
-      info.pDecoded = target.data(); info.pShiftABCX = planes32[0].data();
-      info.pColAMin = planes32[1].data(); info.pColAMax = planes32[2].data(); info.pColBMin = planes32[3].data(); info.pColBMax = planes32[4].data();
-      info.pColCMin = planes32[5].data(); info.pColCMax = planes32[6].data();
-      info.pFactorsA = fac[0].data(); info.pFactorsB = fac[1].data(); info.pFactorsC = fac[2].data();
-
+      limg_result result;
       const int64_t before = CurrentTimeNs();
-      const limg_result result = limg_encode3d_test(source.data(), sizeX, sizeY, hasAlpha, &info, errorFactor, pThreadPool, fastBitCrushing);
+      if (fixedBlocks)
+      {
+        limg_encode3d_info info;
+        info.pDecoded = target.data(); info.pShiftABCX = planes32[0].data();
+        info.pColAMin = planes32[1].data(); info.pColAMax = planes32[2].data(); info.pColBMin = planes32[3].data(); info.pColBMax = planes32[4].data();
+        info.pColCMin = planes32[5].data(); info.pColCMax = planes32[6].data();
+        info.pFactorsA = fac[0].data(); info.pFactorsB = fac[1].data(); info.pFactorsC = fac[2].data();
+        result = limg_encode3d_test(source.data(), sizeX, sizeY, hasAlpha, &info, errorFactor, pThreadPool, fastBitCrushing);
+      }
+      else
+      {
+        limg_blocked_encode3d_info info;
+        info.pDecoded = target.data(); info.pShiftABCX = planes32[0].data();
+        info.pColAMin = planes32[1].data(); info.pColAMax = planes32[2].data(); info.pColBMin = planes32[3].data(); info.pColBMax = planes32[4].data();
+        info.pColCMin = planes32[5].data(); info.pColCMax = planes32[6].data();
+        info.pFactorsA = fac[0].data(); info.pFactorsB = fac[1].data(); info.pFactorsC = fac[2].data();
+        info.pBlockError = nullptr; info.pBitsPerPixel = bitsPerPixel.data(); info.pBlockIndex = blockIndex.data();
+        result = limg_blocked_encode3d_test(source.data(), sizeX, sizeY, hasAlpha, &info, errorFactor, pThreadPool, fastBitCrushing);
+      }
       const int64_t after = CurrentTimeNs();
 
       printf("limg_encode_test completed with exit code 0x%" PRIX32 ".\n", (uint32_t)result);
       printf("Elapsed Time: %f ms\n", (after - before) * 1e-6);
       printf("Throughput: %f Mpx/s\n", (count * 1e-6) / ((after - before) * 1e-9));
       if (result != limg_success) FAIL(EXIT_FAILURE, "Encode failed with exit code 0x%" PRIX32 ".\n", (uint32_t)result);
+      if (!fixedBlocks)
+      {
+        uint64_t bits = 0;
+        for (size_t i = 0; i < count; i++) bits += bitsPerPixel[i];
+        printf("Compression Average: ~%7.4f bits per pixel\n", bits / (double)count); // upstream prints this from inside the library (src/limg.cpp:2433-2440)
+      }
 
       double mean, max;
       const double psnr = limg_compare(source.data(), target.data(), sizeX, sizeY, hasAlpha, &mean, &max);
@@ -314,7 +344,22 @@ int main(const int argc, const char **pArgv)
         std::vector<uint32_t> again(count);
         r = limg_decode(stream.data(), bytes, again.data(), again.size());
         if (r != limg_success) FAIL(EXIT_FAILURE, "limg_decode failed with exit code 0x%" PRIX32 ".\n", (uint32_t)r);
-        const bool same = memcmp(again.data(), target.data(), count * 4) == 0;
+        // the stream belongs to the fixed-8x8 path: compare with that path's decoded image
+        std::vector<uint32_t> fixedDecoded;
+        if (!fixedBlocks)
+        {
+          std::vector<uint32_t> tmp32[7];
+          std::vector<uint8_t> tmp8[3];
+          fixedDecoded.assign(count, 0);
+          for (auto &p : tmp32) p.assign(count, 0);
+          for (auto &p : tmp8) p.assign(count, 0);
+          limg_encode3d_info fi;
+          fi.pDecoded = fixedDecoded.data(); fi.pShiftABCX = tmp32[0].data(); fi.pColAMin = tmp32[1].data(); fi.pColAMax = tmp32[2].data(); fi.pColBMin = tmp32[3].data();
+          fi.pColBMax = tmp32[4].data(); fi.pColCMin = tmp32[5].data(); fi.pColCMax = tmp32[6].data(); fi.pFactorsA = tmp8[0].data(); fi.pFactorsB = tmp8[1].data(); fi.pFactorsC = tmp8[2].data();
+          r = limg_encode3d_test(source.data(), sizeX, sizeY, hasAlpha, &fi, errorFactor, pThreadPool, fastBitCrushing);
+          if (r != limg_success) FAIL(EXIT_FAILURE, "limg_encode3d_test failed with exit code 0x%" PRIX32 ".\n", (uint32_t)r);
+        }
+        const bool same = memcmp(again.data(), fixedBlocks ? target.data() : fixedDecoded.data(), count * 4) == 0;
         printf("Stream: %" PRIu64 " bytes (%5.3f bits per pixel); decoding it %s the decoded image.\n", (uint64_t)bytes, bytes * 8.0 / count, same ? "reproduces" : "DOES NOT reproduce");
         FILE *f = fopen(streamPath.c_str(), "wb");
         if (!f || fwrite(stream.data(), 1, bytes, f) != bytes) FAIL(EXIT_FAILURE, "Failed to write '%s'.\n", streamPath.c_str());
@@ -330,6 +375,14 @@ int main(const int argc, const char **pArgv)
         write_tga(outDir + "/limg_fac_c.tga", sizeX, sizeY, 1, fac[2].data());
         static const char *names[7] = { "limg_bits", "limg_col_a_min", "limg_col_a_max", "limg_col_b_min", "limg_col_b_max", "limg_col_c_min", "limg_col_c_max" };
         for (int i = 0; i < 7; i++) write_tga(outDir + "/" + names[i] + ".tga", sizeX, sizeY, 4, planes32[i].data());
+        if (!fixedBlocks)
+        {
+          write_tga(outDir + "/limg_bpp.tga", sizeX, sizeY, 1, bitsPerPixel.data());
+          write_tga(outDir + "/limg_block_idx_raw.tga", sizeX, sizeY, 4, blockIndex.data());
+          for (size_t i = 0; i < count; i++) // src/main.cpp:264-267
+            if (blockIndex[i] & ((uint32_t)1 << 31)) blockIndex[i] = (uint32_t)Hash((int32_t)blockIndex[i]) | 0xFF000000;
+          write_tga(outDir + "/limg_block_idx.tga", sizeX, sizeY, 4, blockIndex.data());
+        }
       }
     }
     else if (singlePerfEval)
