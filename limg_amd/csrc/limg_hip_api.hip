@@ -693,7 +693,6 @@ extern "C"
   {
     if (!pFits || !pMatchBits) return limg_hip_error_ArgumentNull;
     if (channels != 3 && channels != 4) return limg_hip_error_InvalidParameter;
-    constexpr int side = 2 * kMatchWindow + 1;
     for (size_t sy = 0; sy < blocksY; sy++)
       for (size_t sx = 0; sx < blocksX; sx++)
       {
@@ -701,7 +700,7 @@ extern "C"
         for (int i = 0; i < kMatchWords; i++) w[i] = 0;
         for (int cell = 0; cell < kMatchCells; cell++)
         {
-          const long dy = cell / side - kMatchWindow, dx = cell % side - kMatchWindow;
+          const long dy = cell / kMatchSide - kMatchLo, dx = cell % kMatchSide - kMatchLo;
           const long cx = (long)sx + dx, cy = (long)sy + dy;
           if ((dx | dy) == 0 || cx < 0 || cy < 0 || cx >= (long)blocksX || cy >= (long)blocksY) continue;
           if (blocked_matches_host(channels, pFits[sy * blocksX + sx], pFits[(size_t)cy * blocksX + cx])) w[cell >> 6] |= 1ull << (cell & 63);

@@ -1,7 +1,7 @@
 // limg_hip_blocked.hip -- GPU stages of the merged-block encoder (reference: limg_blocked_encode3d_test, src/limg.cpp:1774-1885, :2329-2453).
 //
 //   k_blocked_match        the block-similarity predicate `limg_encode_3d_matches` (src/limg.cpp:1137-1268) for every block as seed against
-//                          the (2 W + 1)^2 blocks around it: one wave per seed, lane = candidate, 64 pairs per step, results as ballot masks.
+//                          the 18 x 18 blocks around it (offsets -5 .. +12): one wave per seed, lane = candidate, 64 pairs per step, results as ballot masks.
 //                          The host's greedy raster merge (limg_hip_blocked_host.cpp) only looks these bits up.
 //   k_blocked_fit_search   one wave per rectangle ("region") of the merge: gather (src/limg.cpp:1747-1748), channel sums, direction fit
 //                          over all N pixels of the region in row-major order (same functions as for an 8x8 block, src/limg_factorization.h
@@ -122,6 +122,121 @@ namespace limg_hip
       return sum * (1.f / 27) < 3.0f;
     }
 
+    // The same predicate for two candidates per lane, on float2 operands: every operation is elementwise and rounds exactly like its scalar
+    // twin (v_pk_mul_f32 / v_pk_add_f32, IEEE division per component), so both components equal m_matches bit for bit at half the VALU issue.
+    template <typename T>
+    __device__ __forceinline__ float2_t splat2(T v) { return float2_t{ (float)v, (float)v }; }
+    __device__ __forceinline__ float2_t pair2(float x, float y) { return float2_t{ x, y }; }
+
+    template <int CH, typename TA, typename TB>
+    __device__ __forceinline__ float2_t dot_seq2(const TA *a, const TB *b)
+    {
+      float2_t sum = { 0.0f, 0.0f };
+#pragma unroll
+      for (int i = 0; i < CH; i++) sum += a[i] * b[i];
+      return sum;
+    }
+
+    // src/limg_factorization.h:9-42 with any mix of uniform (float) and per-candidate (float2) operands
+    template <int CH, typename TC, typename TR>
+    __device__ __forceinline__ void m_factors2(const TC *color, const TR *mnA, const TR *ofB, const TR *ofC, const TR *nA, const TR *nB, const TR *nC, TR invA, TR invB, TR invC,
+                                               float2_t f[3])
+    {
+      float2_t t[4], est[4];
+#pragma unroll
+      for (int i = 0; i < CH; i++) t[i] = color[i] - mnA[i];
+      f[0] = dot_seq2<CH>(t, nA) * invA;
+#pragma unroll
+      for (int i = 0; i < CH; i++) { est[i] = mnA[i] + f[0] * nA[i]; t[i] = (color[i] - est[i]) - ofB[i]; }
+      f[1] = dot_seq2<CH>(t, nB) * invB;
+#pragma unroll
+      for (int i = 0; i < CH; i++) { est[i] = est[i] + f[1] * nB[i]; t[i] = (color[i] - est[i]) - ofC[i]; }
+      f[2] = dot_seq2<CH>(t, nC) * invC;
+    }
+
+    template <int CH>
+    __device__ void m_matches_pair(const limg_hip_block_record &a, const limg_hip_block_record &b0, const limg_hip_block_record &b1, bool &r0, bool &r1)
+    {
+      MState sa;
+      m_init<CH>(a, sa);
+      float amnA[4], aofB[4], aofC[4];
+      float2_t nA[4], nB[4], nC[4], mnA[4], ofB[4], ofC[4], avgB[4];
+#pragma unroll
+      for (int i = 0; i < CH; i++)
+      {
+        amnA[i] = (float)a.dirA_min[i]; aofB[i] = (float)a.dirB_offset[i]; aofC[i] = (float)a.dirC_offset[i];
+        nA[i] = pair2((float)((int)b0.dirA_max[i] - (int)b0.dirA_min[i]), (float)((int)b1.dirA_max[i] - (int)b1.dirA_min[i]));
+        nB[i] = pair2((float)((int)b0.dirB_mag[i] - (int)b0.dirB_offset[i]), (float)((int)b1.dirB_mag[i] - (int)b1.dirB_offset[i]));
+        nC[i] = pair2((float)((int)b0.dirC_mag[i] - (int)b0.dirC_offset[i]), (float)((int)b1.dirC_mag[i] - (int)b1.dirC_offset[i]));
+        mnA[i] = pair2((float)b0.dirA_min[i], (float)b1.dirA_min[i]);
+        ofB[i] = pair2((float)b0.dirB_offset[i], (float)b1.dirB_offset[i]);
+        ofC[i] = pair2((float)b0.dirC_offset[i], (float)b1.dirC_offset[i]);
+        avgB[i] = pair2(b0.avg[i], b1.avg[i]);
+      }
+      // candidate states (src/limg_internal.h:426-452): 1 / |n|^2, or 0 for an all-zero normal
+      float2_t invBA = 1.0f / dot_seq2<CH>(nA, nA), invBB = 1.0f / dot_seq2<CH>(nB, nB), invBC = 1.0f / dot_seq2<CH>(nC, nC);
+      {
+        bool zA0 = true, zA1 = true, zB0 = true, zB1 = true, zC0 = true, zC1 = true;
+#pragma unroll
+        for (int i = 0; i < CH; i++)
+        {
+          zA0 &= nA[i].x == 0.0f; zA1 &= nA[i].y == 0.0f; zB0 &= nB[i].x == 0.0f; zB1 &= nB[i].y == 0.0f; zC0 &= nC[i].x == 0.0f; zC1 &= nC[i].y == 0.0f;
+        }
+        invBA = pair2(zA0 ? 0.0f : invBA.x, zA1 ? 0.0f : invBA.y);
+        invBB = pair2(zB0 ? 0.0f : invBB.x, zB1 ? 0.0f : invBB.y);
+        invBC = pair2(zC0 ? 0.0f : invBC.x, zC1 ? 0.0f : invBC.y);
+      }
+      const float w[4] = { 2, 4, 3, 3 };
+      float lenA[3] = { 3, 3, 3 };
+      float2_t avgDiffSq = { 0, 0 }, lenB[3] = { { 3, 3 }, { 3, 3 }, { 3, 3 } };
+#pragma unroll
+      for (int i = 0; i < CH; i++)
+      {
+        const float2_t d = a.avg[i] - avgB[i];
+        avgDiffSq += d * d * w[i];
+        lenA[0] += (sa.nA[i] * sa.nA[i]) * w[i]; lenB[0] += (nA[i] * nA[i]) * w[i];
+        lenA[1] += (sa.nB[i] * sa.nB[i]) * w[i]; lenB[1] += (nB[i] * nB[i]) * w[i];
+        lenA[2] += (sa.nC[i] * sa.nC[i]) * w[i]; lenB[2] += (nC[i] * nC[i]) * w[i];
+      }
+      const float sumA = lenA[0] + lenA[1] + lenA[2];
+      const float2_t sumB = lenB[0] + lenB[1] + lenB[2];
+      const float2_t ratio = (sumA + 1) / (sumB + 1);
+      const float maxAvg = (float)(16 * 3 * CH), maxRange = (float)(200 * 3 * CH);
+      const bool q0 = avgDiffSq.x < maxAvg && sumA < maxRange && sumB.x < maxRange, q1 = avgDiffSq.y < maxAvg && sumA < maxRange && sumB.y < maxRange;
+      const bool j0 = ratio.x > 1.375f || ratio.x < (1.f / 1.375f), j1 = ratio.y > 1.375f || ratio.y < (1.f / 1.375f);
+      r0 = q0; r1 = q1;
+      if ((q0 || j0) && (q1 || j1)) return;
+      float invA[3];
+      float2_t invB[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) { invA[i] = 1.0f / lenA[i]; invB[i] = 1.0f / lenB[i]; }
+#pragma unroll
+      for (int i = 1; i < 3; i++) { invA[i] *= 2.f; invB[i] *= 2.f; }
+      float2_t fb[3];
+      m_factors2<CH>(a.avg, mnA, ofB, ofC, nA, nB, nC, invBA, invBB, invBC, fb);
+      const float2_t termB = __builtin_elementwise_abs(fb[0]) * invB[0] + __builtin_elementwise_abs(0.5f - fb[1]) * invB[1] + __builtin_elementwise_abs(0.5f - fb[2]) * invB[2];
+      float2_t sum = { 0, 0 };
+#pragma unroll 1
+      for (int z = 0; z < 3; z++)
+#pragma unroll 1
+        for (int y = 0; y < 3; y++)
+#pragma unroll
+          for (int x = 0; x < 3; x++)
+          {
+            const float xf = x * 0.5f, yf = y * 0.5f, zf = z * 0.5f;
+            float2_t color[4], fa[3];
+#pragma unroll
+            for (int i = 0; i < CH; i++) color[i] = nA[i] * xf + nB[i] * yf + nC[i] * zf;
+            m_factors2<CH>(color, amnA, aofB, aofC, sa.nA, sa.nB, sa.nC, sa.invA, sa.invB, sa.invC, fa);
+            sum += __builtin_elementwise_abs(fa[0]) * invA[0] + __builtin_elementwise_abs(0.5f - fa[1]) * invA[1] + __builtin_elementwise_abs(0.5f - fa[2]) * invA[2];
+            sum += termB;
+          }
+      const float2_t avgF = sum * (1.f / 27);
+      if (!q0 && !j0) r0 = avgF.x < 3.0f;
+      if (!q1 && !j1) r1 = avgF.y < 3.0f;
+    }
+
+    // one wave per seed; lane l of step c evaluates cells 128 c + l and 128 c + 64 + l, so the two ballots are words 2 c and 2 c + 1
     template <int CH>
     __global__ __launch_bounds__(256) void k_blocked_match(const BlockedParams p)
     {
@@ -131,16 +246,28 @@ namespace limg_hip
       if (seed >= nBlocks) return;
       const uint32_t sy = seed / p.blocksX, sx = seed - sy * p.blocksX;
       const limg_hip_block_record a = p.pass1[seed];
-      constexpr int side = 2 * kMatchWindow + 1;
-      for (int c = 0; c < kMatchWords; c++)
+      static_assert(kMatchWords % 2 == 0, "two ballots per step");
+      for (int c = 0; c < kMatchWords / 2; c++)
       {
-        const int cell = c * 64 + lane;
-        const int dy = cell / side - kMatchWindow, dx = cell - (cell / side) * side - kMatchWindow;
-        const uint32_t cx = sx + (uint32_t)dx, cy = sy + (uint32_t)dy; // wraps for negative offsets => fails the range test
-        bool m = false;
-        if (cell < kMatchCells && (dx | dy) != 0 && cx < p.blocksX && cy < p.blocksY) m = m_matches<CH>(a, p.pass1[(size_t)cy * p.blocksX + cx]);
-        const unsigned long long mask = __builtin_amdgcn_ballot_w64(m);
-        if (lane == 0) p.matchBits[(size_t)seed * kMatchWords + c] = mask;
+        bool ok[2];
+        size_t idx[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+        {
+          const int cell = c * 128 + h * 64 + lane;
+          const int dy = cell / kMatchSide - kMatchLo, dx = cell - (cell / kMatchSide) * kMatchSide - kMatchLo;
+          const uint32_t cx = sx + (uint32_t)dx, cy = sy + (uint32_t)dy; // wraps for negative offsets => fails the range test
+          ok[h] = cell < kMatchCells && (dx | dy) != 0 && cx < p.blocksX && cy < p.blocksY;
+          idx[h] = ok[h] ? (size_t)cy * p.blocksX + cx : (size_t)seed;
+        }
+        bool m0 = false, m1 = false;
+        if (ok[0] || ok[1]) m_matches_pair<CH>(a, p.pass1[idx[0]], p.pass1[idx[1]], m0, m1);
+        const unsigned long long mask0 = __builtin_amdgcn_ballot_w64(m0 && ok[0]), mask1 = __builtin_amdgcn_ballot_w64(m1 && ok[1]);
+        if (lane == 0)
+        {
+          p.matchBits[(size_t)seed * kMatchWords + 2 * c] = mask0;
+          p.matchBits[(size_t)seed * kMatchWords + 2 * c + 1] = mask1;
+        }
       }
     }
 

@@ -4,7 +4,7 @@
 // from the centre third, in all four directions) while every block of the next row / column strip is unused and "matches" the seed
 // (src/limg.cpp:1288-1496).  Which rectangle a seed gets depends on everything claimed before it, so the scan itself is serial; the
 // expensive part -- the similarity predicate, ~2500 flops a pair -- is not: the GPU evaluates it for every block against its
-// (2 W + 1)^2 neighbourhood (k_blocked_match) and this scan only looks bits up.  Pairs farther apart than W blocks are evaluated
+// 18 x 18 neighbourhood (k_blocked_match; offsets -5 .. +12) and this scan only looks bits up.  Pairs outside that window are evaluated
 // here, with the same float operations in the same order (built with -ffp-contract=off, like the kernels).
 //
 // Host-only translation unit (no HIP).
@@ -18,8 +18,8 @@
 
 namespace limg_hip
 {
-  constexpr int kMatchWindow = 8; // keep in sync with limg_hip_internal.h
-  constexpr int kMatchSide = 2 * kMatchWindow + 1;
+  constexpr int kMatchLo = 5, kMatchHi = 12; // keep in sync with limg_hip_internal.h
+  constexpr int kMatchSide = kMatchLo + kMatchHi + 1;
   constexpr int kMatchWords = (kMatchSide * kMatchSide + 63) / 64;
 
   struct HostRegion { uint32_t ox, oy, rx, ry, keep; };
@@ -118,68 +118,64 @@ namespace limg_hip
       int ch;
       std::vector<uint8_t> used;
 
-      bool match(size_t sx, size_t sy, size_t cx, size_t cy) const
+      // One expansion (src/limg.cpp:1288-1384) from the seed at (ox, oy).  A strip joins when every block of it is unused
+      // (src/limg.cpp:1121-1135) and matches the seed (:1271-1286); neither test has side effects, so they are fused per block.
+      void expand(uint32_t &ox, uint32_t &oy, uint32_t &rx, uint32_t &ry, bool upLeft) const
       {
-        const long dx = (long)cx - (long)sx, dy = (long)cy - (long)sy;
-        if (bits && dx >= -kMatchWindow && dx <= kMatchWindow && dy >= -kMatchWindow && dy <= kMatchWindow)
-        {
-          const unsigned cell = (unsigned)((dy + kMatchWindow) * kMatchSide + (dx + kMatchWindow));
-          return (bits[(sy * bx + sx) * kMatchWords + (cell >> 6)] >> (cell & 63)) & 1ull;
-        }
-        return blocked_matches_host(ch, rec[sy * bx + sx], rec[cy * bx + cx]);
-      }
-      // src/limg.cpp:1121-1135 and :1271-1286 for one strip of blocks
-      bool strip_ok(size_t sx, size_t sy, size_t ox, size_t oy, size_t rx, size_t ry) const
-      {
-        for (size_t y = 0; y < ry; y++)
-          for (size_t x = 0; x < rx; x++)
-            if (used[(oy + y) * bx + ox + x]) return false;
-        for (size_t y = 0; y < ry; y++)
-          for (size_t x = 0; x < rx; x++)
-            if (!match(sx, sy, ox + x, oy + y)) return false;
-        return true;
-      }
-      // src/limg.cpp:1288-1384
-      void expand(size_t &ox, size_t &oy, size_t &rx, size_t &ry, bool upLeft) const
-      {
-        const size_t sx = ox, sy = oy;
+        const uint32_t sx = ox, sy = oy;
+        const size_t seed = (size_t)sy * bx + sx;
+        const unsigned long long *row = bits ? bits + seed * kMatchWords : nullptr;
+        auto ok = [&](uint32_t cx, uint32_t cy) -> bool {
+          const size_t ci = (size_t)cy * bx + cx;
+          if (used[ci]) return false;
+          const unsigned ux = cx - sx + kMatchLo, uy = cy - sy + kMatchLo; // wraps for offsets below -kMatchLo
+          if (row && ux < (unsigned)kMatchSide && uy < (unsigned)kMatchSide)
+          {
+            const unsigned cell = uy * kMatchSide + ux;
+            return (row[cell >> 6] >> (cell & 63)) & 1ull;
+          }
+          return blocked_matches_host(ch, rec[seed], rec[ci]);
+        };
+        auto column = [&](uint32_t x, uint32_t y0, uint32_t n) { for (uint32_t i = 0; i < n; i++) if (!ok(x, y0 + i)) return false; return true; };
+        auto line = [&](uint32_t y, uint32_t x0, uint32_t n) { for (uint32_t i = 0; i < n; i++) if (!ok(x0 + i, y)) return false; return true; };
         bool up = upLeft, down = true, left = upLeft, right = true;
         while (up || down || left || right)
         {
-          if (right) { if (ox + rx + 1 < bx && strip_ok(sx, sy, ox + rx, oy, 1, ry)) rx++; else right = false; }
-          if (down) { if (oy + ry + 1 < by && strip_ok(sx, sy, ox, oy + ry, rx, 1)) ry++; else down = false; }
+          if (right) { if (ox + rx + 1 < bx && column(ox + rx, oy, ry)) rx++; else right = false; }
+          if (down) { if (oy + ry + 1 < by && line(oy + ry, ox, rx)) ry++; else down = false; }
           if (upLeft)
           {
-            if (up) { if (oy > 0 && strip_ok(sx, sy, ox, oy - 1, rx, 1)) { oy--; ry++; } else up = false; }
-            if (left) { if (ox > 0 && strip_ok(sx, sy, ox - 1, oy, 1, ry)) { ox--; rx++; } else left = false; }
+            if (up) { if (oy > 0 && line(oy - 1, ox, rx)) { oy--; ry++; } else up = false; }
+            if (left) { if (ox > 0 && column(ox - 1, oy, ry)) { ox--; rx++; } else left = false; }
           }
         }
       }
       // src/limg.cpp:1386-1496
-      bool find(bool acceptTiny, size_t &staticX, size_t &staticY, HostRegion &out) const
+      bool find(bool acceptTiny, uint32_t &staticX, uint32_t &staticY, HostRegion &out) const
       {
-        size_t ox = staticX, oy = staticY;
+        uint32_t ox = staticX, oy = staticY;
         for (; oy < by; oy++)
         {
+          const uint8_t *urow = &used[(size_t)oy * bx];
           for (; ox < bx; ox++)
           {
-            if (used[oy * bx + ox]) continue;
-            size_t x = ox, y = oy, rx = 1, ry = 1;
+            if (urow[ox]) continue;
+            uint32_t x = ox, y = oy, rx = 1, ry = 1;
             expand(x, y, rx, ry, false);
             if (rx == 1 && ry == 1) continue;
             if (!acceptTiny)
             {
               if (!(rx >= 3 && ry >= 3)) continue;
-              size_t cx = ox + rx / 3, cy = oy + ry / 3, crx = rx / 3, cry = ry / 3;
+              uint32_t cx = ox + rx / 3, cy = oy + ry / 3, crx = rx / 3, cry = ry / 3; // second attempt from the centre third, all four directions
               expand(cx, cy, crx, cry, true);
-              if (crx * cry > rx * ry)
+              if ((uint64_t)crx * cry > (uint64_t)rx * ry)
               {
-                out = { (uint32_t)cx, (uint32_t)cy, (uint32_t)crx, (uint32_t)cry, 0u };
+                out = { cx, cy, crx, cry, 0u };
                 staticX = ox; staticY = oy;
                 return true;
               }
             }
-            out = { (uint32_t)ox, (uint32_t)oy, (uint32_t)rx, (uint32_t)ry, 0u };
+            out = { ox, oy, rx, ry, 0u };
             staticX = ox + rx; staticY = oy;
             return true;
           }
@@ -204,7 +200,7 @@ namespace limg_hip
     out.clear();
     for (int tiny = 0; tiny < 2; tiny++)
     {
-      size_t sx = 0, sy = 0;
+      uint32_t sx = 0, sy = 0;
       HostRegion r;
       while (m.find(tiny != 0, sx, sy, r)) { m.claim(r); out.push_back(r); }
     }

@@ -73,9 +73,13 @@ namespace limg_hip
   void launch_dither_store(const EncodeParams &p, int channels, hipStream_t s);
 
   // ---- merged-block encoder (limg_hip_blocked.hip; reference: limg_blocked_encode3d_test, src/limg.cpp:1774-1885, :2329-2453) ----
-  constexpr int kMatchWindow = 8;                                            // match bits are precomputed for |dx|, |dy| <= 8 blocks around every seed
-  constexpr int kMatchCells = (2 * kMatchWindow + 1) * (2 * kMatchWindow + 1); // 289
-  constexpr int kMatchWords = (kMatchCells + 63) / 64;                         // 5 x 64 bits per seed
+  // similarity bits are precomputed for candidate offsets dx, dy in [-kMatchLo, +kMatchHi] blocks around every seed: rectangles grow right / down from
+  // their seed (far), and up / left only in the second attempt from the centre third (near); measured on the synthetic workloads, this window answers
+  // 99.7 % of the merge's queries (the rest is evaluated on the host)
+  constexpr int kMatchLo = 5, kMatchHi = 12;
+  constexpr int kMatchSide = kMatchLo + kMatchHi + 1;   // 18
+  constexpr int kMatchCells = kMatchSide * kMatchSide;  // 324
+  constexpr int kMatchWords = (kMatchCells + 63) / 64;  // 6 x 64 bits per seed
 
   struct RegionDesc // one rectangle of 8x8 blocks, in creation (= block index = dither chain) order
   {

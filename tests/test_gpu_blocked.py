@@ -33,7 +33,7 @@ def _input(orc, e):
 def test_stagewise_small(gpu, oracle):
     """Localises a mismatch: rectangles (merge over GPU similarity bits), then the planes."""
     for kind, alpha, shape in (("pn", True, (256, 128)), ("rg", True, (256, 128)), ("rga", True, (203, 61)), ("pn", False, (131, 77)), ("rg", False, (64, 64)),
-                               ("pn", True, (8, 8)), ("flat", True, (96, 80))):
+                               ("pn", True, (8, 8)), ("flat", True, (96, 80)), ("flat", True, (200, 168))):  # the last one: rectangles wider than the similarity window
         w, h = shape
         if kind == "flat":
             img = np.full((h, w), 0xFF336699, dtype=np.uint32)
@@ -71,7 +71,7 @@ def test_reference_hashes(gpu, oracle, name):
 
 
 def test_window_fallback_and_forced_shifts(gpu, oracle):
-    """Rectangles wider than the precomputed similarity window (8 blocks) make the host evaluate the predicate itself; forced shifts bypass the search."""
+    """A wide rectangle (part of it beyond the precomputed similarity window: the host evaluates those pairs itself); forced shifts bypass the search."""
     img = np.zeros((64, 512), dtype=np.uint32)
     img[:] = 0xFF000000 | (np.arange(512, dtype=np.uint32)[None, :] // 4) * 0x010101  # a slow horizontal ramp: one very wide rectangle
     want = oracle.blocked_encode3d(img, True)
