@@ -108,3 +108,16 @@ def test_device_entry_full_size(gpu, oracle):
             assert np.array_equal(got, want[k]), (kind, k)
         t = gpu.blocked_timing()
         assert t["total"] > 0 and len(gpu.blocked_regions()) == len(want["regions"])
+
+
+def test_giant_rectangle(gpu, oracle):
+    """A flat 512x512 image with a few odd blocks: one rectangle of ~250k pixels handled by a single wave (chunk loops, 64-bit block errors, long
+    pixel-order sums, host evaluation of far-apart pairs)."""
+    img = np.full((512, 512), 0xFF808080, dtype=np.uint32)
+    img[200:208, 304:312] = oracle.photo_noise(8, 8, 3)
+    img[:, :] += (np.arange(512, dtype=np.uint32)[None, :] // 128) * 0x000100
+    want = oracle.blocked_encode3d(img, True)
+    assert int((want["regions"]["rx"] * want["regions"]["ry"]).max()) > 1000
+    got = gpu.blocked_encode3d(img, True)
+    bad = [(k, int((got[k] != want[k]).sum())) for k in BLOCKED_WRITTEN if not np.array_equal(got[k], want[k])]
+    assert not bad, bad
