@@ -120,7 +120,9 @@ namespace limg_hip
 
       // One expansion (src/limg.cpp:1288-1384) from the seed at (ox, oy).  A strip joins when every block of it is unused
       // (src/limg.cpp:1121-1135) and matches the seed (:1271-1286); neither test has side effects, so they are fused per block.
-      void expand(uint32_t &ox, uint32_t &oy, uint32_t &rx, uint32_t &ry, bool upLeft) const
+      // minSide > 0 (first attempt of the large-rectangle pass only): give up as soon as the rectangle can no longer reach minSide x minSide --
+      // it grows monotonically and a direction that failed stays off, so the caller would discard it anyway (src/limg.cpp:1425-1427).
+      void expand(uint32_t &ox, uint32_t &oy, uint32_t &rx, uint32_t &ry, bool upLeft, uint32_t minSide = 0) const
       {
         const uint32_t sx = ox, sy = oy;
         const size_t seed = (size_t)sy * bx + sx;
@@ -141,8 +143,8 @@ namespace limg_hip
         bool up = upLeft, down = true, left = upLeft, right = true;
         while (up || down || left || right)
         {
-          if (right) { if (ox + rx + 1 < bx && column(ox + rx, oy, ry)) rx++; else right = false; }
-          if (down) { if (oy + ry + 1 < by && line(oy + ry, ox, rx)) ry++; else down = false; }
+          if (right) { if (ox + rx + 1 < bx && column(ox + rx, oy, ry)) rx++; else { right = false; if (rx < minSide) return; } }
+          if (down) { if (oy + ry + 1 < by && line(oy + ry, ox, rx)) ry++; else { down = false; if (ry < minSide) return; } }
           if (upLeft)
           {
             if (up) { if (oy > 0 && line(oy - 1, ox, rx)) { oy--; ry++; } else up = false; }
@@ -161,7 +163,7 @@ namespace limg_hip
           {
             if (urow[ox]) continue;
             uint32_t x = ox, y = oy, rx = 1, ry = 1;
-            expand(x, y, rx, ry, false);
+            expand(x, y, rx, ry, false, acceptTiny ? 0u : 3u);
             if (rx == 1 && ry == 1) continue;
             if (!acceptTiny)
             {
