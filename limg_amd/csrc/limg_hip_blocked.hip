@@ -236,39 +236,85 @@ namespace limg_hip
       if (!q1 && !j1) r1 = avgF.y < 3.0f;
     }
 
-    // one wave per seed; lane l of step c evaluates cells 128 c + l and 128 c + 64 + l, so the two ballots are words 2 c and 2 c + 1
+    // the two early exits of the predicate (src/limg.cpp:1168-1194) for one candidate: 1 = match, 2 = no match, 0 = the 27-colour loop decides
+    template <int CH>
+    __device__ __forceinline__ int m_early(const limg_hip_block_record &a, const MState &sa, const limg_hip_block_record &b)
+    {
+      MState sb;
+      m_init<CH>(b, sb);
+      const float w[4] = { 2, 4, 3, 3 };
+      float avgDiffSq = 0, lenA[3] = { 3, 3, 3 }, lenB[3] = { 3, 3, 3 };
+#pragma unroll
+      for (int i = 0; i < CH; i++)
+      {
+        const float d = a.avg[i] - b.avg[i];
+        avgDiffSq += d * d * w[i];
+        lenA[0] += (sa.nA[i] * sa.nA[i]) * w[i]; lenB[0] += (sb.nA[i] * sb.nA[i]) * w[i];
+        lenA[1] += (sa.nB[i] * sa.nB[i]) * w[i]; lenB[1] += (sb.nB[i] * sb.nB[i]) * w[i];
+        lenA[2] += (sa.nC[i] * sa.nC[i]) * w[i]; lenB[2] += (sb.nC[i] * sb.nC[i]) * w[i];
+      }
+      const float sumA = lenA[0] + lenA[1] + lenA[2], sumB = lenB[0] + lenB[1] + lenB[2];
+      const float ratio = (sumA + 1) / (sumB + 1);
+      const float maxAvg = (float)(16 * 3 * CH), maxRange = (float)(200 * 3 * CH);
+      if (avgDiffSq < maxAvg && sumA < maxRange && sumB < maxRange) return 1;
+      if (ratio > 1.375f || ratio < (1.f / 1.375f)) return 2;
+      return 0;
+    }
+
+    __device__ __forceinline__ void cell_to_block(const BlockedParams &p, uint32_t sx, uint32_t sy, int cell, bool &ok, size_t &idx)
+    {
+      const int dy = cell / kMatchSide - kMatchLo, dx = cell - (cell / kMatchSide) * kMatchSide - kMatchLo;
+      const uint32_t cx = sx + (uint32_t)dx, cy = sy + (uint32_t)dy; // wraps for negative offsets => fails the range test
+      ok = cell < kMatchCells && (dx | dy) != 0 && cx < p.blocksX && cy < p.blocksY;
+      idx = ok ? (size_t)cy * p.blocksX + cx : 0;
+    }
+
+    // One wave per seed.  Step 1: every cell of the window through the early exits (cheap), lane = cell; the undecided cells are compacted into
+    // a list in LDS.  Step 2: the expensive loop over the list only, two candidates per lane.
     template <int CH>
     __global__ __launch_bounds__(256) void k_blocked_match(const BlockedParams p)
     {
+      __shared__ unsigned short sList[4][kMatchWords * 64];
+      __shared__ unsigned long long sWords[4][kMatchWords];
       const uint32_t nBlocks = p.blocksX * p.blocksY;
-      const uint32_t seed = blockIdx.x * 4 + (threadIdx.x >> 6);
+      const int wave = threadIdx.x >> 6;
+      const uint32_t seed = blockIdx.x * 4 + wave;
       const int lane = lane_id();
       if (seed >= nBlocks) return;
       const uint32_t sy = seed / p.blocksX, sx = seed - sy * p.blocksX;
       const limg_hip_block_record a = p.pass1[seed];
-      static_assert(kMatchWords % 2 == 0, "two ballots per step");
-      for (int c = 0; c < kMatchWords / 2; c++)
+      MState sa;
+      m_init<CH>(a, sa);
+      uint32_t count = 0;
+      for (int c = 0; c < kMatchWords; c++)
       {
-        bool ok[2];
-        size_t idx[2];
-#pragma unroll
-        for (int h = 0; h < 2; h++)
-        {
-          const int cell = c * 128 + h * 64 + lane;
-          const int dy = cell / kMatchSide - kMatchLo, dx = cell - (cell / kMatchSide) * kMatchSide - kMatchLo;
-          const uint32_t cx = sx + (uint32_t)dx, cy = sy + (uint32_t)dy; // wraps for negative offsets => fails the range test
-          ok[h] = cell < kMatchCells && (dx | dy) != 0 && cx < p.blocksX && cy < p.blocksY;
-          idx[h] = ok[h] ? (size_t)cy * p.blocksX + cx : (size_t)seed;
-        }
-        bool m0 = false, m1 = false;
-        if (ok[0] || ok[1]) m_matches_pair<CH>(a, p.pass1[idx[0]], p.pass1[idx[1]], m0, m1);
-        const unsigned long long mask0 = __builtin_amdgcn_ballot_w64(m0 && ok[0]), mask1 = __builtin_amdgcn_ballot_w64(m1 && ok[1]);
-        if (lane == 0)
-        {
-          p.matchBits[(size_t)seed * kMatchWords + 2 * c] = mask0;
-          p.matchBits[(size_t)seed * kMatchWords + 2 * c + 1] = mask1;
-        }
+        const int cell = c * 64 + lane;
+        bool ok;
+        size_t idx;
+        cell_to_block(p, sx, sy, cell, ok, idx);
+        int e = 2;
+        if (ok) e = m_early<CH>(a, sa, p.pass1[idx]);
+        const unsigned long long yes = __builtin_amdgcn_ballot_w64(e == 1), open = __builtin_amdgcn_ballot_w64(e == 0);
+        if (lane == 0) sWords[wave][c] = yes;
+        if (e == 0) sList[wave][count + __builtin_amdgcn_mbcnt_hi((uint32_t)(open >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)open, 0u))] = (unsigned short)cell;
+        count += (uint32_t)__builtin_popcountll(open);
       }
+      wave_lds_fence();
+      for (uint32_t k = 0; k < count; k += 128)
+      {
+        const uint32_t i0 = k + lane, i1 = k + 64 + lane;
+        const bool v0 = i0 < count, v1 = i1 < count;
+        const int cell0 = sList[wave][v0 ? i0 : 0], cell1 = sList[wave][v1 ? i1 : 0];
+        bool ok0, ok1, r0 = false, r1 = false;
+        size_t idx0, idx1;
+        cell_to_block(p, sx, sy, cell0, ok0, idx0);
+        cell_to_block(p, sx, sy, cell1, ok1, idx1);
+        m_matches_pair<CH>(a, p.pass1[idx0], p.pass1[idx1], r0, r1);
+        if (v0 && r0) atomicOr(&sWords[wave][cell0 >> 6], 1ull << (cell0 & 63));
+        if (v1 && r1) atomicOr(&sWords[wave][cell1 >> 6], 1ull << (cell1 & 63));
+      }
+      wave_lds_fence();
+      if (lane < kMatchWords) p.matchBits[(size_t)seed * kMatchWords + lane] = sWords[wave][lane];
     }
 
     // ---- regions ----------------------------------------------------------------------------------------------------------------------
