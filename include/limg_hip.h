@@ -152,8 +152,9 @@ limg_hip_result limg_hip_blocked_encode3d_device(limg_hip_context *pCtx, const u
                                                  const limg_hip_blocked_encode3d_info *pInfo, uint32_t errorFactor, int fastBitCrushing, void *stream);
 /* The rectangles of the context's last merged-block encode (copies up to `capacity`, always reports the count). */
 limg_hip_result limg_hip_blocked_regions(limg_hip_context *pCtx, limg_hip_region *pRegions, size_t capacity, size_t *pCount);
-/* Milliseconds of the stages of the last merged-block encode: [0] pass 1 + similarity bits (GPU, incl. their copy to the host), [1] greedy merge (host),
- * [2] per-rectangle fit + search (GPU), [3] dither chain walk + noise upload (host), [4] dither + decode + stores (GPU), [5] total. */
+/* Milliseconds of the last merged-block encode: [0] pass 1 + similarity bits (GPU, incl. their copy to the host), [1] greedy merge (host, this thread), and --
+ * overlapped with [1] on a worker thread, summed over its batches -- [2] per-rectangle fit + search (GPU, incl. copies), [3] dither chain walk (host),
+ * [4] noise upload + dither/decode/store launch; [5] wall-clock total. */
 limg_hip_result limg_hip_blocked_timing(limg_hip_context *pCtx, double *pMs6);
 /* Host-only (no GPU touched): the block-similarity predicate `limg_encode_3d_matches` (src/limg.cpp:1137-1268) as the host merge evaluates it
  * for candidates outside the precomputed window; records in `limg_hip_block_record` layout. */

@@ -8,6 +8,10 @@
 #include <string.h>
 #include <new>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 namespace limg_hip
@@ -79,6 +83,7 @@ struct limg_hip_context
   DevBuf cmp;                                    // 8-byte accumulator of limg_hip_compare
   DevBuf bMatch, bRegions, bOut, bPx, bV, bFac, bNoise, bNoiseBase; // merged-block encoder: similarity bits, region table / results, scratch, noise
   HostBuf hRec, hBits, hDesc, hOut, hNoise, hNoiseBase;
+  hipStream_t workStream = nullptr; // the merged-block encoder's worker thread launches on its own stream
   std::vector<HostRegion> lastRegions;
   double blockedMs[6] = { 0, 0, 0, 0, 0, 0 };
   DevBuf streamFac, streamTiles, streamStatus, streamBuf; // stream packer: 3 factor planes, per-tile payload words; decode status word; host-entry staging
@@ -334,6 +339,7 @@ extern "C"
     for (DevBuf *b : bufs) b->release();
     HostBuf *hbufs[] = { &c->hRec, &c->hBits, &c->hDesc, &c->hOut, &c->hNoise, &c->hNoiseBase };
     for (HostBuf *b : hbufs) b->release();
+    if (c->workStream) (void)hipStreamDestroy(c->workStream);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     delete c;
     *ppCtx = nullptr;
@@ -756,72 +762,114 @@ extern "C"
     HIP_TRY(hipStreamSynchronize(s));
     const clk::time_point t1 = clk::now();
 
-    // the greedy raster merge (host, serial by construction; it only looks the similarity bits up)
-    blocked_merge(hRec, hBits, blocksX, blocksY, channels, c->lastRegions);
-    const std::vector<HostRegion> &regs = c->lastRegions;
-    const size_t nRegions = regs.size();
-    if ((r = c->hDesc.ensure(nRegions * sizeof(RegionDesc))) != limg_hip_success) return r;
+    // Everything after this point is a two-thread pipeline.  This thread runs the greedy raster merge (serial by construction; it only looks the
+    // similarity bits up) and publishes finished rectangles every few thousand; a worker thread takes them batch by batch, in creation order:
+    // fit + search kernel, copy of the shift words, dither chain walk for the batch (the chain is serial too, but independent of the merge),
+    // noise upload, store kernel.  Buffers are sized for the worst case up front so that nothing is reallocated while both threads run.
+    const size_t px = sizeX * sizeY;
+    const uint64_t capMax = ((uint64_t)px + 3ull * blocks + 3ull) & ~3ull; // every rectangle's scratch slice is rounded up to a multiple of 4
+    if (capMax > 0xFFFFFFF0ull) return limg_hip_error_InvalidParameter;
+    if ((r = c->hDesc.ensure(blocks * sizeof(RegionDesc))) != limg_hip_success) return r;
+    if ((r = c->hOut.ensure(blocks * sizeof(RegionOut))) != limg_hip_success) return r;
+    if ((r = c->hNoiseBase.ensure(blocks * 8 + 8)) != limg_hip_success) return r;
+    if ((r = c->hNoise.ensure(3 * px + 64)) != limg_hip_success) return r;
+    if ((r = c->bRegions.ensure(blocks * sizeof(RegionDesc))) != limg_hip_success) return r;
+    if ((r = c->bOut.ensure(blocks * sizeof(RegionOut))) != limg_hip_success) return r;
+    if ((r = c->bNoiseBase.ensure(blocks * 8 + 8)) != limg_hip_success) return r;
+    if ((r = c->bNoise.ensure(3 * px + 64)) != limg_hip_success) return r;
+    if ((r = c->bPx.ensure(capMax * 4)) != limg_hip_success) return r;
+    if ((r = c->bV.ensure(capMax * 16)) != limg_hip_success) return r;
+    if ((r = c->bFac.ensure(capMax * 3)) != limg_hip_success) return r;
+    if (!c->workStream) HIP_TRY(hipStreamCreateWithFlags(&c->workStream, hipStreamNonBlocking));
     RegionDesc *desc = (RegionDesc *)c->hDesc.p;
-    std::vector<uint32_t> npx(nRegions);
-    uint64_t cap = 0;
-    for (size_t i = 0; i < nRegions; i++)
-    {
-      const HostRegion &h = regs[i];
-      size_t xpx = (size_t)h.rx * kBlock, ypx = (size_t)h.ry * kBlock;
-      if (h.ox + h.rx == blocksX && (sizeX % kBlock)) xpx = xpx - kBlock + sizeX % kBlock;
-      if (h.oy + h.ry == blocksY && (sizeY % kBlock)) ypx = ypx - kBlock + sizeY % kBlock;
-      npx[i] = (uint32_t)(xpx * ypx);
-      desc[i] = { h.ox, h.oy, h.rx, h.ry, h.keep, (uint32_t)cap, { 0, 0 } };
-      cap += ((uint64_t)npx[i] + 3) & ~3ull;
-    }
-    if (cap > 0xFFFFFFF0ull) return limg_hip_error_InvalidParameter;
-    const clk::time_point t2 = clk::now();
-
-    if ((r = c->bRegions.ensure(nRegions * sizeof(RegionDesc))) != limg_hip_success) return r;
-    if ((r = c->bOut.ensure(nRegions * sizeof(RegionOut))) != limg_hip_success) return r;
-    if ((r = c->bPx.ensure(cap * 4)) != limg_hip_success) return r;
-    if ((r = c->bV.ensure(cap * 16)) != limg_hip_success) return r;
-    if ((r = c->bFac.ensure(cap * 3)) != limg_hip_success) return r;
-    HIP_TRY(hipMemcpyAsync(c->bRegions.p, desc, nRegions * sizeof(RegionDesc), hipMemcpyHostToDevice, s));
-    bp.regions = (const RegionDesc *)c->bRegions.p; bp.nRegions = (uint32_t)nRegions; bp.out = (RegionOut *)c->bOut.p;
-    bp.scratchPx = (uint32_t *)c->bPx.p; bp.scratchV = (float *)c->bV.p; bp.scratchFac = (uint8_t *)c->bFac.p; bp.scratchCap = (uint32_t)cap;
-    launch_blocked_fit_search(bp, s);
-    HIP_TRY(hipGetLastError());
-    if ((r = c->hOut.ensure(nRegions * sizeof(RegionOut))) != limg_hip_success) return r;
-    const RegionOut *hOut = (const RegionOut *)c->hOut.p;
-    HIP_TRY(hipMemcpyAsync(c->hOut.p, c->bOut.p, nRegions * sizeof(RegionOut), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    const clk::time_point t3 = clk::now();
-
-    // the dither chain (src/limg_internal.h:711, src/limg.cpp:1541-1551): one chain through all regions in creation order; a call over N pixels
-    // advances it by floor(N / 8) AES rounds + N % 8 PCG steps, so it is walked here, producing the byte every pixel adds
-    if ((r = c->hNoiseBase.ensure(nRegions * 8 + 8)) != limg_hip_success) return r;
+    RegionOut *hOut = (RegionOut *)c->hOut.p;
     unsigned long long *noiseBase = (unsigned long long *)c->hNoiseBase.p;
-    uint64_t total = 0;
-    for (size_t i = 0; i < nRegions; i++) { noiseBase[i] = total; total += (uint64_t)(hOut[i].shiftWord >> 24) * npx[i]; }
-    if ((r = c->hNoise.ensure(total + 64)) != limg_hip_success) return r;
     uint8_t *noise = (uint8_t *)c->hNoise.p;
-    {
-      uint64_t h = kDitherSeed;
-      const bool pcg = c->opt.dither_pcg != 0;
-      for (size_t i = 0; i < nRegions; i++)
+    std::vector<uint32_t> npx(blocks);
+    bp.scratchPx = (uint32_t *)c->bPx.p; bp.scratchV = (float *)c->bV.p; bp.scratchFac = (uint8_t *)c->bFac.p; bp.scratchCap = (uint32_t)capMax;
+    bp.noise = (const uint8_t *)c->bNoise.p;
+
+    struct Pipe { std::mutex m; std::condition_variable cv; size_t ready = 0; bool finished = false; } pipe;
+    limg_hip_result workerResult = limg_hip_success;
+    double busy[3] = { 0, 0, 0 }; // worker: fit + search (incl. copies), chain walk, store launch
+    const bool pcg = c->opt.dither_pcg != 0;
+    hipStream_t ws = c->workStream;
+
+    std::thread worker([&]() {
+      if (hipSetDevice(c->device) != hipSuccess) { workerResult = limg_hip_error_Generic; }
+      size_t done = 0;
+      uint64_t chain = kDitherSeed, noiseOff = 0;
+      for (;;)
       {
-        const uint32_t calls = hOut[i].shiftWord >> 24;
-        for (uint32_t k = 0; k < calls; k++) h = chain_call_n(h, npx[i], noise + noiseBase[i] + (uint64_t)k * npx[i], pcg);
+        size_t upto;
+        bool fin;
+        {
+          std::unique_lock<std::mutex> lk(pipe.m);
+          pipe.cv.wait(lk, [&] { return pipe.ready > done || pipe.finished; });
+          upto = pipe.ready; fin = pipe.finished;
+        }
+        if (upto == done) { if (fin) break; continue; }
+        if (workerResult != limg_hip_success) { done = upto; continue; } // keep draining so that the producer never blocks
+        const size_t n = upto - done;
+        const clk::time_point w0 = clk::now();
+        BlockedParams q = bp;
+        q.regions = (const RegionDesc *)c->bRegions.p + done; q.nRegions = (uint32_t)n; q.regionBase = (uint32_t)done;
+        q.out = (RegionOut *)c->bOut.p + done;
+        q.noiseBase = (const unsigned long long *)c->bNoiseBase.p + done;
+        bool ok = hipMemcpyAsync((RegionDesc *)c->bRegions.p + done, desc + done, n * sizeof(RegionDesc), hipMemcpyHostToDevice, ws) == hipSuccess;
+        if (ok) { launch_blocked_fit_search(q, ws); ok = hipGetLastError() == hipSuccess; }
+        ok = ok && hipMemcpyAsync(hOut + done, (RegionOut *)c->bOut.p + done, n * sizeof(RegionOut), hipMemcpyDeviceToHost, ws) == hipSuccess;
+        ok = ok && hipStreamSynchronize(ws) == hipSuccess;
+        const clk::time_point w1 = clk::now();
+        // the dither chain (src/limg_internal.h:711, src/limg.cpp:1541-1551): one chain through all rectangles in creation order; a call over N pixels
+        // advances it by floor(N / 8) AES rounds + N % 8 PCG steps, so it is walked here, producing the byte every pixel adds
+        const uint64_t noiseStart = noiseOff;
+        if (ok)
+          for (size_t i = done; i < upto; i++)
+          {
+            noiseBase[i] = noiseOff;
+            const uint32_t calls = hOut[i].shiftWord >> 24;
+            for (uint32_t k = 0; k < calls; k++, noiseOff += npx[i]) chain = chain_call_n(chain, npx[i], noise + noiseOff, pcg);
+          }
+        const clk::time_point w2 = clk::now();
+        if (ok && noiseOff > noiseStart) ok = hipMemcpyAsync((uint8_t *)c->bNoise.p + noiseStart, noise + noiseStart, noiseOff - noiseStart, hipMemcpyHostToDevice, ws) == hipSuccess;
+        ok = ok && hipMemcpyAsync((unsigned long long *)c->bNoiseBase.p + done, noiseBase + done, n * 8, hipMemcpyHostToDevice, ws) == hipSuccess;
+        if (ok) { launch_blocked_store(q, ws); ok = hipGetLastError() == hipSuccess; }
+        const clk::time_point w3 = clk::now();
+        busy[0] += ms(w0, w1); busy[1] += ms(w1, w2); busy[2] += ms(w2, w3);
+        if (!ok) workerResult = limg_hip_error_Generic;
+        done = upto;
       }
-    }
-    if ((r = c->bNoise.ensure(total + 64)) != limg_hip_success) return r;
-    if ((r = c->bNoiseBase.ensure(nRegions * 8 + 8)) != limg_hip_success) return r;
-    HIP_TRY(hipMemcpyAsync(c->bNoise.p, noise, total + 64, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(c->bNoiseBase.p, noiseBase, nRegions * 8, hipMemcpyHostToDevice, s));
-    bp.noise = (const uint8_t *)c->bNoise.p; bp.noiseBase = (const unsigned long long *)c->bNoiseBase.p;
-    const clk::time_point t4 = clk::now();
-    launch_blocked_store(bp, s);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(s)); // the pinned staging buffers are reused by the next call
+      if (workerResult == limg_hip_success && hipStreamSynchronize(ws) != hipSuccess) workerResult = limg_hip_error_Generic;
+    });
+
+    // producer: the merge; its progress callback lays the finished rectangles out (pixel counts, scratch slices) and hands them over
+    size_t laid = 0;
+    uint64_t cap = 0;
+    const std::function<void(size_t)> progress = [&](size_t count) {
+      const std::vector<HostRegion> &regs = c->lastRegions;
+      for (size_t i = laid; i < count; i++)
+      {
+        const HostRegion &h = regs[i];
+        size_t xpx = (size_t)h.rx * kBlock, ypx = (size_t)h.ry * kBlock;
+        if (h.ox + h.rx == blocksX && (sizeX % kBlock)) xpx = xpx - kBlock + sizeX % kBlock;
+        if (h.oy + h.ry == blocksY && (sizeY % kBlock)) ypx = ypx - kBlock + sizeY % kBlock;
+        npx[i] = (uint32_t)(xpx * ypx);
+        desc[i] = { h.ox, h.oy, h.rx, h.ry, h.keep, (uint32_t)cap, { 0, 0 } };
+        cap += ((uint64_t)npx[i] + 3) & ~3ull;
+      }
+      laid = count;
+      { std::lock_guard<std::mutex> lk(pipe.m); pipe.ready = count; }
+      pipe.cv.notify_one();
+    };
+    blocked_merge(hRec, hBits, blocksX, blocksY, channels, c->lastRegions, &progress);
+    const clk::time_point t2 = clk::now();
+    { std::lock_guard<std::mutex> lk(pipe.m); pipe.finished = true; }
+    pipe.cv.notify_one();
+    worker.join();
     const clk::time_point t5 = clk::now();
-    c->blockedMs[0] = ms(t0, t1); c->blockedMs[1] = ms(t1, t2); c->blockedMs[2] = ms(t2, t3); c->blockedMs[3] = ms(t3, t4); c->blockedMs[4] = ms(t4, t5); c->blockedMs[5] = ms(t0, t5);
-    return limg_hip_success;
+    c->blockedMs[0] = ms(t0, t1); c->blockedMs[1] = ms(t1, t2); c->blockedMs[2] = busy[0]; c->blockedMs[3] = busy[1]; c->blockedMs[4] = busy[2]; c->blockedMs[5] = ms(t0, t5);
+    return workerResult;
   }
 
   limg_hip_result limg_hip_blocked_regions(limg_hip_context *c, limg_hip_region *pRegions, size_t capacity, size_t *pCount)

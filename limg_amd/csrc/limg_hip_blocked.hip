@@ -647,7 +647,7 @@ namespace limg_hip
       // src/limg.cpp:1629-1636: 110 / 136 header bits + (8 - shift) bits per factor and pixel, per-pixel average rounded to nearest
       const uint64_t bits = (uint64_t)(CH * 18 + CH * 8 + 32) + (uint64_t)n * ((8 - shift[0]) + (8 - shift[1]) + (8 - shift[2]));
       const uint8_t bpp = (uint8_t)((bits + n / 2) / n);
-      const uint32_t blockIndex = 0xFF000000u | (r + 1u);
+      const uint32_t blockIndex = 0xFF000000u | (p.regionBase + r + 1u);
       int nn[3][4], mc[3][4];
 #pragma unroll
       for (int f = 0; f < 3; f++)

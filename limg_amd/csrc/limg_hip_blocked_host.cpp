@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <functional>
 #include <vector>
 
 #include "../../include/limg_hip.h"
@@ -193,22 +194,28 @@ namespace limg_hip
     };
   }
 
-  // src/limg.cpp:1813-1881: large rectangles, then small ones, then the remaining single blocks
-  void blocked_merge(const limg_hip_block_record *pass1, const unsigned long long *matchBits, uint32_t blocksX, uint32_t blocksY, int channels, std::vector<HostRegion> &out)
+  // src/limg.cpp:1813-1881: large rectangles, then small ones, then the remaining single blocks.  `progress` (optional) is told how many rectangles
+  // of `out` are final every few thousand, so that a consumer can work on them while the scan goes on; `out` never reallocates (reserved up front).
+  void blocked_merge(const limg_hip_block_record *pass1, const unsigned long long *matchBits, uint32_t blocksX, uint32_t blocksY, int channels, std::vector<HostRegion> &out,
+                     const std::function<void(size_t)> *progress)
   {
     Merge m;
     m.rec = pass1; m.bits = matchBits; m.bx = blocksX; m.by = blocksY; m.ch = channels;
     m.used.assign((size_t)blocksX * blocksY, 0);
     out.clear();
+    out.reserve((size_t)blocksX * blocksY);
+    size_t told = 0;
+    auto tell = [&](bool force) { if (progress && (force || out.size() - told >= 4096)) { told = out.size(); (*progress)(told); } };
     for (int tiny = 0; tiny < 2; tiny++)
     {
       uint32_t sx = 0, sy = 0;
       HostRegion r;
-      while (m.find(tiny != 0, sx, sy, r)) { m.claim(r); out.push_back(r); }
+      while (m.find(tiny != 0, sx, sy, r)) { m.claim(r); out.push_back(r); tell(false); }
     }
     for (uint32_t y = 0; y < blocksY; y++)
       for (uint32_t x = 0; x < blocksX; x++)
-        if (!m.used[(size_t)y * blocksX + x]) out.push_back({ x, y, 1u, 1u, 1u });
+        if (!m.used[(size_t)y * blocksX + x]) { out.push_back({ x, y, 1u, 1u, 1u }); tell(false); }
+    tell(true);
   }
 
   // One dither call over n pixels (src/limg.cpp:824-879 / :799-822), any n: floor(n / 8) AES rounds on {h, ~h}, then n % 8 PCG steps on the

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
 #include <vector>
 
 #include "../../include/limg_hip.h"
@@ -103,8 +104,9 @@ namespace limg_hip
     int32_t crushBits, fast, forced[3];
     const limg_hip_block_record *pass1;
     unsigned long long *matchBits; // [blocks][kMatchWords]
-    const RegionDesc *regions;
+    const RegionDesc *regions; // of this launch (a batch of consecutive rectangles)
     uint32_t nRegions;
+    uint32_t regionBase;       // index of regions[0] in creation order (block index = regionBase + r + 1)
     RegionOut *out;
     uint32_t *scratchPx; // gathered pixels, region-major (src/limg.cpp:1747-1748)
     float *scratchV;     // 4 slot planes of scratchCap floats: the parked unit vectors of the current direction pass
@@ -121,7 +123,8 @@ namespace limg_hip
 
   // host side of the merged-block encoder (limg_hip_blocked_host.cpp): the greedy raster merge and the dither chain walk
   struct HostRegion { uint32_t ox, oy, rx, ry, keep; };
-  void blocked_merge(const limg_hip_block_record *pass1, const unsigned long long *matchBits, uint32_t blocksX, uint32_t blocksY, int channels, std::vector<HostRegion> &out);
+  void blocked_merge(const limg_hip_block_record *pass1, const unsigned long long *matchBits, uint32_t blocksX, uint32_t blocksY, int channels, std::vector<HostRegion> &out,
+                     const std::function<void(size_t)> *progress = nullptr);
   bool blocked_matches_host(int channels, const limg_hip_block_record &seed, const limg_hip_block_record &cand);
   uint64_t chain_call_n(uint64_t h, size_t n, uint8_t *noise, bool pcg);
 
