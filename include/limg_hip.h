@@ -119,8 +119,9 @@ int limg_hip_profile_end(limg_hip_context *pCtx, float *pMs, int maxEncodes);
 /* Host-only helpers (no GPU touched): the data-independent dither noise stream and the strip partition rule.
  *  limg_hip_host_noise_table : `calls` x 64 noise bytes of a chain of full 8x8 blocks starting at the reference's seed
  *                              (src/limg.cpp:1893); byte p of call k is what the AES dither ANDs with ditherSize for pixel p.
- *  limg_hip_host_chain_call  : one dither call's state walk over `pixelCount` (<= 64) pixels: returns the next chain value
- *                              (src/limg.cpp:824-879), optionally writing the noise bytes (64-byte buffer).
+ *  limg_hip_host_chain_call  : one dither call's state walk over `pixelCount` pixels (64 for an 8x8 block, any count for a rectangle of the
+ *                              merged-block encoder): returns the next chain value (src/limg.cpp:824-879), optionally writing the noise
+ *                              bytes (buffer of max(64, pixelCount) bytes).
  *                              forceSoftwareAes bit 0: do not use AES-NI; bit 1: PCG dither instead of AES.
  *  limg_hip_host_partition   : src/limg.cpp:2114-2134 in block rows: chain c < count-1 owns rows [c*rows, (c+1)*rows), the last the rest. */
 limg_hip_result limg_hip_host_noise_table(uint8_t *pOut, size_t calls);

@@ -420,7 +420,7 @@ extern "C"
 
   uint64_t limg_hip_host_chain_call(uint64_t chainValue, size_t pixelCount, uint8_t *pNoise64, int forceSoftwareAes)
   {
-    if (pixelCount > 64) return 0;
+    if (pixelCount > 0xFFFFFFFFull) return 0;
     return chain_call(chainValue, (unsigned)pixelCount, pNoise64, (forceSoftwareAes & 1) != 0, (forceSoftwareAes & 2) != 0);
   }
 

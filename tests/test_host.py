@@ -94,6 +94,20 @@ def test_chain_walk_partial_block_noise(lib, oracle):
             assert h == oh and np.array_equal((np.clip(t, 0, 255) >> s).astype(np.uint8), want), (n, s)
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_chain_walk_rectangles_of_any_size(lib, oracle, mode):
+    """The merged-block encoder dithers whole rectangles: one call over N pixels = floor(N / 8) AES rounds + N % 8 PCG steps (or N PCG steps)."""
+    for n in (65, 100, 1000, 4096 + 3, 64 * 37 + 5):
+        rng = np.random.default_rng(n)
+        f = rng.integers(0, 256, n, dtype=np.uint8)
+        buf = np.zeros(n + 8, dtype=np.uint8)
+        h = lib.limg_hip_host_chain_call(0xCA7F00D15BADF00D, n, buf.ctypes.data_as(C.c_void_p), mode)
+        for s in (1, 4, 7):
+            oh, want = oracle.dither(s, 0xCA7F00D15BADF00D, f, mode=(1 if mode == 2 else 0))
+            t = f.astype(np.int32) + ((buf[:n].astype(np.int32) & ((1 << s) - 1)) - (1 << (s - 1)))
+            assert h == oh and np.array_equal((np.clip(t, 0, 255) >> s).astype(np.uint8), want), (n, s, mode)
+
+
 @pytest.mark.parametrize("size_y,pool", [(8192, 0), (8192, 2), (618, 8), (200, 2), (64, 3), (24, 8), (8, 1), (1000, 7)])
 def test_partition_rule(lib, size_y, pool):
     cc, rr = C.c_uint32(), C.c_uint32()
