@@ -84,6 +84,7 @@ struct limg_hip_context
   DevBuf bMatch, bRegions, bOut, bPx, bV, bFac, bNoise, bNoiseBase; // merged-block encoder: similarity bits, region table / results, scratch, noise
   HostBuf hRec, hBits, hDesc, hOut, hNoise, hNoiseBase;
   hipStream_t workStream = nullptr; // the merged-block encoder's worker thread launches on its own stream
+  hipEvent_t workEvent[2] = { nullptr, nullptr };
   std::vector<HostRegion> lastRegions;
   double blockedMs[6] = { 0, 0, 0, 0, 0, 0 };
   DevBuf streamFac, streamTiles, streamStatus, streamBuf; // stream packer: 3 factor planes, per-tile payload words; decode status word; host-entry staging
@@ -340,6 +341,7 @@ extern "C"
     HostBuf *hbufs[] = { &c->hRec, &c->hBits, &c->hDesc, &c->hOut, &c->hNoise, &c->hNoiseBase };
     for (HostBuf *b : hbufs) b->release();
     if (c->workStream) (void)hipStreamDestroy(c->workStream);
+    for (hipEvent_t e : c->workEvent) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     delete c;
     *ppCtx = nullptr;
@@ -795,52 +797,76 @@ extern "C"
     const bool pcg = c->opt.dither_pcg != 0;
     hipStream_t ws = c->workStream;
 
+    if (!c->workEvent[0])
+      for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&c->workEvent[i], hipEventDisableTiming));
+
     std::thread worker([&]() {
       if (hipSetDevice(c->device) != hipSuccess) { workerResult = limg_hip_error_Generic; }
-      size_t done = 0;
+      // Software pipeline of depth two: the fit + search kernel of batch k + 1 is enqueued before the chain of batch k is walked, so the GPU
+      // round trip (upload, kernel, shift words back) hides behind the AES chain, which is this thread's real work.
+      struct Batch { size_t r0 = 0, r1 = 0; bool live = false; } pending;
+      size_t issued = 0;
+      int slot = 0;
       uint64_t chain = kDitherSeed, noiseOff = 0;
+      bool fin = false;
+      auto params_of = [&](const Batch &b) {
+        BlockedParams q = bp;
+        q.regions = (const RegionDesc *)c->bRegions.p + b.r0; q.nRegions = (uint32_t)(b.r1 - b.r0); q.regionBase = (uint32_t)b.r0;
+        q.out = (RegionOut *)c->bOut.p + b.r0;
+        q.noiseBase = (const unsigned long long *)c->bNoiseBase.p + b.r0;
+        return q;
+      };
       for (;;)
       {
-        size_t upto;
-        bool fin;
+        // 1. take whatever the merge has published since the last look (wait for it only if there is nothing else to do)
+        Batch next;
+        if (!fin)
         {
           std::unique_lock<std::mutex> lk(pipe.m);
-          pipe.cv.wait(lk, [&] { return pipe.ready > done || pipe.finished; });
-          upto = pipe.ready; fin = pipe.finished;
+          if (!pending.live) pipe.cv.wait(lk, [&] { return pipe.ready > issued || pipe.finished; });
+          if (pipe.ready > issued) { next.r0 = issued; next.r1 = pipe.ready; next.live = true; issued = pipe.ready; }
+          else fin = pipe.finished;
         }
-        if (upto == done) { if (fin) break; continue; }
-        if (workerResult != limg_hip_success) { done = upto; continue; } // keep draining so that the producer never blocks
-        const size_t n = upto - done;
         const clk::time_point w0 = clk::now();
-        BlockedParams q = bp;
-        q.regions = (const RegionDesc *)c->bRegions.p + done; q.nRegions = (uint32_t)n; q.regionBase = (uint32_t)done;
-        q.out = (RegionOut *)c->bOut.p + done;
-        q.noiseBase = (const unsigned long long *)c->bNoiseBase.p + done;
-        bool ok = hipMemcpyAsync((RegionDesc *)c->bRegions.p + done, desc + done, n * sizeof(RegionDesc), hipMemcpyHostToDevice, ws) == hipSuccess;
-        if (ok) { launch_blocked_fit_search(q, ws); ok = hipGetLastError() == hipSuccess; }
-        ok = ok && hipMemcpyAsync(hOut + done, (RegionOut *)c->bOut.p + done, n * sizeof(RegionOut), hipMemcpyDeviceToHost, ws) == hipSuccess;
-        ok = ok && hipStreamSynchronize(ws) == hipSuccess;
-        const clk::time_point w1 = clk::now();
-        // the dither chain (src/limg_internal.h:711, src/limg.cpp:1541-1551): one chain through all rectangles in creation order; a call over N pixels
-        // advances it by floor(N / 8) AES rounds + N % 8 PCG steps, so it is walked here, producing the byte every pixel adds
-        const uint64_t noiseStart = noiseOff;
-        if (ok)
-          for (size_t i = done; i < upto; i++)
-          {
-            noiseBase[i] = noiseOff;
-            const uint32_t calls = hOut[i].shiftWord >> 24;
-            for (uint32_t k = 0; k < calls; k++, noiseOff += npx[i]) chain = chain_call_n(chain, npx[i], noise + noiseOff, pcg);
-          }
-        const clk::time_point w2 = clk::now();
-        if (ok && noiseOff > noiseStart) ok = hipMemcpyAsync((uint8_t *)c->bNoise.p + noiseStart, noise + noiseStart, noiseOff - noiseStart, hipMemcpyHostToDevice, ws) == hipSuccess;
-        ok = ok && hipMemcpyAsync((unsigned long long *)c->bNoiseBase.p + done, noiseBase + done, n * 8, hipMemcpyHostToDevice, ws) == hipSuccess;
-        if (ok) { launch_blocked_store(q, ws); ok = hipGetLastError() == hipSuccess; }
-        const clk::time_point w3 = clk::now();
-        busy[0] += ms(w0, w1); busy[1] += ms(w1, w2); busy[2] += ms(w2, w3);
-        if (!ok) workerResult = limg_hip_error_Generic;
-        done = upto;
+        if (next.live && workerResult == limg_hip_success)
+        {
+          const size_t n = next.r1 - next.r0;
+          const BlockedParams q = params_of(next);
+          bool ok = hipMemcpyAsync((RegionDesc *)c->bRegions.p + next.r0, desc + next.r0, n * sizeof(RegionDesc), hipMemcpyHostToDevice, ws) == hipSuccess;
+          if (ok) { launch_blocked_fit_search(q, ws); ok = hipGetLastError() == hipSuccess; }
+          ok = ok && hipMemcpyAsync(hOut + next.r0, (RegionOut *)c->bOut.p + next.r0, n * sizeof(RegionOut), hipMemcpyDeviceToHost, ws) == hipSuccess;
+          ok = ok && hipEventRecord(c->workEvent[slot], ws) == hipSuccess;
+          if (!ok) workerResult = limg_hip_error_Generic;
+        }
+        // 2. finish the batch enqueued one round earlier: its shift words are (about to be) back
+        if (pending.live && workerResult == limg_hip_success)
+        {
+          bool ok = hipEventSynchronize(c->workEvent[slot ^ 1]) == hipSuccess;
+          const clk::time_point w1 = clk::now();
+          // the dither chain (src/limg_internal.h:711, src/limg.cpp:1541-1551): one chain through all rectangles in creation order; a call over N
+          // pixels advances it by floor(N / 8) AES rounds + N % 8 PCG steps, so it is walked here, producing the byte every pixel adds
+          const uint64_t noiseStart = noiseOff;
+          if (ok)
+            for (size_t i = pending.r0; i < pending.r1; i++)
+            {
+              noiseBase[i] = noiseOff;
+              const uint32_t calls = hOut[i].shiftWord >> 24;
+              for (uint32_t k = 0; k < calls; k++, noiseOff += npx[i]) chain = chain_call_n(chain, npx[i], noise + noiseOff, pcg);
+            }
+          const clk::time_point w2 = clk::now();
+          const BlockedParams q = params_of(pending);
+          if (ok && noiseOff > noiseStart) ok = hipMemcpyAsync((uint8_t *)c->bNoise.p + noiseStart, noise + noiseStart, noiseOff - noiseStart, hipMemcpyHostToDevice, ws) == hipSuccess;
+          ok = ok && hipMemcpyAsync((unsigned long long *)c->bNoiseBase.p + pending.r0, noiseBase + pending.r0, (pending.r1 - pending.r0) * 8, hipMemcpyHostToDevice, ws) == hipSuccess;
+          if (ok) { launch_blocked_store(q, ws); ok = hipGetLastError() == hipSuccess; }
+          const clk::time_point w3 = clk::now();
+          busy[0] += ms(w0, w1); busy[1] += ms(w1, w2); busy[2] += ms(w2, w3);
+          if (!ok) workerResult = limg_hip_error_Generic;
+        }
+        pending = next;
+        slot ^= 1;
+        if (!pending.live && fin) break;
       }
-      if (workerResult == limg_hip_success && hipStreamSynchronize(ws) != hipSuccess) workerResult = limg_hip_error_Generic;
+      if (hipStreamSynchronize(ws) != hipSuccess && workerResult == limg_hip_success) workerResult = limg_hip_error_Generic;
     });
 
     // producer: the merge; its progress callback lays the finished rectangles out (pixel counts, scratch slices) and hands them over

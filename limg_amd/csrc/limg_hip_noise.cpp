@@ -75,7 +75,29 @@ namespace limg_hip
       const __m128i key = _mm_set_epi64x(0x2A76E98006CB4CADLL, (long long)0x824A73EAAB705E1DULL);
       const __m128i pick = _mm_set_epi8(-1, -1, -1, -1, -1, -1, -1, -1, 14, 12, 10, 8, 6, 4, 2, 0);
       __m128i st = _mm_set_epi64x((long long)~h, (long long)h);
-      for (unsigned j = 0; j < rounds; j++)
+      unsigned j = 0;
+      if (noise && rounds >= 64 && (reinterpret_cast<uintptr_t>(noise) & 7u) == 0)
+      { // long calls (rectangles of the merged-block encoder): the bytes are written once and read by the GPU only -- stream them past the
+        // caches the concurrently running merge lives in, as whole 64-byte lines
+        for (; j < rounds && (reinterpret_cast<uintptr_t>(noise + 8 * j) & 63u); j++)
+        {
+          st = _mm_aesdec_si128(st, key);
+          _mm_storel_epi64(reinterpret_cast<__m128i *>(noise + 8 * j), _mm_shuffle_epi8(st, pick));
+        }
+        for (; j + 8 <= rounds; j += 8)
+        {
+          __m128i *line = reinterpret_cast<__m128i *>(noise + 8 * j);
+          for (int k = 0; k < 4; k++)
+          {
+            st = _mm_aesdec_si128(st, key);
+            const __m128i lo = _mm_shuffle_epi8(st, pick);
+            st = _mm_aesdec_si128(st, key);
+            _mm_stream_si128(line + k, _mm_unpacklo_epi64(lo, _mm_shuffle_epi8(st, pick)));
+          }
+        }
+        _mm_sfence();
+      }
+      for (; j < rounds; j++)
       {
         st = _mm_aesdec_si128(st, key);
         if (noise) _mm_storel_epi64(reinterpret_cast<__m128i *>(noise + 8 * j), _mm_shuffle_epi8(st, pick));
