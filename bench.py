@@ -135,7 +135,25 @@ def run_sharded(args, g, dist, rank, world):
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        if args.config == 5:
+        if args.config == 5 and args.gather_stream:
+            # the north-star's shape: only the bitstream crosses xGMI; rank 0 decodes every strip into its rows of the full image
+            per = 8 // world
+            full = torch.empty((H, W), dtype=torch.int32, device="cuda") if rank == 0 else None
+            for k in range(per):
+                st, nb = g.encode_stream_device(units[k][0], True, error_factor=args.error_factor)
+                parts = shard.gather_bytes(st if on_gpu else st.cpu(), nb, dist, dst=0)
+                if rank == 0:
+                    for r in range(world):
+                        y0, y1 = rows[r * per + k]
+                        part = parts[r] if on_gpu else parts[r].cuda()
+                        g.decode_stream_device(part, part.numel(), W, y1 - y0, out=full[y0:y1])
+                        gathered_bytes += part.numel()
+            torch.cuda.synchronize()
+            if rank == 0:   # decoded strips == the pDecoded planes of the same strips (this rank's own, checked here)
+                for k in range(per):
+                    y0, y1 = rows[k]
+                    assert torch.equal(full[y0:y1], units[k][1]["pDecoded"]), "stream round trip differs from pDecoded"
+        elif args.config == 5:
             per = 8 // world
             for k in range(per):   # strip k of every rank; rows of the gathered pieces come from the strip table
                 planes = units[k][1] if on_gpu else {n: v.cpu() for n, v in units[k][1].items()}
@@ -178,7 +196,7 @@ def run_sharded(args, g, dist, rank, world):
             "config": {"workload": name + ", errorFactor %d, fast bit-crush" % args.error_factor,
                        "parallelism": "no data-path collective; plane reassembly on rank 0 timed apart",
                        "gather_ms": None if gather_ms is None else round(gather_ms, 3), "gathered_bytes_rank0": gathered_bytes,
-                       "gather_backend": None if dist is None else dist.get_backend()},
+                       "gather_backend": None if dist is None else dist.get_backend(), "gathered": "LMG3 streams, decoded on rank 0" if args.gather_stream else "planes"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": None, "algorithmic_bytes_per_launch": int(ALGO_BYTES_PER_PX * px_per_launch),
                          "kernels_ms": {"k_encode_persistent": round(float(kavg[0]), 4)},
@@ -331,6 +349,8 @@ def main():
     ap.add_argument("--blocked", action="store_true", help="merged-block encoder limg_blocked_encode3d_test (SURVEY 8(f) #1): GPU kernels + host merge / chain walk")
     ap.add_argument("--images", type=int, default=64, help="--config 4: images in the batch")
     ap.add_argument("--no-gather", action="store_true", help="--config 4/5: skip the reassembly of the planes on rank 0")
+    ap.add_argument("--gather-stream", action="store_true", help="--config 5: reassemble through the compact LMG3 stream instead of the planes: every rank encodes its "
+                                                                     "strips to streams, rank 0 gathers the bytes and decodes them into the full image")
     args = ap.parse_args()
 
     import torch

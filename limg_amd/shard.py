@@ -66,3 +66,22 @@ def gather_planes(planes, rows, width, dist, dst=0):
         else:
             dist.send(t.contiguous(), dst=dst)
     return out if rank == dst else None
+
+
+def gather_bytes(buf, nbytes, dist, dst=0):
+    """Variable-size gather of one byte tensor per rank (the compact LMG3 stream of a rank's strip / image) to rank `dst`: sizes first
+    (one all_gather of an int64 per rank), then grouped point-to-point transfers of exactly the used bytes.  Returns the list of tensors on `dst`."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = buf.device
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([int(nbytes)], dtype=torch.int64, device=dev))
+    sizes = [int(t.item()) for t in sizes]
+    if rank == dst:
+        parts = [buf[:sizes[r]] if r == dst else torch.empty(sizes[r], dtype=torch.uint8, device=dev) for r in range(world)]
+        reqs = [dist.irecv(parts[r], src=r) for r in range(world) if r != dst]
+        for q in reqs:
+            q.wait()
+        return parts
+    dist.send(buf[:sizes[rank]].contiguous(), dst=dst)
+    return None

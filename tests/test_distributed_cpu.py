@@ -78,3 +78,33 @@ def test_plans():
     assert shard.equivalent_pool_threads(8) == 2 and shard.equivalent_pool_threads(2) is None
     assert shard.batch_assignment(64, 8, 3) == list(range(3, 64, 8))
     assert sorted(sum((shard.batch_assignment(10, 4, r) for r in range(4)), [])) == list(range(10))
+
+
+def _bytes_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from limg_amd import shard
+    n = 1000 + 37 * rank                       # every rank's stream has its own size
+    buf = torch.zeros(4096, dtype=torch.uint8)  # worst-case buffer, only the first n bytes are meaningful
+    buf[:n] = torch.arange(n, dtype=torch.int64).remainder(251).to(torch.uint8) + rank
+    parts = shard.gather_bytes(buf, n, dist, dst=0)
+    if rank == 0:
+        assert len(parts) == world
+        for r in range(world):
+            want = (torch.arange(1000 + 37 * r, dtype=torch.int64).remainder(251).to(torch.uint8) + r)
+            assert parts[r].numel() == 1000 + 37 * r and torch.equal(parts[r], want), r
+        open(os.path.join(tmp, "ok"), "w").write("1")
+    else:
+        assert parts is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_variable_size_stream_gather(tmp_path, world):
+    """What config 5's `--gather-stream` does between the ranks: only the used bytes of every rank's compact stream travel to rank 0."""
+    port = _free_port()
+    mp.spawn(_bytes_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), "ok"))
