@@ -1,9 +1,10 @@
 /* limg_hip.h -- C ABI of liblimg_hip.so: the MI355X (gfx950) implementation of limg's encode hot path.
  *
- * Drop-in boundary for the reference's `limg_encode3d_test` / `limg_encode3d_test_perf` / `limg_compare`
- * (reference: src/limg.h:27-48; the reference has no FFI layer, its API is plain C++ functions).  Every entry point
- * below names the reference interface it replaces.  Plain pointers and sizes only; no C++ or torch types.
- * A header-only C++ shim with the *exact* reference signatures is in include/limg_hip_shim.hpp.
+ * Drop-in boundary for the reference's `limg_encode3d_test` / `limg_encode3d_test_perf` / `limg_compare` and (further down)
+ * `limg_blocked_encode3d_test` (reference: src/limg.h:27-48; the reference has no FFI layer, its API is plain C++ functions), plus
+ * the build-defined compact stream pair the task names `limg_encode` / `limg_decode`.  Every entry point below names the reference
+ * interface it replaces.  Plain pointers and sizes only; no C++ or torch types.  A header-only C++ shim with the *exact* reference
+ * signatures is in include/limg_hip_shim.hpp.  There is no CPU fallback: without a HIP device limg_hip_init fails.
  *
  * Data layout (identical to the reference, src/limg.h:29-33 and SURVEY.md 8(b)):
  *   pIn            row-major uint32 RGBA8, byte 0 = R, sizeX*sizeY elements, row stride sizeX
