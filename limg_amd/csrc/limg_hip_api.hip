@@ -85,6 +85,8 @@ struct limg_hip_context
   HostBuf hRec, hBits, hDesc, hOut, hNoise, hNoiseBase;
   hipStream_t workStream = nullptr; // the merged-block encoder's worker thread launches on its own stream
   hipEvent_t workEvent[2] = { nullptr, nullptr };
+  hipStream_t copyStream = nullptr;      // copies of the similarity-bit bands, behind the kernels that produce them
+  std::vector<hipEvent_t> bandEvents;
   std::vector<HostRegion> lastRegions;
   double blockedMs[6] = { 0, 0, 0, 0, 0, 0 };
   DevBuf streamFac, streamTiles, streamStatus, streamBuf; // stream packer: 3 factor planes, per-tile payload words; decode status word; host-entry staging
@@ -342,6 +344,8 @@ extern "C"
     for (HostBuf *b : hbufs) b->release();
     if (c->workStream) (void)hipStreamDestroy(c->workStream);
     for (hipEvent_t e : c->workEvent) if (e) (void)hipEventDestroy(e);
+    if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
+    for (hipEvent_t e : c->bandEvents) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     delete c;
     *ppCtx = nullptr;
@@ -752,17 +756,50 @@ extern "C"
     if ((r = c->bMatch.ensure(blocks * kMatchWords * 8)) != limg_hip_success) return r;
     bp.matchBits = (unsigned long long *)c->bMatch.p;
     bp.info = *pInfo;
-    launch_blocked_match(bp, s);
-    HIP_TRY(hipGetLastError());
-
+    // The similarity bits are produced and copied band by band (block rows) so that the merge, which consumes seeds in raster order, can start
+    // after the first band: kernel launches on `s`, copies on a second stream chained by events.
     if ((r = c->hRec.ensure(blocks * sizeof(limg_hip_block_record))) != limg_hip_success) return r;
     if ((r = c->hBits.ensure(blocks * kMatchWords * 8)) != limg_hip_success) return r;
     limg_hip_block_record *hRec = (limg_hip_block_record *)c->hRec.p;
     unsigned long long *hBits = (unsigned long long *)c->hBits.p;
-    HIP_TRY(hipMemcpyAsync(hRec, c->records.p, blocks * sizeof(limg_hip_block_record), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(hBits, c->bMatch.p, blocks * kMatchWords * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    constexpr uint32_t kBands = 16;
+    const uint32_t bandRows = (blocksY + kBands - 1) / kBands, nBands = (blocksY + bandRows - 1) / bandRows;
+    if (!c->copyStream) HIP_TRY(hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
+    while (c->bandEvents.size() < 2 * kBands + 1)
+    {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      c->bandEvents.push_back(e);
+    }
+    hipStream_t cs = c->copyStream;
+    hipEvent_t evPass1 = c->bandEvents[2 * kBands];
+    HIP_TRY(hipEventRecord(evPass1, s));
+    HIP_TRY(hipStreamWaitEvent(cs, evPass1, 0));
+    HIP_TRY(hipMemcpyAsync(hRec, c->records.p, blocks * sizeof(limg_hip_block_record), hipMemcpyDeviceToHost, cs));
+    HIP_TRY(hipEventRecord(evPass1, cs)); // reused: now "records are on the host"
+    for (uint32_t b = 0; b < nBands; b++)
+    {
+      const uint32_t row0 = b * bandRows, rows = min(bandRows, blocksY - row0);
+      bp.seedBase = row0 * blocksX; bp.seedCount = rows * blocksX;
+      launch_blocked_match(bp, s);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(c->bandEvents[2 * b], s));
+      HIP_TRY(hipStreamWaitEvent(cs, c->bandEvents[2 * b], 0));
+      HIP_TRY(hipMemcpyAsync(hBits + (size_t)bp.seedBase * kMatchWords, (unsigned long long *)c->bMatch.p + (size_t)bp.seedBase * kMatchWords, (size_t)bp.seedCount * kMatchWords * 8,
+                             hipMemcpyDeviceToHost, cs));
+      HIP_TRY(hipEventRecord(c->bandEvents[2 * b + 1], cs));
+    }
+    HIP_TRY(hipEventSynchronize(evPass1));
     const clk::time_point t1 = clk::now();
+    uint32_t bandsReady = 0;
+    bool bandError = false;
+    const std::function<void(uint32_t)> needSeedRow = [&](uint32_t row) {
+      while (bandsReady < nBands && row >= bandsReady * bandRows)
+      {
+        if (hipEventSynchronize(c->bandEvents[2 * bandsReady + 1]) != hipSuccess) bandError = true;
+        bandsReady++;
+      }
+    };
 
     // Everything after this point is a two-thread pipeline.  This thread runs the greedy raster merge (serial by construction; it only looks the
     // similarity bits up) and publishes finished rectangles every few thousand; a worker thread takes them batch by batch, in creation order:
@@ -888,13 +925,15 @@ extern "C"
       { std::lock_guard<std::mutex> lk(pipe.m); pipe.ready = count; }
       pipe.cv.notify_one();
     };
-    blocked_merge(hRec, hBits, blocksX, blocksY, channels, c->lastRegions, &progress);
+    blocked_merge(hRec, hBits, blocksX, blocksY, channels, c->lastRegions, &progress, &needSeedRow);
+    needSeedRow(blocksY - 1); // every band's copy is complete before the staging buffers can be reused
     const clk::time_point t2 = clk::now();
     { std::lock_guard<std::mutex> lk(pipe.m); pipe.finished = true; }
     pipe.cv.notify_one();
     worker.join();
     const clk::time_point t5 = clk::now();
     c->blockedMs[0] = ms(t0, t1); c->blockedMs[1] = ms(t1, t2); c->blockedMs[2] = busy[0]; c->blockedMs[3] = busy[1]; c->blockedMs[4] = busy[2]; c->blockedMs[5] = ms(t0, t5);
+    if (bandError) return limg_hip_error_Generic;
     return workerResult;
   }
 

@@ -276,11 +276,10 @@ namespace limg_hip
     {
       __shared__ unsigned short sList[4][kMatchWords * 64];
       __shared__ unsigned long long sWords[4][kMatchWords];
-      const uint32_t nBlocks = p.blocksX * p.blocksY;
       const int wave = threadIdx.x >> 6;
-      const uint32_t seed = blockIdx.x * 4 + wave;
+      const uint32_t seed = p.seedBase + blockIdx.x * 4 + wave;
       const int lane = lane_id();
-      if (seed >= nBlocks) return;
+      if (seed >= p.seedBase + p.seedCount) return;
       const uint32_t sy = seed / p.blocksX, sx = seed - sy * p.blocksX;
       const limg_hip_block_record a = p.pass1[seed];
       MState sa;
@@ -718,8 +717,8 @@ namespace limg_hip
 
   void launch_blocked_match(const BlockedParams &p, hipStream_t s)
   {
-    const uint32_t nBlocks = p.blocksX * p.blocksY;
-    const dim3 grid((nBlocks + 3) / 4), block(256);
+    if (p.seedCount == 0) return;
+    const dim3 grid((p.seedCount + 3) / 4), block(256);
     if (p.channels == 4) hipLaunchKernelGGL(k_blocked_match<4>, grid, block, 0, s, p);
     else hipLaunchKernelGGL(k_blocked_match<3>, grid, block, 0, s, p);
   }

@@ -118,6 +118,8 @@ namespace limg_hip
       uint32_t bx, by;
       int ch;
       std::vector<uint8_t> used;
+      const std::function<void(uint32_t)> *needRow = nullptr; // the similarity bits arrive band by band: called before a seed row's bits are first read
+      mutable uint32_t rowsSeen = 0;
 
       // One expansion (src/limg.cpp:1288-1384) from the seed at (ox, oy).  A strip joins when every block of it is unused
       // (src/limg.cpp:1121-1135) and matches the seed (:1271-1286); neither test has side effects, so they are fused per block.
@@ -126,6 +128,7 @@ namespace limg_hip
       void expand(uint32_t &ox, uint32_t &oy, uint32_t &rx, uint32_t &ry, bool upLeft, uint32_t minSide = 0) const
       {
         const uint32_t sx = ox, sy = oy;
+        if (needRow && sy >= rowsSeen) { (*needRow)(sy); rowsSeen = sy + 1; }
         const size_t seed = (size_t)sy * bx + sx;
         const unsigned long long *row = bits ? bits + seed * kMatchWords : nullptr;
         auto ok = [&](uint32_t cx, uint32_t cy) -> bool {
@@ -197,10 +200,10 @@ namespace limg_hip
   // src/limg.cpp:1813-1881: large rectangles, then small ones, then the remaining single blocks.  `progress` (optional) is told how many rectangles
   // of `out` are final every few thousand, so that a consumer can work on them while the scan goes on; `out` never reallocates (reserved up front).
   void blocked_merge(const limg_hip_block_record *pass1, const unsigned long long *matchBits, uint32_t blocksX, uint32_t blocksY, int channels, std::vector<HostRegion> &out,
-                     const std::function<void(size_t)> *progress)
+                     const std::function<void(size_t)> *progress, const std::function<void(uint32_t)> *needSeedRow)
   {
     Merge m;
-    m.rec = pass1; m.bits = matchBits; m.bx = blocksX; m.by = blocksY; m.ch = channels;
+    m.rec = pass1; m.bits = matchBits; m.bx = blocksX; m.by = blocksY; m.ch = channels; m.needRow = needSeedRow;
     m.used.assign((size_t)blocksX * blocksY, 0);
     out.clear();
     out.reserve((size_t)blocksX * blocksY);
