@@ -925,7 +925,9 @@ extern "C"
       { std::lock_guard<std::mutex> lk(pipe.m); pipe.ready = count; }
       pipe.cv.notify_one();
     };
-    blocked_merge(hRec, hBits, blocksX, blocksY, channels, c->lastRegions, &progress, &needSeedRow);
+    bool mergeFailed = false;
+    try { blocked_merge(hRec, hBits, blocksX, blocksY, channels, c->lastRegions, &progress, &needSeedRow); }
+    catch (...) { mergeFailed = true; } // out of host memory: the worker must still be released and joined
     needSeedRow(blocksY - 1); // every band's copy is complete before the staging buffers can be reused
     const clk::time_point t2 = clk::now();
     { std::lock_guard<std::mutex> lk(pipe.m); pipe.finished = true; }
@@ -933,6 +935,7 @@ extern "C"
     worker.join();
     const clk::time_point t5 = clk::now();
     c->blockedMs[0] = ms(t0, t1); c->blockedMs[1] = ms(t1, t2); c->blockedMs[2] = busy[0]; c->blockedMs[3] = busy[1]; c->blockedMs[4] = busy[2]; c->blockedMs[5] = ms(t0, t5);
+    if (mergeFailed) return limg_hip_error_MemoryAllocationFailure;
     if (bandError) return limg_hip_error_Generic;
     return workerResult;
   }
