@@ -78,6 +78,10 @@ def test_single_file_fixed_blocks_matches_reference(cli, oracle, tmp_path):
     import limg_amd
     st = np.fromfile(str(tmp_path / "o.lmg3"), dtype=np.uint8)
     assert limg_amd.stream_info(st) == (1024, 618, False, st.size)
+    # --decode: the stream file back to an image == the decoded image written above
+    r = subprocess.run([cli, "--decode", str(tmp_path / "o.lmg3"), str(tmp_path / "again.tga")], capture_output=True, text=True)
+    assert r.returncode == 0 and "1024 x 618 pixels, RGB." in r.stdout, r.stdout + r.stderr
+    assert np.array_equal(_read_tga(str(tmp_path / "again.tga")), _read_tga(str(tmp_path / "limg_out.tga")))
     # the stream check also works from the merged-block mode (it then encodes the 8x8 path on the side)
     r = subprocess.run([cli, PNG, "--no-output", "--single-thread", "--stream", str(tmp_path / "p.lmg3")], capture_output=True, text=True)
     assert r.returncode == 0 and "decoding it reproduces the decoded image" in r.stdout

@@ -11,7 +11,8 @@
 // of stb_image; TGAs are written uncompressed (upstream's stb writer uses RLE); the block-error plane upstream allocates but never
 // fills is not written.  Extras: `--fixed-blocks` (single-file mode with `limg_encode3d_test`, fixed 8x8 blocks, instead), `--threads <T>`
 // (size of the pool whose strip partition the 8x8 path reproduces; default: hardware threads, like limg_threading_max_threads),
-// `--out-dir <dir>`, `--stream <file>` (also write the compact LMG3 stream of the 8x8 path and verify that it decodes to that path's image).
+// `--out-dir <dir>`, `--stream <file>` (also write the compact LMG3 stream of the 8x8 path and verify that it decodes to that path's image),
+// and the extra mode `limg_hip_cli --decode <file.lmg3> [<out.tga>]`.
 #include <inttypes.h>
 #include <math.h>
 #include <stdio.h>
@@ -229,6 +230,25 @@ int main(const int argc, const char **pArgv)
   if (argc == 1)
     FAIL(EXIT_SUCCESS, "Usage:\nlimg_hip_cli [<InputFile> | --] [%s | %s <Factor> | %s | %s | %s | %s <T> | %s <dir> | %s <file>] \n  if input file is --:\n    [%s <Count>] -- <list of files>)\n",
          Arg_NoWrite, Arg_ErrorFactor, Arg_AccurateBitCrushing, Arg_SingleThreaded, Arg_FixedBlocks, Arg_Threads, Arg_OutDir, Arg_Stream, Arg_ListCount);
+
+  // extra mode: limg_hip_cli --decode <file.lmg3> [<out.tga>]   (limg_decode of a compact stream written by --stream)
+  if (!strcmp(pArgv[1], "--decode"))
+  {
+    if (argc < 3) FAIL(EXIT_FAILURE, "Usage: limg_hip_cli --decode <file.lmg3> [<out.tga>]\n");
+    std::vector<uint8_t> stream;
+    if (!read_file(pArgv[2], stream)) FAIL(EXIT_FAILURE, "Failed to read '%s'.\n", pArgv[2]);
+    size_t sx = 0, sy = 0;
+    bool alpha = false;
+    limg_result r = limg_decode_info(stream.data(), stream.size(), &sx, &sy, &alpha);
+    if (r != limg_success) FAIL(EXIT_FAILURE, "'%s' is not an LMG3 stream (0x%" PRIX32 ").\n", pArgv[2], (uint32_t)r);
+    std::vector<uint32_t> image(sx * sy);
+    r = limg_decode(stream.data(), stream.size(), image.data(), image.size());
+    if (r != limg_success) FAIL(EXIT_FAILURE, "limg_decode failed with exit code 0x%" PRIX32 ".\n", (uint32_t)r);
+    const std::string out = argc > 3 ? pArgv[3] : "limg_out.tga";
+    printf("%" PRIu64 " x %" PRIu64 " pixels, %s.\n", (uint64_t)sx, (uint64_t)sy, alpha ? "RGBA" : "RGB");
+    puts(write_tga(out, sx, sy, 4, image.data()) ? "Wrote decoded file." : "Failed to write decoded file.");
+    return EXIT_SUCCESS;
+  }
 
   const char *sourceImagePath = pArgv[1];
   bool writeEncodedImages = true, fastBitCrushing = true, useThreadPool = true, fixedBlocks = false;
