@@ -83,7 +83,9 @@ def test_full_image_hashes(gpu, oracle, name):
     assert psnr == pytest.approx(e["psnr"], abs=1e-9) and mse == pytest.approx(e["mse"], rel=1e-12)
 
 
-@pytest.mark.parametrize("w,h", [(8, 8), (5, 3), (61, 27), (264, 16), (256, 8), (1000, 40), (4, 100), (2048, 8)])
+# the last five have edge blocks of fewer than 4 pixels: upstream sums 4 pixels there regardless (src/limg.cpp:478-487, beyond the gathered data), so
+# these are pinned against the oracle only, which sums the block's own pixels
+@pytest.mark.parametrize("w,h", [(8, 8), (5, 3), (61, 27), (264, 16), (256, 8), (1000, 40), (4, 100), (2048, 8), (9, 9), (17, 10), (3, 1), (1, 1), (2, 65)])
 @pytest.mark.parametrize("alpha", [True, False])
 def test_ragged_and_edge_shapes(gpu, oracle, w, h, alpha):
     img = oracle.photo_noise(w, h, 13)
