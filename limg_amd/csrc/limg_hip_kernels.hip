@@ -629,7 +629,25 @@ namespace limg_hip
         px = (uint32_t)lane < n ? px : 0u;
         px8[i] = px;
         const V4 pf = px_to_v4(px);
-        const uint32_t s02 = wave_sum(px & 0x00FF00FFu), s13 = wave_sum((px >> 8) & 0x00FF00FFu);
+        uint32_t pxs = px;
+        if (n < 4)
+        { // Upstream's SIMD sum loop consumes at least 4 pixels (src/limg.cpp:478-487): a block of fewer than 4 also sums what the previous block of its
+          // strip left at positions n..3 of the gather buffer (:1890, :1899-1905).  Only the bottom-right corner block can be that small; the previous
+          // block in raster order is its left neighbour, or the last block of the row above for a one-block-wide image.  The first block of a strip
+          // has no predecessor (uninitialised stack upstream): nothing is added then.
+          const uint32_t bxx = strip * kStripBlocks + sb;
+          uint32_t chainStart = 0;
+          if (p.chainCount > 1 && p.chainRows != 0) chainStart = min(by / p.chainRows, p.chainCount - 1) * p.chainRows;
+          const bool hasPrev = bxx > 0 || by > chainStart;
+          if (hasPrev && (uint32_t)lane >= n && lane < 4)
+          {
+            const uint32_t pbx = bxx > 0 ? bxx - 1 : p.blocksX - 1, pby = bxx > 0 ? by : by - 1;
+            const uint32_t prx = min(p.sizeX - pbx * kBlock, (uint32_t)kBlock);
+            const uint32_t row = (uint32_t)lane / prx, col = (uint32_t)lane - row * prx; // gather index -> position inside the previous block
+            pxs = p.in[(size_t)(pby * kBlock + row) * p.sizeX + pbx * kBlock + col];
+          }
+        }
+        const uint32_t s02 = wave_sum(pxs & 0x00FF00FFu), s13 = wave_sum((pxs >> 8) & 0x00FF00FFu);
         float inv_count = 0.015625f;
         if (n != 64) inv_count = 1.0f / (float)n;
         V4 avg;

@@ -113,8 +113,17 @@ static void sum_contributions(float (*v)[4], const int *valid, size_t n, int flo
  * (src/limg_factorization.h:578-794 for 4 channels, :382-576 for 3 channels) */
 void limg_oracle_block_fit(const uint32_t *px, size_t n, int channels, int float_mode, limg_oracle_record *out)
 {
+  limg_oracle_block_fit_gathered(px, n, n, channels, float_mode, out);
+}
+
+/* `sum_n` pixels enter the channel sums, `n` everything else.  Upstream's SIMD sum loop (src/limg.cpp:478-487) always consumes at least 4 pixels:
+ * for a block of fewer than 4 it also adds px[n..3], i.e. whatever the previous block left in the gather buffer (src/limg.cpp:1890,1899-1905: the buffer
+ * lives outside the block loops).  The drivers below keep such a persistent buffer and pass sum_n = max(n, 4), which reproduces upstream bit for bit
+ * wherever a previous block exists; the very first block of a strip would read uninitialised stack upstream (zeroes here). */
+void limg_oracle_block_fit_gathered(const uint32_t *px, size_t n, size_t sum_n, int channels, int float_mode, limg_oracle_record *out)
+{
   uint32_t sum[4] = { 0, 0, 0, 0 };
-  for (size_t i = 0; i < n; i++)
+  for (size_t i = 0; i < sum_n; i++)
     for (int c = 0; c < 4; c++) sum[c] += (px[i] >> (8 * c)) & 0xFF;
 
   const float inv_count = 1.0f / (float)n;
@@ -698,7 +707,7 @@ static void encode_strip(strip_job *j)
   const limg_oracle_config *cfg = j->cfg;
   const size_t blocksX = (sizeX + LIMG_BLOCK - 1) / LIMG_BLOCK;
   uint64_t ditherLast = 0xCA7F00D15BADF00DULL; /* per strip, src/limg.cpp:1893 */
-  uint32_t pixels[64];
+  uint32_t pixels[64] = { 0 }; /* persists across the blocks of the strip, like upstream's (src/limg.cpp:1890) */
   uint8_t A[64], B[64], C[64];
   static const uint8_t bit_to_pattern[9] = { 0, 0x22, 0x44, 0x66, 0x88, 0xAA, 0xCC, 0xEE, 0xFF };
 
@@ -711,7 +720,7 @@ static void encode_strip(strip_job *j)
       for (size_t yy = 0; yy < ry; yy++) memcpy(pixels + yy * rx, j->pIn + (y + yy) * sizeX + x, rx * sizeof(uint32_t));
 
       limg_oracle_record rec;
-      limg_oracle_block_fit(pixels, n, channels, cfg->float_mode, &rec);
+      limg_oracle_block_fit_gathered(pixels, n, n < 4 ? 4 : n, channels, cfg->float_mode, &rec);
       limg_oracle_block_factors(pixels, n, channels, &rec, A, B, C);
 
       if (j->pPreA)

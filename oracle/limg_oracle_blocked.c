@@ -332,13 +332,13 @@ int limg_oracle_blocked_encode3d(const uint32_t *pIn, size_t sizeX, size_t sizeY
   if (!c.decomp || !c.inUse) { free(c.decomp); free(c.inUse); return 104; }
 
   /* pass 1: src/limg.cpp:1088-1119 (the thread pool only splits this loop; it carries no state) */
-  uint32_t pixels[64];
+  uint32_t pixels[64] = { 0 }; /* persistent gather buffer: blocks of fewer than 4 pixels also sum what the previous block left in it (see limg_oracle_block_fit_gathered) */
   for (size_t by = 0; by < c.blockY; by++)
     for (size_t bx = 0; bx < c.blockX; bx++)
     {
       const size_t rx = sizeX - bx * BLK < BLK ? sizeX - bx * BLK : BLK, ry = sizeY - by * BLK < BLK ? sizeY - by * BLK : BLK;
       for (size_t yy = 0; yy < ry; yy++) memcpy(pixels + yy * rx, pIn + (by * BLK + yy) * sizeX + bx * BLK, rx * sizeof(uint32_t));
-      limg_oracle_block_fit(pixels, rx * ry, c.channels, cfg->float_mode, &c.decomp[by * c.blockX + bx]);
+      limg_oracle_block_fit_gathered(pixels, rx * ry, rx * ry < 4 ? 4 : rx * ry, c.channels, cfg->float_mode, &c.decomp[by * c.blockX + bx]);
     }
   if (pPass1) memcpy(pPass1, c.decomp, blocks * sizeof(limg_oracle_record));
 

@@ -33,7 +33,7 @@ def _input(orc, e):
 def test_stagewise_small(gpu, oracle):
     """Localises a mismatch: rectangles (merge over GPU similarity bits), then the planes."""
     for kind, alpha, shape in (("pn", True, (256, 128)), ("rg", True, (256, 128)), ("rga", True, (203, 61)), ("pn", False, (131, 77)), ("rg", False, (64, 64)),
-                               ("pn", True, (8, 8)), ("pn", True, (9, 9)), ("rg", False, (17, 10)), ("pn", True, (1, 1)), ("flat", True, (96, 80)), ("flat", True, (200, 168))):  # the last one: rectangles wider than the similarity window
+                               ("pn", True, (8, 8)), ("pn", True, (9, 9)), ("rg", False, (17, 10)), ("pn", True, (1, 1)), ("pn", True, (2, 65)), ("pn", False, (25, 33)), ("rg", True, (265, 9)), ("flat", True, (96, 80)), ("flat", True, (200, 168))):  # the last one: rectangles wider than the similarity window
         w, h = shape
         if kind == "flat":
             img = np.full((h, w), 0xFF336699, dtype=np.uint32)

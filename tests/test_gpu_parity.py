@@ -83,13 +83,16 @@ def test_full_image_hashes(gpu, oracle, name):
     assert psnr == pytest.approx(e["psnr"], abs=1e-9) and mse == pytest.approx(e["mse"], rel=1e-12)
 
 
-# the last five have edge blocks of fewer than 4 pixels: upstream sums 4 pixels there regardless (src/limg.cpp:478-487, beyond the gathered data), so
-# these are pinned against the oracle only, which sums the block's own pixels
-@pytest.mark.parametrize("w,h", [(8, 8), (5, 3), (61, 27), (264, 16), (256, 8), (1000, 40), (4, 100), (2048, 8), (9, 9), (17, 10), (3, 1), (1, 1), (2, 65)])
+# the last ones have a corner block of fewer than 4 pixels: upstream's sum loop consumes 4 pixels regardless (src/limg.cpp:478-487) and so picks up what the
+# previous block left in the gather buffer; oracle (pinned to the reference there too) and kernels reproduce that.  (3, 1) and (1, 1): no previous block.
+@pytest.mark.parametrize("w,h", [(8, 8), (5, 3), (61, 27), (264, 16), (256, 8), (1000, 40), (4, 100), (2048, 8), (9, 9), (17, 10), (3, 1), (1, 1), (2, 65), (10, 9), (25, 33),
+                                 (1, 17), (17, 1), (265, 9), (257, 17)])
 @pytest.mark.parametrize("alpha", [True, False])
 def test_ragged_and_edge_shapes(gpu, oracle, w, h, alpha):
     img = oracle.photo_noise(w, h, 13)
     _assert_planes(gpu.encode3d(img, alpha), oracle.encode3d(img, alpha), (w, h, alpha))
+    if h >= 16:  # also with a strip partition (the corner block's predecessor must come from its own strip)
+        _assert_planes(gpu.encode3d(img, alpha, pool_threads=1), oracle.encode3d(img, alpha, pool_threads=1), (w, h, alpha, "pool"))
 
 
 @pytest.mark.parametrize("ef", [0, 1, 2, 25, 50, 100, 200, 400, 3000, 4000000000])

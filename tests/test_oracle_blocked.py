@@ -46,6 +46,8 @@ def test_golden_plane_hashes(oracle, name):
     ((64, 64), True, "rg", {}), ((72, 40), True, "pn", {}), ((37, 29), True, "rga", {}), ((131, 77), False, "pn", {}), ((8, 8), True, "pn", {}),
     ((24, 200), False, "rg", {}), ((320, 96), True, "pn", {"error_factor": 50}), ((320, 96), True, "rg", {"fast": False}), ((96, 96), True, "flat", {}),
     ((128, 128), True, "pn", {"pool_threads": 2}),
+    # corner blocks of fewer than 4 pixels: pass 1 sums stale gather-buffer entries upstream (see limg_oracle_block_fit_gathered)
+    ((9, 9), True, "pn", {}), ((17, 10), False, "pn", {}), ((2, 65), True, "pn", {}), ((25, 33), True, "rg", {}), ((11, 9), False, "rg", {}),
 ])
 def test_against_reference(oracle, ref, shape, alpha, gen, kw):
     w, h = shape

@@ -27,6 +27,20 @@ def test_planes_bit_exact(oracle, ref, name, w, h, has_alpha, ef):
         assert np.array_equal(r[k], o[k]), (k, int((r[k] != o[k]).sum()))
 
 
+@pytest.mark.parametrize("w,h", [(9, 9), (17, 10), (10, 9), (2, 65), (2, 9), (9, 2), (3, 9), (25, 33), (1, 17), (17, 1), (11, 9)])
+@pytest.mark.parametrize("has_alpha", [True, False])
+def test_corner_blocks_of_fewer_than_4_pixels(oracle, ref, w, h, has_alpha):
+    """Upstream's channel-sum loop consumes at least 4 pixels (src/limg.cpp:478-487): a smaller block also sums what the previous block left in the
+    gather buffer.  The oracle keeps the same persistent buffer, so even these shapes are bit-exact (the first block of a strip excepted: it would
+    read uninitialised stack upstream)."""
+    img = oracle.photo_noise(w, h, seed=13)
+    for pool in (0, 1):
+        r = ref.encode3d(img, has_alpha, pool_threads=pool)
+        o = oracle.encode3d(img, has_alpha, pool_threads=pool)
+        for k in PLANES:
+            assert np.array_equal(r[k], o[k]), (k, pool)
+
+
 @pytest.mark.parametrize("pool", [1, 2, 3, 8])
 def test_strip_partition(oracle, ref, pool):
     img = oracle.photo_noise(64, 200, seed=11)
