@@ -837,6 +837,7 @@ extern "C"
     if (!c->workEvent[0])
       for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&c->workEvent[i], hipEventDisableTiming));
 
+    double dbgEnqueue = 0, dbgWait = 0; int dbgBatches = 0;
     std::thread worker([&]() {
       if (hipSetDevice(c->device) != hipSuccess) { workerResult = limg_hip_error_Generic; }
       // Software pipeline of depth two: the fit + search kernel of batch k + 1 is enqueued before the chain of batch k is walked, so the GPU
@@ -865,6 +866,7 @@ extern "C"
           else fin = pipe.finished;
         }
         const clk::time_point w0 = clk::now();
+        if (next.live) dbgBatches++;
         if (next.live && workerResult == limg_hip_success)
         {
           const size_t n = next.r1 - next.r0;
@@ -875,11 +877,14 @@ extern "C"
           ok = ok && hipEventRecord(c->workEvent[slot], ws) == hipSuccess;
           if (!ok) workerResult = limg_hip_error_Generic;
         }
+        const clk::time_point w0b = clk::now();
+        dbgEnqueue += ms(w0, w0b);
         // 2. finish the batch enqueued one round earlier: its shift words are (about to be) back
         if (pending.live && workerResult == limg_hip_success)
         {
           bool ok = hipEventSynchronize(c->workEvent[slot ^ 1]) == hipSuccess;
           const clk::time_point w1 = clk::now();
+          dbgWait += ms(w0b, w1);
           // the dither chain (src/limg_internal.h:711, src/limg.cpp:1541-1551): one chain through all rectangles in creation order; a call over N
           // pixels advances it by floor(N / 8) AES rounds + N % 8 PCG steps, so it is walked here, producing the byte every pixel adds
           const uint64_t noiseStart = noiseOff;
@@ -935,6 +940,7 @@ extern "C"
     worker.join();
     const clk::time_point t5 = clk::now();
     c->blockedMs[0] = ms(t0, t1); c->blockedMs[1] = ms(t1, t2); c->blockedMs[2] = busy[0]; c->blockedMs[3] = busy[1]; c->blockedMs[4] = busy[2]; c->blockedMs[5] = ms(t0, t5);
+    if (getenv("LIMG_HIP_DEBUG_TIMING")) fprintf(stderr, "worker: %d batches, enqueue %.2f ms, event wait %.2f ms, chain %.2f ms, store enqueue %.2f ms\n", dbgBatches, dbgEnqueue, dbgWait, busy[1], busy[2]);
     if (mergeFailed) return limg_hip_error_MemoryAllocationFailure;
     if (bandError) return limg_hip_error_Generic;
     return workerResult;
