@@ -9,6 +9,9 @@
 //
 // Host-only translation unit (no HIP).
 #include <math.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <stdint.h>
 #include <string.h>
 
@@ -68,6 +71,65 @@ namespace limg_hip
     }
   }
 
+  namespace
+  {
+    // The 27 colours of src/limg.cpp:1219-1243 (x fastest, then y, then z; factors 0, 0.5, 1) projected into the seed's basis: the per-iteration
+    // term  |fa| / lenA0 + |0.5 - fb| * 2 / lenA1 + |0.5 - fc| * 2 / lenA2.  The iterations are independent (only their sum is ordered), so they can be
+    // evaluated side by side -- every lane performs exactly the scalar operation sequence.
+    void terms27(const limg_hip_block_record &a, const State &sa, const State &sb, int ch, const float invA[3], float out[32])
+    {
+      for (int i = 0; i < 27; i++)
+      {
+        const float xf = (i % 3) * 0.5f, yf = ((i / 3) % 3) * 0.5f, zf = (i / 9) * 0.5f;
+        float color[4], fa[3];
+        for (int c = 0; c < ch; c++) color[c] = sb.nA[c] * xf + sb.nB[c] * yf + sb.nC[c] * zf;
+        colour_factors(color, a, sa, ch, fa);
+        out[i] = fabsf(fa[0]) * invA[0] + fabsf(0.5f - fa[1]) * invA[1] + fabsf(0.5f - fa[2]) * invA[2];
+      }
+    }
+
+#if defined(__x86_64__)
+    __attribute__((target("avx2"))) void terms27_avx2(const limg_hip_block_record &a, const State &sa, const State &sb, int ch, const float invA[3], float out[32])
+    {
+      alignas(32) static const float XF[32] = { 0, .5f, 1, 0, .5f, 1, 0, .5f, 1, 0, .5f, 1, 0, .5f, 1, 0, .5f, 1, 0, .5f, 1, 0, .5f, 1, 0, .5f, 1, 0, 0, 0, 0, 0 };
+      alignas(32) static const float YF[32] = { 0, 0, 0, .5f, .5f, .5f, 1, 1, 1, 0, 0, 0, .5f, .5f, .5f, 1, 1, 1, 0, 0, 0, .5f, .5f, .5f, 1, 1, 1, 0, 0, 0, 0, 0 };
+      alignas(32) static const float ZF[32] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, .5f, .5f, .5f, .5f, .5f, .5f, .5f, .5f, .5f, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0 };
+      const __m256 absmask = _mm256_castsi256_ps(_mm256_set1_epi32(0x7FFFFFFF)), half = _mm256_set1_ps(0.5f), zero = _mm256_setzero_ps();
+      for (int g = 0; g < 4; g++)
+      {
+        const __m256 xf = _mm256_load_ps(XF + 8 * g), yf = _mm256_load_ps(YF + 8 * g), zf = _mm256_load_ps(ZF + 8 * g);
+        __m256 color[4], t[4], est[4];
+        for (int c = 0; c < ch; c++)
+          color[c] = _mm256_add_ps(_mm256_add_ps(_mm256_mul_ps(_mm256_set1_ps(sb.nA[c]), xf), _mm256_mul_ps(_mm256_set1_ps(sb.nB[c]), yf)), _mm256_mul_ps(_mm256_set1_ps(sb.nC[c]), zf));
+        // colour_factors(color, a, sa): same operations, same order (limg_dot starts from 0 and adds the products in index order)
+        __m256 dot = zero;
+        for (int c = 0; c < ch; c++) { t[c] = _mm256_sub_ps(color[c], _mm256_set1_ps((float)a.dirA_min[c])); dot = _mm256_add_ps(dot, _mm256_mul_ps(t[c], _mm256_set1_ps(sa.nA[c]))); }
+        const __m256 fa = _mm256_mul_ps(dot, _mm256_set1_ps(sa.invA));
+        dot = zero;
+        for (int c = 0; c < ch; c++)
+        {
+          est[c] = _mm256_add_ps(_mm256_set1_ps((float)a.dirA_min[c]), _mm256_mul_ps(fa, _mm256_set1_ps(sa.nA[c])));
+          t[c] = _mm256_sub_ps(_mm256_sub_ps(color[c], est[c]), _mm256_set1_ps((float)a.dirB_offset[c]));
+        }
+        for (int c = 0; c < ch; c++) dot = _mm256_add_ps(dot, _mm256_mul_ps(t[c], _mm256_set1_ps(sa.nB[c])));
+        const __m256 fb = _mm256_mul_ps(dot, _mm256_set1_ps(sa.invB));
+        dot = zero;
+        for (int c = 0; c < ch; c++)
+        {
+          est[c] = _mm256_add_ps(est[c], _mm256_mul_ps(fb, _mm256_set1_ps(sa.nB[c])));
+          t[c] = _mm256_sub_ps(_mm256_sub_ps(color[c], est[c]), _mm256_set1_ps((float)a.dirC_offset[c]));
+        }
+        for (int c = 0; c < ch; c++) dot = _mm256_add_ps(dot, _mm256_mul_ps(t[c], _mm256_set1_ps(sa.nC[c])));
+        const __m256 fc = _mm256_mul_ps(dot, _mm256_set1_ps(sa.invC));
+        const __m256 term = _mm256_add_ps(_mm256_add_ps(_mm256_mul_ps(_mm256_and_ps(fa, absmask), _mm256_set1_ps(invA[0])),
+                                                        _mm256_mul_ps(_mm256_and_ps(_mm256_sub_ps(half, fb), absmask), _mm256_set1_ps(invA[1]))),
+                                          _mm256_mul_ps(_mm256_and_ps(_mm256_sub_ps(half, fc), absmask), _mm256_set1_ps(invA[2])));
+        _mm256_storeu_ps(out + 8 * g, term);
+      }
+    }
+#endif
+  }
+
   // limg_encode_3d_matches (src/limg.cpp:1137-1268)
   bool blocked_matches_host(int ch, const limg_hip_block_record &a, const limg_hip_block_record &b)
   {
@@ -95,17 +157,15 @@ namespace limg_hip
     float fb[3];
     colour_factors(a.avg, b, sb, ch, fb); // loop-invariant upstream (:1236-1239 builds a colour it then does not pass)
     const float termB = fabsf(fb[0]) * invB[0] + fabsf(0.5f - fb[1]) * invB[1] + fabsf(0.5f - fb[2]) * invB[2];
-    float sum = 0, color[4], fa[3];
-    for (int z = 0; z < 3; z++)
-      for (int y = 0; y < 3; y++)
-        for (int x = 0; x < 3; x++)
-        {
-          const float xf = x * 0.5f, yf = y * 0.5f, zf = z * 0.5f;
-          for (int i = 0; i < ch; i++) color[i] = sb.nA[i] * xf + sb.nB[i] * yf + sb.nC[i] * zf;
-          colour_factors(color, a, sa, ch, fa);
-          sum += fabsf(fa[0]) * invA[0] + fabsf(0.5f - fa[1]) * invA[1] + fabsf(0.5f - fa[2]) * invA[2];
-          sum += termB;
-        }
+    float termA[32];
+#if defined(__x86_64__)
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) terms27_avx2(a, sa, sb, ch, invA, termA);
+    else
+#endif
+      terms27(a, sa, sb, ch, invA, termA);
+    float sum = 0;
+    for (int i = 0; i < 27; i++) { sum += termA[i]; sum += termB; } // upstream's accumulation order: iteration by iteration, A term then B term
     return sum * (1.f / 27) < 3.0f;
   }
 
