@@ -81,7 +81,9 @@ struct limg_hip_context
   DevBuf lookback;                               // fused path: ticket + timeout flag (16 B) then one 8-byte descriptor per work strip
   DevBuf in, planes;                             // staging for the host-pointer entry points
   DevBuf cmp;                                    // 8-byte accumulator of limg_hip_compare
+  DevBuf bFlags;
   DevBuf bMatch, bRegions, bOut, bPx, bV, bFac, bNoise, bNoiseBase; // merged-block encoder: similarity bits, region table / results, scratch, noise
+  HostBuf hFlags;
   HostBuf hRec, hBits, hDesc, hOut, hNoise, hNoiseBase;
   hipStream_t workStream = nullptr; // the merged-block encoder's worker thread launches on its own stream
   hipEvent_t workEvent[2] = { nullptr, nullptr };
@@ -338,9 +340,9 @@ extern "C"
     (void)hipDeviceSynchronize();
     DevBuf *bufs[] = { &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->lookback, &c->park, &c->in, &c->planes, &c->cmp,
                        &c->streamFac, &c->streamTiles, &c->streamStatus, &c->streamBuf,
-                       &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bV, &c->bFac, &c->bNoise, &c->bNoiseBase };
+                       &c->bFlags, &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bV, &c->bFac, &c->bNoise, &c->bNoiseBase };
     for (DevBuf *b : bufs) b->release();
-    HostBuf *hbufs[] = { &c->hRec, &c->hBits, &c->hDesc, &c->hOut, &c->hNoise, &c->hNoiseBase };
+    HostBuf *hbufs[] = { &c->hFlags, &c->hRec, &c->hBits, &c->hDesc, &c->hOut, &c->hNoise, &c->hNoiseBase };
     for (HostBuf *b : hbufs) b->release();
     if (c->workStream) (void)hipStreamDestroy(c->workStream);
     for (hipEvent_t e : c->workEvent) if (e) (void)hipEventDestroy(e);
@@ -692,7 +694,19 @@ extern "C"
     if (!pFits || !pCount) return limg_hip_error_ArgumentNull;
     if (blocksX == 0 || blocksY == 0 || blocksX > 0x0FFFFFFFull || blocksY > 0x0FFFFFFFull || (channels != 3 && channels != 4)) return limg_hip_error_InvalidParameter;
     std::vector<HostRegion> regs;
-    blocked_merge(pFits, (const unsigned long long *)pMatchBits, (uint32_t)blocksX, (uint32_t)blocksY, channels, regs);
+    std::vector<uint8_t> flags;
+    if (pMatchBits)
+    { // the per-seed viability flags the GPU kernel derives from the same bits (k_blocked_match)
+      flags.resize(blocksX * blocksY);
+      for (size_t i = 0; i < flags.size(); i++)
+      {
+        const uint64_t *w = pMatchBits + i * kMatchWords;
+        auto bit = [&](int dx, int dy) -> unsigned { const int cell = (dy + kMatchLo) * kMatchSide + dx + kMatchLo; return (unsigned)(w[cell >> 6] >> (cell & 63)) & 1u; };
+        const unsigned all8 = bit(1, 0) & bit(2, 0) & bit(0, 1) & bit(1, 1) & bit(2, 1) & bit(0, 2) & bit(1, 2) & bit(2, 2);
+        flags[i] = (uint8_t)(all8 | ((bit(1, 0) | bit(0, 1)) << 1));
+      }
+    }
+    blocked_merge(pFits, (const unsigned long long *)pMatchBits, (uint32_t)blocksX, (uint32_t)blocksY, channels, regs, nullptr, nullptr, pMatchBits ? flags.data() : nullptr);
     *pCount = regs.size();
     if (pRegions)
       for (size_t i = 0; i < regs.size() && i < capacity; i++) pRegions[i] = { regs[i].ox, regs[i].oy, regs[i].rx, regs[i].ry };
@@ -755,6 +769,10 @@ extern "C"
     bp.pass1 = (const limg_hip_block_record *)c->records.p;
     if ((r = c->bMatch.ensure(blocks * kMatchWords * 8)) != limg_hip_success) return r;
     bp.matchBits = (unsigned long long *)c->bMatch.p;
+    if ((r = c->bFlags.ensure(blocks)) != limg_hip_success) return r;
+    if ((r = c->hFlags.ensure(blocks)) != limg_hip_success) return r;
+    bp.matchFlags = (uint8_t *)c->bFlags.p;
+    uint8_t *hFlags = (uint8_t *)c->hFlags.p;
     bp.info = *pInfo;
     // The similarity bits are produced and copied band by band (block rows) so that the merge, which consumes seeds in raster order, can start
     // after the first band: kernel launches on `s`, copies on a second stream chained by events.
@@ -787,16 +805,20 @@ extern "C"
       HIP_TRY(hipStreamWaitEvent(cs, c->bandEvents[2 * b], 0));
       HIP_TRY(hipMemcpyAsync(hBits + (size_t)bp.seedBase * kMatchWords, (unsigned long long *)c->bMatch.p + (size_t)bp.seedBase * kMatchWords, (size_t)bp.seedCount * kMatchWords * 8,
                              hipMemcpyDeviceToHost, cs));
+      HIP_TRY(hipMemcpyAsync(hFlags + bp.seedBase, (uint8_t *)c->bFlags.p + bp.seedBase, bp.seedCount, hipMemcpyDeviceToHost, cs));
       HIP_TRY(hipEventRecord(c->bandEvents[2 * b + 1], cs));
     }
     HIP_TRY(hipEventSynchronize(evPass1));
     const clk::time_point t1 = clk::now();
     uint32_t bandsReady = 0;
     bool bandError = false;
+    double bandWaitMs = 0;
     const std::function<void(uint32_t)> needSeedRow = [&](uint32_t row) {
       while (bandsReady < nBands && row >= bandsReady * bandRows)
       {
+        const clk::time_point q0 = clk::now();
         if (hipEventSynchronize(c->bandEvents[2 * bandsReady + 1]) != hipSuccess) bandError = true;
+        bandWaitMs += ms(q0, clk::now());
         bandsReady++;
       }
     };
@@ -931,7 +953,7 @@ extern "C"
       pipe.cv.notify_one();
     };
     bool mergeFailed = false;
-    try { blocked_merge(hRec, hBits, blocksX, blocksY, channels, c->lastRegions, &progress, &needSeedRow); }
+    try { blocked_merge(hRec, hBits, blocksX, blocksY, channels, c->lastRegions, &progress, &needSeedRow, hFlags); }
     catch (...) { mergeFailed = true; } // out of host memory: the worker must still be released and joined
     needSeedRow(blocksY - 1); // every band's copy is complete before the staging buffers can be reused
     const clk::time_point t2 = clk::now();
@@ -940,6 +962,7 @@ extern "C"
     worker.join();
     const clk::time_point t5 = clk::now();
     c->blockedMs[0] = ms(t0, t1); c->blockedMs[1] = ms(t1, t2); c->blockedMs[2] = busy[0]; c->blockedMs[3] = busy[1]; c->blockedMs[4] = busy[2]; c->blockedMs[5] = ms(t0, t5);
+    if (getenv("LIMG_HIP_DEBUG_TIMING")) fprintf(stderr, "merge waited %.2f ms for similarity-bit bands; ", bandWaitMs);
     if (getenv("LIMG_HIP_DEBUG_TIMING")) fprintf(stderr, "worker: %d batches, enqueue %.2f ms, event wait %.2f ms, chain %.2f ms, store enqueue %.2f ms\n", dbgBatches, dbgEnqueue, dbgWait, busy[1], busy[2]);
     if (mergeFailed) return limg_hip_error_MemoryAllocationFailure;
     if (bandError) return limg_hip_error_Generic;

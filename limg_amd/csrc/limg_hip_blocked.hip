@@ -314,6 +314,14 @@ namespace limg_hip
       }
       wave_lds_fence();
       if (lane < kMatchWords) p.matchBits[(size_t)seed * kMatchWords + lane] = sWords[wave][lane];
+      if (lane == 0)
+      { // necessary conditions the host scan tests before it bothers to grow a rectangle from this seed: the growth order is right, down, right, down
+        // (src/limg.cpp:1307-1335), so a rectangle of >= 3 x 3 blocks needs all eight neighbours of the seed's 3x3 window, and any rectangle at all needs the
+        // right or the lower neighbour
+        auto bit = [&](int dx, int dy) -> uint32_t { const int cell = (dy + kMatchLo) * kMatchSide + dx + kMatchLo; return (uint32_t)(sWords[wave][cell >> 6] >> (cell & 63)) & 1u; };
+        const uint32_t all8 = bit(1, 0) & bit(2, 0) & bit(0, 1) & bit(1, 1) & bit(2, 1) & bit(0, 2) & bit(1, 2) & bit(2, 2);
+        p.matchFlags[seed] = (uint8_t)(all8 | ((bit(1, 0) | bit(0, 1)) << 1));
+      }
     }
 
     // ---- regions ----------------------------------------------------------------------------------------------------------------------

@@ -180,6 +180,7 @@ namespace limg_hip
       std::vector<uint8_t> used;
       const std::function<void(uint32_t)> *needRow = nullptr; // the similarity bits arrive band by band: called before a seed row's bits are first read
       mutable uint32_t rowsSeen = 0;
+      const uint8_t *flags = nullptr; // per seed, from the GPU: bit 0 = a rectangle of >= 3 x 3 is possible at all, bit 1 = any rectangle is (necessary conditions)
 
       // One expansion (src/limg.cpp:1288-1384) from the seed at (ox, oy).  A strip joins when every block of it is unused
       // (src/limg.cpp:1121-1135) and matches the seed (:1271-1286); neither test has side effects, so they are fused per block.
@@ -223,9 +224,13 @@ namespace limg_hip
         for (; oy < by; oy++)
         {
           const uint8_t *urow = &used[(size_t)oy * bx];
+          if (flags && needRow && oy >= rowsSeen) { (*needRow)(oy); rowsSeen = oy + 1; }
+          const uint8_t *frow = flags ? flags + (size_t)oy * bx : nullptr;
+          const uint8_t need = acceptTiny ? 2 : 1;
           for (; ox < bx; ox++)
           {
             if (urow[ox]) continue;
+            if (frow && !(frow[ox] & need)) continue; // cannot become a rectangle of the wanted kind whatever is in use: same outcome as growing and discarding
             uint32_t x = ox, y = oy, rx = 1, ry = 1;
             expand(x, y, rx, ry, false, acceptTiny ? 0u : 3u);
             if (rx == 1 && ry == 1) continue;
@@ -260,10 +265,10 @@ namespace limg_hip
   // src/limg.cpp:1813-1881: large rectangles, then small ones, then the remaining single blocks.  `progress` (optional) is told how many rectangles
   // of `out` are final every few thousand, so that a consumer can work on them while the scan goes on; `out` never reallocates (reserved up front).
   void blocked_merge(const limg_hip_block_record *pass1, const unsigned long long *matchBits, uint32_t blocksX, uint32_t blocksY, int channels, std::vector<HostRegion> &out,
-                     const std::function<void(size_t)> *progress, const std::function<void(uint32_t)> *needSeedRow)
+                     const std::function<void(size_t)> *progress, const std::function<void(uint32_t)> *needSeedRow, const uint8_t *seedFlags)
   {
     Merge m;
-    m.rec = pass1; m.bits = matchBits; m.bx = blocksX; m.by = blocksY; m.ch = channels; m.needRow = needSeedRow;
+    m.rec = pass1; m.bits = matchBits; m.bx = blocksX; m.by = blocksY; m.ch = channels; m.needRow = needSeedRow; m.flags = matchBits ? seedFlags : nullptr;
     m.used.assign((size_t)blocksX * blocksY, 0);
     out.clear();
     out.reserve((size_t)blocksX * blocksY);

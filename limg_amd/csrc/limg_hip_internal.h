@@ -105,6 +105,7 @@ namespace limg_hip
     const limg_hip_block_record *pass1;
     unsigned long long *matchBits; // [blocks][kMatchWords]
     uint32_t seedBase, seedCount;  // k_blocked_match: the seeds of this launch (a band of block rows)
+    uint8_t *matchFlags;           // per seed: bit 0 = its 3x3 neighbourhood (right / down) matches entirely, bit 1 = its right or its lower neighbour matches
     const RegionDesc *regions; // of this launch (a batch of consecutive rectangles)
     uint32_t nRegions;
     uint32_t regionBase;       // index of regions[0] in creation order (block index = regionBase + r + 1)
@@ -125,7 +126,7 @@ namespace limg_hip
   // host side of the merged-block encoder (limg_hip_blocked_host.cpp): the greedy raster merge and the dither chain walk
   struct HostRegion { uint32_t ox, oy, rx, ry, keep; };
   void blocked_merge(const limg_hip_block_record *pass1, const unsigned long long *matchBits, uint32_t blocksX, uint32_t blocksY, int channels, std::vector<HostRegion> &out,
-                     const std::function<void(size_t)> *progress = nullptr, const std::function<void(uint32_t)> *needSeedRow = nullptr);
+                     const std::function<void(size_t)> *progress = nullptr, const std::function<void(uint32_t)> *needSeedRow = nullptr, const uint8_t *seedFlags = nullptr);
   bool blocked_matches_host(int channels, const limg_hip_block_record &seed, const limg_hip_block_record &cand);
   uint64_t chain_call_n(uint64_t h, size_t n, uint8_t *noise, bool pcg);
 
