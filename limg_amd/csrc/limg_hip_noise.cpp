@@ -13,6 +13,8 @@
 #include <string.h>
 #include <stddef.h>
 
+#include <mutex>
+
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
@@ -40,9 +42,8 @@ namespace limg_hip
 
     inline uint8_t xtime(uint8_t x) { return (uint8_t)((x << 1) ^ ((x >> 7) * 0x1B)); }
 
-    void build_tables()
+    void build_tables_once()
     {
-      if (g_td_ready) return;
       for (int x = 0; x < 256; x++)
       {
         const uint8_t s = kInvSbox[x];
@@ -55,6 +56,12 @@ namespace limg_hip
         g_td[3][x] = (uint32_t)m9 | ((uint32_t)m13 << 8) | ((uint32_t)m11 << 16) | ((uint32_t)m14 << 24);
       }
       g_td_ready = true;
+    }
+
+    void build_tables()
+    { // contexts on different threads may get here together
+      static std::once_flag once;
+      std::call_once(once, build_tables_once);
     }
 
     // AESDEC: InvShiftRows, InvSubBytes, InvMixColumns, xor round key.  State = 4 little-endian column words.

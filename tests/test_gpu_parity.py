@@ -294,3 +294,36 @@ def test_compact_mode(gpu, oracle):
     gsh = sh.cpu().numpy().astype(np.uint32).reshape(8, 64)
     for i in range(3):
         assert np.array_equal((gsh >> (8 * i)) & 0xFF, want["shifts"][:, :, i])
+
+
+def test_two_contexts_on_two_threads(oracle):
+    """Contexts are independent: two host threads, each with its own context, encode different images at the same time (8x8 path and merged-block encoder)."""
+    import threading
+    import limg_amd
+    from oracle.bind import BLOCKED_WRITTEN
+    imgs = [oracle.photo_noise(512, 256, 21), oracle.random_gradient(384, 264, 22, False)]
+    want = [oracle.encode3d(i, True) for i in imgs]
+    wantb = [oracle.blocked_encode3d(i, True) for i in imgs]
+    errs = []
+
+    def work(k):
+        try:
+            g = limg_amd.LimgHip(0)
+            for _ in range(5):
+                got = g.encode3d(imgs[k], True)
+                bad = [p for p in PLANES if not np.array_equal(got[p], want[k][p])]
+                gotb = g.blocked_encode3d(imgs[k], True)
+                bad += [p for p in BLOCKED_WRITTEN if not np.array_equal(gotb[p], wantb[k][p])]
+                if bad:
+                    errs.append((k, bad))
+            g.check()
+            g.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((k, repr(e)))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
