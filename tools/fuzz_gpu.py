@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-blocks", type=int, default=40, help="largest image width in 8-pixel blocks (height: 60 %% of it)")
     args = ap.parse_args()
     import limg_amd
     from oracle.bind import Oracle, PLANES, BLOCKED_WRITTEN
@@ -28,8 +29,8 @@ def main():
     n = {"fixed": 0, "stream": 0, "blocked": 0}
     last = t0
     while time.time() - t0 < args.seconds:
-        w = int(rng.integers(1, 40)) * 8 + (int(rng.integers(0, 8)) if rng.random() < 0.4 else 0)
-        h = int(rng.integers(1, 24)) * 8 + (int(rng.integers(0, 8)) if rng.random() < 0.4 else 0)
+        w = int(rng.integers(1, args.max_blocks)) * 8 + (int(rng.integers(0, 8)) if rng.random() < 0.4 else 0)
+        h = int(rng.integers(1, max(2, args.max_blocks * 6 // 10))) * 8 + (int(rng.integers(0, 8)) if rng.random() < 0.4 else 0)
         gen = ["pn", "rg", "rga", "rand", "flat"][int(rng.integers(0, 5))]
         seed = int(rng.integers(1, 1 << 30))
         alpha = bool(rng.random() < 0.7)
