@@ -670,30 +670,43 @@ namespace limg_hip
       serial_sums2<CH, kDirA>(V, blkh, lane);
 
       // ---- phase B: factor A extrema, residual -> second direction (pass 2) --------------------------------------------
-#pragma unroll
-      for (int i = 0; i < kBatch; i++)
       {
-        const int b = h * kBatch + i;
-        uint32_t rx, n;
-        if (!geom(b, rx, n)) continue;
-        if ((uint32_t)sgpr((int)blk[b].flags) & kZeroA) continue;
-        const V4 dirA = ld4(blk[b].dirA), avg = ld4(blk[b].avg);
-        const float invA = blk[b].invA;
-        const V4 pf = px_to_v4(px8[i]);
-        const bool active = (uint32_t)lane < n;
-        const float fA = dp4<CH>(pf - avg, dirA) * invA;
-        float mn = active ? fA : 0.0f, mx = mn; // min / max start at 0 upstream (src/limg_factorization.h:633-634)
-        wave_min_max(mn, mx);
-        mn = vmin(mn, 0.0f); mx = vmax(mx, 0.0f);
-        est8[i] = avg + dirA * fA;
-        V4 e = pf - est8[i];
-        mask_alpha<CH>(e);
-        st4(V + i * kVDw + lane * 4, unit4<CH>(s_rsq, e, active));
-        if (lane == 0) { blk[b].mm[0] = mn; blk[b].mm[1] = mx; }
+        static_assert(kBatch == 4, "wave_reduce4");
+        float mnv[kBatch], mxv[kBatch];
+        bool did[kBatch];
+#pragma unroll
+        for (int i = 0; i < kBatch; i++)
+        {
+          const int b = h * kBatch + i;
+          uint32_t rx, n;
+          did[i] = false; mnv[i] = 0.0f; mxv[i] = 0.0f;
+          if (!geom(b, rx, n)) continue;
+          if ((uint32_t)sgpr((int)blk[b].flags) & kZeroA) continue;
+          did[i] = true;
+          const V4 dirA = ld4(blk[b].dirA), avg = ld4(blk[b].avg);
+          const float invA = blk[b].invA;
+          const V4 pf = px_to_v4(px8[i]);
+          const bool active = (uint32_t)lane < n;
+          const float fA = dp4<CH>(pf - avg, dirA) * invA;
+          mnv[i] = active ? fA : 0.0f; mxv[i] = mnv[i]; // min / max start at 0 upstream (src/limg_factorization.h:633-634)
+          est8[i] = avg + dirA * fA;
+          V4 e = pf - est8[i];
+          mask_alpha<CH>(e);
+          st4(V + i * kVDw + lane * 4, unit4<CH>(s_rsq, e, active));
+        }
+        wave_reduce4<false>(mnv);
+        wave_reduce4<true>(mxv);
+#pragma unroll
+        for (int i = 0; i < kBatch; i++)
+          if (did[i] && lane == 0) { blk[h * kBatch + i].mm[0] = vmin(mnv[i], 0.0f); blk[h * kBatch + i].mm[1] = vmax(mxv[i], 0.0f); }
       }
       serial_sums2<CH, kDirB>(V, blkh, lane);
 
       // ---- phase C: factor B (and, 3 ch, C) extrema; 4 ch: residual -> third direction (pass 3) ---------------------
+      float mnCv[kBatch], mxCv[kBatch];
+      bool didC[kBatch];
+#pragma unroll
+      for (int i = 0; i < kBatch; i++) { didC[i] = false; mnCv[i] = FLT_MAX; mxCv[i] = -FLT_MAX; }
 #pragma unroll
       for (int i = 0; i < kBatch; i++)
       {
@@ -709,14 +722,10 @@ namespace limg_hip
         float mnB = active ? fB : FLT_MAX, mxB = active ? fB : -FLT_MAX;
         if (CH == 4)
         {
-          wave_min_max(mnB, mxB);
+          didC[i] = true; mnCv[i] = mnB; mxCv[i] = mxB; // reduced for the whole batch after the loop
           est8[i] = est8[i] + dirB * fB;
           st4(V + i * kVDw + lane * 4, unit4<CH>(s_rsq, pf - est8[i], active));
-          if (lane == 0)
-          {
-            blk[b].mm[2] = mnB; blk[b].mm[3] = mxB;
-            st4(blk[b].est0, est8[i]);
-          }
+          if (lane == 0) st4(blk[b].est0, est8[i]);
         }
         else
         {
@@ -750,26 +759,38 @@ namespace limg_hip
       }
       if (CH == 4)
       {
+        wave_reduce4<false>(mnCv);
+        wave_reduce4<true>(mxCv);
+#pragma unroll
+        for (int i = 0; i < kBatch; i++)
+          if (didC[i] && lane == 0) { blk[h * kBatch + i].mm[2] = mnCv[i]; blk[h * kBatch + i].mm[3] = mxCv[i]; }
         // blocks that skipped phase C left stale pass-2 contributions in V; their dirC is never used (flags)
         serial_sums2<CH, kDirC>(V, blkh, lane);
         // ---- phase D: factor C extrema (pass 4).  Upstream never advances its estimate pointer in this loop
         //      (src/limg_factorization.h:748-758), so every pixel is measured against pixel 0's A+B estimate.
+        float mnDv[kBatch], mxDv[kBatch];
+        bool didD[kBatch];
 #pragma unroll
         for (int i = 0; i < kBatch; i++)
         {
           const int b = h * kBatch + i;
           uint32_t rx, n;
+          didD[i] = false; mnDv[i] = FLT_MAX; mxDv[i] = -FLT_MAX;
           if (!geom(b, rx, n)) continue;
           if ((uint32_t)sgpr((int)blk[b].flags) & kZeroC) continue;
+          didD[i] = true;
           const V4 dirC = ld4(blk[b].dirC), est0 = ld4(blk[b].est0);
           const float invC = blk[b].invC;
           const V4 pf = px_to_v4(px8[i]);
           const bool active = (uint32_t)lane < n;
           const float fC = dp4<CH>(pf - est0, dirC) * invC;
-          float mnC = active ? fC : FLT_MAX, mxC = active ? fC : -FLT_MAX;
-          wave_min_max(mnC, mxC);
-          if (lane == 0) { blk[b].mm[4] = mnC; blk[b].mm[5] = mxC; }
+          mnDv[i] = active ? fC : FLT_MAX; mxDv[i] = active ? fC : -FLT_MAX;
         }
+        wave_reduce4<false>(mnDv);
+        wave_reduce4<true>(mxDv);
+#pragma unroll
+        for (int i = 0; i < kBatch; i++)
+          if (didD[i] && lane == 0) { blk[h * kBatch + i].mm[4] = mnDv[i]; blk[h * kBatch + i].mm[5] = mxDv[i]; }
       }
       } // batches
       wave_lds_fence();
