@@ -278,46 +278,46 @@ namespace limg_hip
       mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mx), 63));
     }
 
-    // Exact min (MAX = false) or max of FOUR independent values over the wave at once, results wave-uniform.  gfx950's lane-swap instructions fold the
-    // values into one register on the way down: v_permlane32_swap puts the two halves of a pair side by side (one op then reduces both values from 64 to 32
-    // lanes), v_permlane16_swap does the same for the two pairs (32 -> 16 lanes), and four DPP steps finish all four 16-lane rows together: 10 VALU
-    // instructions instead of 24.
-    template <bool MAX>
-    __device__ __forceinline__ void wave_reduce4(float v[4])
+    __device__ __forceinline__ float vmin_(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+    __device__ __forceinline__ float vmax_(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+    // Exact min and max of FOUR independent value pairs over the wave at once, results wave-uniform.  gfx950's lane-swap instructions fold the values into
+    // one register on the way down: v_permlane32_swap puts the two halves of a pair of values side by side (one op then reduces both from 64 to 32 lanes),
+    // v_permlane16_swap does the same for the two pairs (32 -> 16 lanes), and four DPP steps finish all four 16-lane rows together: 10 VALU instructions
+    // per four values instead of 24.  The min and the max chain are interleaved so that each DPP step needs only one wait state.
+    __device__ __forceinline__ void wave_reduce4_min_max(float mn[4], float mx[4])
     {
-      auto op = [](float a, float b) { float r; if (MAX) asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); else asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
-      auto s01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[1]), false, false);
-      auto s23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2]), __float_as_uint(v[3]), false, false);
-      const float m01 = op(__uint_as_float(s01[0]), __uint_as_float(s01[1])); // lanes 0..31: v0 (64 -> 32), lanes 32..63: v1
-      const float m23 = op(__uint_as_float(s23[0]), __uint_as_float(s23[1]));
-      auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(m01), __float_as_uint(m23), false, false);
-      float m = op(__uint_as_float(s[0]), __uint_as_float(s[1])); // rows of 16 lanes: v0, v2, v1, v3
-      if (MAX)
-        asm volatile("s_nop 1\n\t"
-                     "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                     "s_nop 1\n\t"
-                     "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                     "s_nop 1\n\t"
-                     "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                     "s_nop 1\n\t"
-                     "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-                     "s_nop 1"
-                     : "+v"(m));
-      else
-        asm volatile("s_nop 1\n\t"
-                     "v_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                     "s_nop 1\n\t"
-                     "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                     "s_nop 1\n\t"
-                     "v_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                     "s_nop 1\n\t"
-                     "v_min_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-                     "s_nop 1"
-                     : "+v"(m));
-      v[0] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 0));
-      v[2] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 16));
-      v[1] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 32));
-      v[3] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 48));
+      auto swap32 = [](float a, float b, float &x, float &y) { auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false); x = __uint_as_float(r[0]); y = __uint_as_float(r[1]); };
+      auto swap16 = [](float a, float b, float &x, float &y) { auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false); x = __uint_as_float(r[0]); y = __uint_as_float(r[1]); };
+      float x, y;
+      swap32(mn[0], mn[1], x, y); const float n01 = vmin_(x, y); // lanes 0..31: value 0 (64 -> 32 lanes), lanes 32..63: value 1
+      swap32(mx[0], mx[1], x, y); const float x01 = vmax_(x, y);
+      swap32(mn[2], mn[3], x, y); const float n23 = vmin_(x, y);
+      swap32(mx[2], mx[3], x, y); const float x23 = vmax_(x, y);
+      swap16(n01, n23, x, y); float n = vmin_(x, y); // rows of 16 lanes: values 0, 2, 1, 3
+      swap16(x01, x23, x, y); float m = vmax_(x, y);
+      asm volatile(
+          "s_nop 1\n\t"
+          "v_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+          "v_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 0\n\t"
+          "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+          "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 0\n\t"
+          "v_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+          "v_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 0\n\t"
+          "v_min_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+          "v_max_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 1"
+          : "+v"(n), "+v"(m));
+      const int rows[4] = { 0, 32, 16, 48 }; // value i sits in the row starting at lane rows[i]
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+      {
+        mn[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(n), rows[i]));
+        mx[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), rows[i]));
+      }
     }
 
     __device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }

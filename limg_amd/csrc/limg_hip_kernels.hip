@@ -671,7 +671,7 @@ namespace limg_hip
 
       // ---- phase B: factor A extrema, residual -> second direction (pass 2) --------------------------------------------
       {
-        static_assert(kBatch == 4, "wave_reduce4");
+        static_assert(kBatch == 4, "wave_reduce4_min_max");
         float mnv[kBatch], mxv[kBatch];
         bool did[kBatch];
 #pragma unroll
@@ -694,8 +694,7 @@ namespace limg_hip
           mask_alpha<CH>(e);
           st4(V + i * kVDw + lane * 4, unit4<CH>(s_rsq, e, active));
         }
-        wave_reduce4<false>(mnv);
-        wave_reduce4<true>(mxv);
+        wave_reduce4_min_max(mnv, mxv);
 #pragma unroll
         for (int i = 0; i < kBatch; i++)
           if (did[i] && lane == 0) { blk[h * kBatch + i].mm[0] = vmin(mnv[i], 0.0f); blk[h * kBatch + i].mm[1] = vmax(mxv[i], 0.0f); }
@@ -759,8 +758,7 @@ namespace limg_hip
       }
       if (CH == 4)
       {
-        wave_reduce4<false>(mnCv);
-        wave_reduce4<true>(mxCv);
+        wave_reduce4_min_max(mnCv, mxCv);
 #pragma unroll
         for (int i = 0; i < kBatch; i++)
           if (didC[i] && lane == 0) { blk[h * kBatch + i].mm[2] = mnCv[i]; blk[h * kBatch + i].mm[3] = mxCv[i]; }
@@ -786,8 +784,7 @@ namespace limg_hip
           const float fC = dp4<CH>(pf - est0, dirC) * invC;
           mnDv[i] = active ? fC : FLT_MAX; mxDv[i] = active ? fC : -FLT_MAX;
         }
-        wave_reduce4<false>(mnDv);
-        wave_reduce4<true>(mxDv);
+        wave_reduce4_min_max(mnDv, mxDv);
 #pragma unroll
         for (int i = 0; i < kBatch; i++)
           if (didD[i] && lane == 0) { blk[h * kBatch + i].mm[4] = mnDv[i]; blk[h * kBatch + i].mm[5] = mxDv[i]; }
