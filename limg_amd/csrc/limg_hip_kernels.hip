@@ -535,7 +535,7 @@ namespace limg_hip
 
     // LDS of an E task (fit + search of one work strip); the F task's areas overlay `V`.
     constexpr int kLdsStrip = 0, kLdsV = kLdsStrip + 8 * kRowDw * 4, kLdsVBytes = kWaves * kBatch * kVDw * 4;
-    constexpr int kLdsBlk = kLdsV + kLdsVBytes, kLdsCalls = kLdsBlk + kStripBlocks * 192, kLdsTotal = kLdsCalls + 16;
+    constexpr int kLdsBlk = kLdsV + kLdsVBytes, kLdsCalls = kLdsBlk + kStripBlocks * 192, kLdsTotal = kLdsCalls + 32; // 4 per-wave call counts + the phase-E block queue
     static_assert(kLdsTotal <= 32768 - 16, "5 workgroups per CU");
 
 
@@ -865,6 +865,8 @@ namespace limg_hip
           }
         }
       }
+      uint32_t *s_queue = s_calls + 4;
+      if (tid == 0) *s_queue = 0;
       __syncthreads(); // all waves are done with V: wave 0's V region becomes the factor-byte staging area
 
       uint8_t *stage = reinterpret_cast<uint8_t *>(s_V); // [3 planes][8 rows][256 px]
@@ -872,20 +874,28 @@ namespace limg_hip
       if (PERSIST && lane < kBlocksPerWave) reinterpret_cast<uint32_t *>(park + kParkShift)[wave * kBlocksPerWave + lane] = 0u; // blocks past the right edge
 
       // ---- phase E: per-pixel factors (a8) + shift search (a10-a12) ----------------------------------------------------
+      // The strip's 32 blocks are handed out dynamically: the number of trials differs from block to block (2 .. 20), and with a fixed 8 blocks per wave
+      // the fastest wave would idle at the next barrier.  Everything phase E touches of a block lives in LDS and is indexed by the block, not the wave.
+      auto grab = [&]() -> uint32_t { uint32_t v = 0; if (lane == 0) v = atomicAdd(s_queue, 1u); return (uint32_t)sgpr((int)v); };
+      uint32_t sbNext = grab();
 #pragma unroll 1
-      for (int b = 0; b < kBlocksPerWave; b++)
+      for (;;)
       {
-        uint32_t rx, n;
-        if (!geom(b, rx, n)) continue;
-        const uint32_t sb = wave * kBlocksPerWave + b;
+        const uint32_t sb = sbNext;
+        if (sb >= (uint32_t)kStripBlocks) break;
+        uint32_t qv = 0;
+        if (lane == 0) qv = atomicAdd(s_queue, 1u); // the next block's index arrives while this one is searched
         const uint32_t bx = strip * kStripBlocks + sb;
+        if (bx >= p.blocksX) { sbNext = (uint32_t)sgpr((int)qv); continue; }
+        const uint32_t rx = min(p.sizeX - bx * kBlock, (uint32_t)kBlock), n = rx * ry;
+        BlkF *const blkE = s_blk + sb;
         uint32_t lx, ly;
         if (rx == 8) { lx = lane & 7; ly = lane >> 3; }
         else { const uint32_t l = (uint32_t)lane < n ? (uint32_t)lane : 0u; ly = l / rx; lx = l - ly * rx; }
         uint32_t px = s_strip[ly * kRowDw + sb * kBlock + lx];
         const bool active = (uint32_t)lane < n;
         px = active ? px : 0u;
-        const BlkE *be = reinterpret_cast<const BlkE *>(&blk[b]);
+        const BlkE *be = reinterpret_cast<const BlkE *>(blkE);
 
         uint32_t fA, fB, fC;
         { // a8 (src/limg_factorization.h:149-197): fa = ((px - Amin) . nA) * invA, est = Amin + nA * fa, fb from px - est - Boff, ...
@@ -914,7 +924,7 @@ namespace limg_hip
           // be * 16 < maxBlock * n  <=>  be < ceil(maxBlock * n / 16); clamped to 32 bits (be itself never gets near 2^32)
           const uint64_t lim64 = (maxBlockN + 15ull) >> 4;
           const uint32_t blockLimit = (uint32_t)sgpr((int)(lim64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)lim64));
-          const bool big = ((uint32_t)sgpr((int)blk[b].flags) & kBig) != 0;
+          const bool big = ((uint32_t)sgpr((int)blkE->flags) & kBig) != 0;
           if (!big)
           {
             TrialState t;
@@ -929,7 +939,7 @@ namespace limg_hip
             for (int c = 0; c < 3; c++)
             { // uniform values, kept in VGPRs: they are operands of v_mad_i32_i24
               const int bias = c == 0 ? (kTermBias << 8) : 0;
-              const int loA = blk[b].rec[c], hiA = blk[b].rec[4 + c], loB = blk[b].rec[8 + c], hiB = blk[b].rec[12 + c], loC = blk[b].rec[16 + c], hiC = blk[b].rec[20 + c];
+              const int loA = blkE->rec[c], hiA = blkE->rec[4 + c], loB = blkE->rec[8 + c], hiB = blkE->rec[12 + c], loC = blkE->rec[16 + c], hiC = blkE->rec[20 + c];
               t.nA[c] = hiA - loA; t.nB[c] = hiB - loB; t.nC[c] = hiC - loC;
               t.mA[c] = (loA << 8) + 128 + bias; t.mB[c] = (loB << 8) + 128 + bias; t.mC[c] = (loC << 8) + 128 + bias;
             }
@@ -958,7 +968,7 @@ namespace limg_hip
           {
             // out-of-range record (never produced by a fit of byte pixels; kept so that no input can break exactness):
             // generic 32-bit trial, deliberately a real call so that none of it is speculated into the common path
-            const uint32_t packed = search_generic(px, fA, fB, fC, blk[b].rec, active, p.maxPixel32, maxBlockN, p.fast != 0);
+            const uint32_t packed = search_generic(px, fA, fB, fC, blkE->rec, active, p.maxPixel32, maxBlockN, p.fast != 0);
             shift[0] = packed & 0xFF; shift[1] = (packed >> 8) & 0xFF; shift[2] = (packed >> 16) & 0xFF;
           }
         }
@@ -979,6 +989,7 @@ namespace limg_hip
           const uint32_t o = ly * 256 + sb * kBlock + lx;
           stage[o] = (uint8_t)fA; stage[2048 + o] = (uint8_t)fB; stage[4096 + o] = (uint8_t)fC;
         }
+        sbNext = (uint32_t)sgpr((int)qv);
       }
       if (lane == 0) s_calls[wave] = waveCalls;
       __syncthreads();
