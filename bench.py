@@ -28,10 +28,10 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES_PER_PX = 39          # 4 B read + 35 B written (plane-compatible mode)
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # HBM bytes per launch of k_encode_persistent on the default workload (8192x8192 RGBA photo-noise, errorFactor 100), from separate
-# rocprofv3 --pmc passes (profiles/r01_final_persistent_pmc4.csv / pmc5.csv): FETCH_SIZE 372,700 KiB, WRITE_SIZE 2,549,000 KiB.
+# rocprofv3 --pmc passes (profiles/r01_final_persistent_pmc4.csv / pmc5.csv): FETCH_SIZE 356,100 KiB, WRITE_SIZE 2,548,000 KiB.
 # gfx950 correction of the microarch guide: FETCH_SIZE counts half the bytes (calibrated here on k_compare: 537 MB read -> 268 MB
 # reported; WRITE_SIZE exact on k_synth_photo_noise and k_dither_store) => 2 * FETCH + WRITE.
-PMC_TRAFFIC_BYTES_DEFAULT = int((2 * 372700 + 2549000) * 1024)
+PMC_TRAFFIC_BYTES_DEFAULT = int((2 * 356100 + 2548000) * 1024)
 
 
 def cpu_baseline(width, seed, budget_s=25.0):
@@ -464,7 +464,7 @@ def main():
                                         if args.split else {"k_encode_persistent": round(float(kavg[0]), 4)}),
                          "note": ("whole encode = 3 launches; achieved = 39 B/px * pixels / sum of the three average kernel durations (HIP events)" if args.split else
                                   "whole encode = one persistent launch; achieved = 39 B/px * pixels / its average duration (HIP events on the launch stream). "
-                                  "The kernel is VALU-issue-bound, not HBM-bound: ~1069 VALU instructions per 64-px block at one wave64 VALU instruction per 4 cycles "
+                                  "The kernel is VALU-issue-bound, not HBM-bound: ~1060 VALU instructions per 64-px block at one wave64 VALU instruction per 4 cycles "
                                   "per SIMD, SQ_ACTIVE_INST_VALU ~86 % of the kernel (profiles/r01_final_persistent_summary.txt)")},
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
