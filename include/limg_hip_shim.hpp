@@ -1,5 +1,6 @@
 // limg_hip_shim.hpp -- header-only C++ shim that re-exposes the reference's own signatures (src/limg.h:27-48, incl. limg_blocked_encode3d_test) on top of
-// the C ABI of liblimg_hip.so, so a caller written against limg.h (e.g. src/main.cpp:282-332) relinks unchanged:
+// the C ABI of liblimg_hip.so, so a caller written against limg.h relinks unchanged -- the reference's own src/main.cpp compiles against it as it is
+// (tests/test_shim_ref_main.py does exactly that):
 //
 //     #include "limg_hip_shim.hpp"      // instead of "limg.h"
 //     limg_encode3d_test(pIn, sizeX, sizeY, hasAlpha, &info, errorFactor, pThreadPool, fastBitCrushing);
@@ -11,6 +12,10 @@
 
 #include <stddef.h>
 #include <stdint.h>
+
+#include <functional>
+#include <thread>
+#include <vector>
 
 #include "limg_hip.h"
 
@@ -24,10 +29,30 @@ enum limg_result
   limg_error_MemoryAllocationFailure,
 };
 
-struct limg_thread_pool { size_t threads; };
-inline limg_thread_pool *limg_thread_pool_new(const size_t threads) { return new limg_thread_pool{ threads }; }
+// The whole of src/limg_threading.h:9-17.  On the GPU a pool is only the name of a dither-chain partition, so it owns no threads: tasks given to
+// `limg_thread_pool_add` are kept and run by the caller in `limg_thread_pool_await` (upstream's await also drains the queue on the calling thread,
+// src/limg_threading.cpp:129-161).
+struct limg_thread_pool { size_t threads; std::vector<std::function<void(void)>> tasks; };
+inline limg_thread_pool *limg_thread_pool_new(const size_t threads) { return new limg_thread_pool{ threads, {} }; }
 inline void limg_thread_pool_destroy(limg_thread_pool **pp) { if (pp && *pp) { delete *pp; *pp = nullptr; } }
-inline size_t limg_thread_pool_thread_count(limg_thread_pool *p) { return p ? p->threads : 0; }
+inline size_t limg_thread_pool_thread_count(limg_thread_pool *p) { return (p == nullptr || p->threads == 0) ? 1 : p->threads; } // src/limg_threading.cpp:110-116
+inline void limg_thread_pool_add(limg_thread_pool *p, const std::function<void(void)> &func) { p->tasks.push_back(func); }
+inline void limg_thread_pool_await(limg_thread_pool *p)
+{
+  while (!p->tasks.empty())
+  {
+    std::vector<std::function<void(void)>> run;
+    run.swap(p->tasks); // a task may add tasks
+    for (auto &f : run) f();
+  }
+}
+inline size_t limg_threading_max_threads() { return std::thread::hardware_concurrency(); } // src/limg_threading.cpp:163-166
+
+namespace limg_hip_shim
+{
+  // pool -> the C ABI's `poolThreads` (0 = no pool = one dither chain; a pool of T threads = 4 T row strips, src/limg.cpp:2114-2134)
+  inline int pool_threads(limg_thread_pool *p) { return p ? (int)limg_thread_pool_thread_count(p) : 0; }
+}
 
 struct limg_encode3d_info
 {
@@ -59,7 +84,7 @@ inline limg_result limg_encode3d_test(const uint32_t *pIn, const size_t sizeX, c
   limg_hip_context *c = limg_hip_shim::context();
   if (!c) return limg_error_Generic;
   return (limg_result)limg_hip_encode3d(c, pIn, sizeX, sizeY, hasAlpha ? 1 : 0, reinterpret_cast<limg_hip_encode3d_info *>(pInfo), errorFactor,
-                                        pThreadPool ? (int)pThreadPool->threads : 0, fastBitCrushing ? 1 : 0);
+                                        limg_hip_shim::pool_threads(pThreadPool), fastBitCrushing ? 1 : 0);
 }
 
 inline limg_result limg_encode3d_test_perf(const uint32_t *pIn, const size_t sizeX, const size_t sizeY, const bool hasAlpha, const uint32_t errorFactor, limg_thread_pool *pThreadPool,
@@ -67,7 +92,7 @@ inline limg_result limg_encode3d_test_perf(const uint32_t *pIn, const size_t siz
 {
   limg_hip_context *c = limg_hip_shim::context();
   if (!c) return limg_error_Generic;
-  return (limg_result)limg_hip_encode3d_perf(c, pIn, sizeX, sizeY, hasAlpha ? 1 : 0, errorFactor, pThreadPool ? (int)pThreadPool->threads : 0, fastBitCrushing ? 1 : 0);
+  return (limg_result)limg_hip_encode3d_perf(c, pIn, sizeX, sizeY, hasAlpha ? 1 : 0, errorFactor, limg_hip_shim::pool_threads(pThreadPool), fastBitCrushing ? 1 : 0);
 }
 
 // src/limg.h:46.  The pool only splits upstream's first pass and cannot change the result; it is accepted and ignored.
@@ -97,7 +122,7 @@ inline limg_result limg_encode(const uint32_t *pIn, const size_t sizeX, const si
 {
   limg_hip_context *c = limg_hip_shim::context();
   if (!c) return limg_error_Generic;
-  return (limg_result)limg_hip_encode_stream(c, pIn, sizeX, sizeY, hasAlpha ? 1 : 0, pOut, outCapacity, pOutSize, errorFactor, pThreadPool ? (int)pThreadPool->threads : 0,
+  return (limg_result)limg_hip_encode_stream(c, pIn, sizeX, sizeY, hasAlpha ? 1 : 0, pOut, outCapacity, pOutSize, errorFactor, limg_hip_shim::pool_threads(pThreadPool),
                                              fastBitCrushing ? 1 : 0);
 }
 
