@@ -64,7 +64,11 @@ typedef struct limg_hip_options
   int32_t dither_pcg;          /* non-0: the reference's PCG dither (src/limg.cpp:799-822, what it runs on hosts without AES-NI) instead of the AES one */
   int32_t test_record_limit;   /* test hook, 0 = default: blocks with a record value of magnitude >= this take the generic 32-bit trial
                                   (default 8001: a fit of byte pixels never gets there); 1 sends every block through it */
-  int32_t reserved[2];
+  int32_t float_mode;          /* 0 (default) = EXACT: the float stage op for op as the reference's strict SSE build (DPPS order, x86 RSQRTPS table, correctly
+                                  rounded divisions): every plane bit-identical to the reference.  1 = FAST: hardware v_rsq_f32 / v_rcp_f32 and fused multiply-adds;
+                                  contract: the integer stage stays bit-exact given the same records, extrema within +-2 LSB on >= 99.9 % of blocks, perceptual PSNR
+                                  within 0.10 dB of EXACT; the 8x8 path only (the merged-block encoder always runs EXACT) */
+  int32_t reserved[1];
 } limg_hip_options;
 
 typedef struct limg_hip_context limg_hip_context;
@@ -90,7 +94,10 @@ limg_hip_result limg_hip_encode3d_perf(limg_hip_context *pCtx, const uint32_t *p
  * is a DEVICE pointer; pInfo / pCompact themselves are host structs.  Asynchronous on `stream` (a hipStream_t passed
  * as void*; NULL = default stream).  pInfo == NULL gives the `_perf` behaviour (fit + search only).
  * Compact mode (SURVEY.md 8(d), 8.05 B/px): pInfo with the eight uint32 plane pointers all NULL and the three factor planes set
- * writes only the crushed factor bytes; together with pCompact (records + shift words) that is everything a decoder needs. */
+ * writes only the crushed factor bytes; together with pCompact (records + shift words) that is everything a decoder needs.
+ * Alignment: any (4-byte aligned pIn / uint32 planes) is accepted.  The kernels use 16-byte accesses on pIn when it is 16-byte aligned and
+ * sizeX % 4 == 0, and on the factor planes when all three are 16-byte aligned and sizeX % 16 == 0; other pointers (sliced, offset) take
+ * dword / byte paths with identical results (hipMalloc and torch allocations are 256-byte aligned). */
 limg_hip_result limg_hip_encode3d_device(limg_hip_context *pCtx, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha,
                                          const limg_hip_encode3d_info *pInfo, const limg_hip_compact_out *pCompact, uint32_t errorFactor, int poolThreads,
                                          int fastBitCrushing, void *stream);

@@ -56,7 +56,7 @@ class CompactOut(C.Structure):
 
 
 class Options(C.Structure):
-    _fields_ = [("forced_shift", C.c_int32 * 3), ("force_split_kernels", C.c_int32), ("dither_pcg", C.c_int32), ("test_record_limit", C.c_int32), ("reserved", C.c_int32 * 2)]
+    _fields_ = [("forced_shift", C.c_int32 * 3), ("force_split_kernels", C.c_int32), ("dither_pcg", C.c_int32), ("test_record_limit", C.c_int32), ("float_mode", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 def load_library(path=None):
@@ -198,7 +198,7 @@ class LimgHip:
         except Exception:
             pass
 
-    def set_options(self, forced_shift=None, force_split=False, dither_pcg=False, test_record_limit=0):
+    def set_options(self, forced_shift=None, force_split=False, dither_pcg=False, test_record_limit=0, float_fast=False):
         o = Options()
         self.lib.limg_hip_default_options(C.byref(o))
         if forced_shift is not None:
@@ -207,6 +207,7 @@ class LimgHip:
         o.force_split_kernels = int(force_split)
         o.dither_pcg = int(dither_pcg)
         o.test_record_limit = int(test_record_limit)
+        o.float_mode = 1 if float_fast else 0
         _check(self.lib.limg_hip_set_options(self.ctx, C.byref(o)), "limg_hip_set_options")
 
     def set_forced_shift(self, shift=None):

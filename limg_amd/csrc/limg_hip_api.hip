@@ -78,7 +78,8 @@ struct limg_hip_context
   uint64_t noiseNext = kDitherSeed;              // chain value after the last generated entry
   DevBuf noiseDyn;                               // data-dependent chains (images with partial blocks)
   DevBuf park;                                   // persistent kernel: 2 x 8 KiB per workgroup
-  DevBuf lookback;                               // fused path: ticket + timeout flag (16 B) then one 8-byte descriptor per work strip
+  DevBuf lookback;                               // fused path: ticket (16 B) then one 8-byte descriptor per work strip
+  DevBuf devStatus;                              // sticky look-back timeout word: never touched by the per-launch memset, cleared by limg_hip_check_device_status
   DevBuf in, planes;                             // staging for the host-pointer entry points
   DevBuf cmp;                                    // 8-byte accumulator of limg_hip_compare
   DevBuf bFlags;
@@ -93,7 +94,7 @@ struct limg_hip_context
   double blockedMs[6] = { 0, 0, 0, 0, 0, 0 };
   DevBuf streamFac, streamTiles, streamStatus, streamBuf; // stream packer: 3 factor planes, per-tile payload words; decode status word; host-entry staging
   // optional per-kernel timing (bench): 4 events per encode, recorded on the caller's stream, read back in one go
-  int persistentWorkgroups = 1024; // 4 per CU (LDS-limited), set from the device's CU count at init
+  int persistentWorkgroups = 1280; // 5 per CU (LDS- and VGPR-limited), set from the device's CU count at init
   bool forceSplit = false; // options: run the three-kernel path even where the fused kernel applies (A/B, tests)
   bool profiling = false;
   std::vector<hipEvent_t> events;
@@ -198,6 +199,7 @@ namespace
     const bool forced = c->opt.forced_shift[0] >= 0 && c->opt.forced_shift[0] <= 8 && c->opt.forced_shift[1] >= 0 && c->opt.forced_shift[1] <= 8 &&
                         c->opt.forced_shift[2] >= 0 && c->opt.forced_shift[2] <= 8;
     for (int i = 0; i < 3; i++) p.forced[i] = forced ? c->opt.forced_shift[i] : -1;
+    p.floatFast = (c->opt.float_mode == 1 && !fitOnly) ? 1 : 0;
     p.recordLimit = c->opt.test_record_limit > 0 ? c->opt.test_record_limit - 1 : 8000;
     const Partition pt = partition(sizeY, poolThreads);
     p.chainCount = pt.chainCount; p.chainRows = pt.chainRows;
@@ -216,6 +218,10 @@ namespace
     p.streamRaw = streamRaw && !fullPlanes;
     p.fitOnly = fitOnly && !dInfo;
     if (dInfo) p.info = *dInfo;
+    // 16-byte vector access straight on caller pointers only where the address is 16-byte aligned for every row: sliced or offset
+    // device pointers take the dword paths
+    p.vecIn = (sizeX % 4 == 0) && (((uintptr_t)dIn) & 15u) == 0;
+    p.vecFactors = dInfo && (sizeX % 16 == 0) && ((((uintptr_t)dInfo->pFactorsA) | ((uintptr_t)dInfo->pFactorsB) | ((uintptr_t)dInfo->pFactorsC)) & 15u) == 0;
     const int channels = hasAlpha ? 4 : 3;
     const bool ragged = (sizeX % kBlock) != 0 || (sizeY % kBlock) != 0;
 
@@ -235,6 +241,12 @@ namespace
       if ((r = c->lookback.ensure(16 + strips * 8)) != limg_hip_success) return r;
       HIP_TRY(hipMemsetAsync(c->lookback.p, 0, 16 + strips * 8, stream));
       p.ticket = (uint32_t *)c->lookback.p;
+      if (!c->devStatus.p)
+      {
+        if ((r = c->devStatus.ensure(16)) != limg_hip_success) return r;
+        HIP_TRY(hipMemsetAsync(c->devStatus.p, 0, 16, stream));
+      }
+      p.timeout = (uint32_t *)c->devStatus.p;
       p.desc = (unsigned long long *)((uint8_t *)c->lookback.p + 16);
       p.compactOut = compact != nullptr;
       if ((r = c->park.ensure((size_t)c->persistentWorkgroups * 2 * 8192)) != limg_hip_success) return r;
@@ -338,7 +350,7 @@ extern "C"
     limg_hip_context *c = *ppCtx;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = { &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->lookback, &c->park, &c->in, &c->planes, &c->cmp,
+    DevBuf *bufs[] = { &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->lookback, &c->devStatus, &c->park, &c->in, &c->planes, &c->cmp,
                        &c->streamFac, &c->streamTiles, &c->streamStatus, &c->streamBuf,
                        &c->bFlags, &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bV, &c->bFac, &c->bNoise, &c->bNoiseBase };
     for (DevBuf *b : bufs) b->release();
@@ -368,12 +380,13 @@ extern "C"
     if (!c) return limg_hip_error_ArgumentNull;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());
-    if (c->lookback.p)
+    if (c->devStatus.p)
     {
-      uint32_t words[2] = { 0, 0 };
-      HIP_TRY(hipMemcpy(words, c->lookback.p, 8, hipMemcpyDeviceToHost));
-      if (words[1] != 0)
+      uint32_t word = 0;
+      HIP_TRY(hipMemcpy(&word, c->devStatus.p, 4, hipMemcpyDeviceToHost));
+      if (word != 0)
       {
+        HIP_TRY(hipMemset(c->devStatus.p, 0, 4)); // sticky until reported once
         fprintf(stderr, "limg_hip: look-back timeout in the fused encode kernel\n");
         return limg_hip_error_Generic;
       }

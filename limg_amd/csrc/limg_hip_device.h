@@ -345,9 +345,18 @@ namespace limg_hip
     __device__ __forceinline__ V4 operator-(const V4 &x, const V4 &y) { V4 r; r.a = x.a - y.a; r.b = x.b - y.b; return r; }
     __device__ __forceinline__ V4 operator+(const V4 &x, const V4 &y) { V4 r; r.a = x.a + y.a; r.b = x.b + y.b; return r; }
     __device__ __forceinline__ V4 operator*(const V4 &x, float s) { V4 r; r.a = x.a * s; r.b = x.b * s; return r; }
-    template <int CH>
+    // FAST (limg_hip_options.float_mode = 1): the same dot product with the second pair of products fused into the first (v_pk_fma_f32): one
+    // instruction and two roundings fewer; not the reference's bits, covered by the FAST-mode tolerance contract (DESIGN.md "numerics").
+    template <int CH, bool FAST = false>
     __device__ __forceinline__ float dp4(const V4 &x, const V4 &y)
     {
+      if (FAST)
+      {
+        float2_t yb = y.b;
+        if (CH == 3) yb.y = 0.0f;
+        const float2_t s2 = __builtin_elementwise_fma(x.b, yb, x.a * y.a);
+        return s2.x + s2.y;
+      }
       const float2_t m = x.a * y.a;
       float2_t n = x.b * y.b;
       if (CH == 3) n.y = 0.0f; // DPPS mask 0x7F
@@ -362,7 +371,8 @@ namespace limg_hip
     // min/max by v_min3/v_max3: their only differences from MINPS/MAXPS are NaN handling and the sign of a zero result,
     // neither of which can reach the comparison's outcome; the NaN-producing degenerate cases never get here (kZero* flags).
     // RSQRTPS = the captured Intel table: index = [exponent lsb : top 10 mantissa bits], exponent = 126 - floor((e - 127) / 2).
-    template <int CH>
+    // FAST: the hardware's v_rsq_f32 (1 ulp) instead of the 12-bit x86 table -- unit vectors 2^-12 closer to unit length than the reference's.
+    template <int CH, bool FAST = false>
     __device__ __forceinline__ V4 unit4(const unsigned short *tab, const V4 &d, bool active)
     {
       const float2_t biasA = { FLT_EPSILON * 3, FLT_EPSILON * 1 }, biasB = { FLT_EPSILON * 2, 0.0f };
@@ -371,13 +381,18 @@ namespace limg_hip
       const float mx = vmax3(xbA.x, xbA.y, vmax(xbB.x, xbB.y));
       const uint32_t anybits = (__float_as_uint(d.a.x) | __float_as_uint(d.a.y) | __float_as_uint(d.b.x) | __float_as_uint(d.b.y)) << 1;
       const bool use = (anybits != 0u) && active;
-      const float len2 = dp4<CH>(d, d);
-      // RSQRTPS table lookup; for skipped lanes len2 == 0 => index 0x400, exponent garbage: result discarded below
-      const uint32_t bits = __float_as_uint(len2);
-      const uint32_t idx2 = ((bits >> 12) & 0xFFEu) ^ 0x800u; // byte offset into the u16 table
-      const uint32_t tv = *reinterpret_cast<const unsigned short *>(reinterpret_cast<const unsigned char *>(tab) + idx2);
-      const uint32_t ex = (380u - (bits >> 23)) >> 1; // 126 - floor((e - 127) / 2)
-      float inv = __uint_as_float((ex << 23) | (tv << 11));
+      const float len2 = dp4<CH, FAST>(d, d);
+      float inv;
+      if (FAST) inv = __builtin_amdgcn_rsqf(len2);
+      else
+      {
+        // RSQRTPS table lookup; for skipped lanes len2 == 0 => index 0x400, exponent garbage: result discarded below
+        const uint32_t bits = __float_as_uint(len2);
+        const uint32_t idx2 = ((bits >> 12) & 0xFFEu) ^ 0x800u; // byte offset into the u16 table
+        const uint32_t tv = *reinterpret_cast<const unsigned short *>(reinterpret_cast<const unsigned char *>(tab) + idx2);
+        const uint32_t ex = (380u - (bits >> 23)) >> 1; // 126 - floor((e - 127) / 2)
+        inv = __uint_as_float((ex << 23) | (tv << 11));
+      }
       inv = (-mn > mx) ? -inv : inv; // |min| > max  (min >= 0 can never satisfy either form)
       inv = use ? inv : 0.0f;
       return d * inv;

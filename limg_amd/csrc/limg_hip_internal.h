@@ -41,11 +41,15 @@ namespace limg_hip
     const uint8_t *noise;
     // fused single-kernel path: per-strip look-back descriptors (status << 32 | value), work ticket, error word
     unsigned long long *desc;
-    uint32_t *ticket;   // [0] = next strip id, [1] = look-back timeout flag
+    uint32_t *ticket;   // [0] = next strip id
+    uint32_t *timeout;  // sticky: set when a look-back spin gave up; lives outside the per-launch words, cleared only by limg_hip_check_device_status
     uint8_t *park;      // persistent kernel: per workgroup two 8 KiB slots holding a strip's parked results between its E and F steps
     int32_t compactOut; // persistent kernel: also write records / shift words to the raster-order arrays
     int32_t streamRaw;  // compact mode only: factors with shift 8 store their raw byte instead of 0 (input of the stream packer)
     int32_t fitOnly;    // split path: stop after the records (pass 1 of the merged-block encoder, src/limg.cpp:1088-1119)
+    int32_t floatFast;  // host dispatch only: FAST float stage (limg_hip_options.float_mode = 1)
+    int32_t vecIn;      // rows of pIn may be read 16 bytes per lane (sizeX % 4 == 0 and pIn 16-byte aligned); otherwise dword loads
+    int32_t vecFactors; // the three factor planes may be accessed 16 bytes per lane (sizeX % 16 == 0 and all three 16-byte aligned)
   };
 
   // stream pack (limg_hip_stream.hip): from the compact outputs of an encode (factor planes, records, shift words)

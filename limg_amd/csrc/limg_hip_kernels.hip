@@ -375,7 +375,7 @@ namespace limg_hip
       {
         const uint32_t stripW = min(p.sizeX - x0, (uint32_t)(kStripBlocks * kBlock));
         uint8_t *planes8[3] = { p.info.pFactorsA, p.info.pFactorsB, p.info.pFactorsC };
-        if ((p.sizeX & 15u) == 0)
+        if (p.vecFactors)
         {
           for (int i = tid; i < 384; i += kThreads)
           {
@@ -441,7 +441,7 @@ namespace limg_hip
     // Pixel-order accumulation (as `serial_sums`) followed, lane-parallel over the wave's 8 blocks, by everything the next
     // phase needs of the new direction: 1 / (dir . dir) with the DPPS order (correctly rounded division, once per 8 blocks)
     // and the all-zero flag.
-    template <int CH, int WHICH>
+    template <int CH, int WHICH, bool FAST>
     __device__ __forceinline__ void serial_sums2(const float *V, BlkF *blk, int lane)
     {
       wave_lds_fence();
@@ -463,7 +463,7 @@ namespace limg_hip
         uint32_t z = (dir == 0.0f) ? 1u : 0u;
         z &= (uint32_t)dpp<0xB1, 0xF>(0, (int)z);
         z &= (uint32_t)dpp<0x4E, 0xF>(0, (int)z);
-        const float inv = 1.0f / p;
+        const float inv = FAST ? __builtin_amdgcn_rcpf(p) : 1.0f / p;
         if (c == 0)
         {
           if (WHICH == kDirA) { blk[b].invA = inv; if (z) blk[b].flags |= kZeroA | kZeroB | kZeroC; }
@@ -479,7 +479,7 @@ namespace limg_hip
     // own count, 2 = inclusive count of the chain up to and including this strip).  Written and read with relaxed agent-scope
     // 8-byte atomics only: value and status travel in one granule, so no other ordering is needed.  Strip ids are handed out
     // by a ticket, so every predecessor of a running workgroup has itself started (and never waits on a successor): the
-    // look-back always terminates.  The spin is bounded all the same; a timeout raises ticket[1] and the kernel finishes.
+    // look-back always terminates.  The spin is bounded all the same; a timeout raises the context's sticky status word and the kernel finishes.
     constexpr uint32_t kDescAggregate = 1u, kDescInclusive = 2u;
 
     __device__ __forceinline__ void desc_store(unsigned long long *d, uint32_t status, uint32_t value)
@@ -524,7 +524,7 @@ namespace limg_hip
           }
           if (++spins > (1u << 22))
           {
-            if (lane == 0) atomicExch(p.ticket + 1, 1u);
+            if (lane == 0) atomicExch(p.timeout, 1u);
             return base;
           }
           __builtin_amdgcn_s_sleep(2);
@@ -544,7 +544,7 @@ namespace limg_hip
     // parked results of one strip (persistent kernel): pre-dither factor bytes, records (int16 part), shift words
     constexpr int kParkFac = 0, kParkRec = 6144, kParkShift = 6144 + 1536, kParkBytes = 8192;
 
-    template <int CH, bool PERSIST>
+    template <int CH, bool PERSIST, bool FAST>
     __device__ __forceinline__ void fit_search_strip(const EncodeParams &p, const uint32_t id, uint8_t *lds, uint8_t *park, const int tid)
     {
       // the 4 KiB RSQRTPS table is read straight from global memory (it lives in the CU's vector L1): keeping a copy in LDS would
@@ -562,7 +562,7 @@ namespace limg_hip
       const uint32_t ry = min(p.sizeY - y0, (uint32_t)kBlock);
 
       // ---- stage: the strip's pixel rows into LDS (the rsqrt table is loaded by the caller) ----------------------------
-      if ((p.sizeX & 3u) == 0)
+      if (p.vecIn)
       {
 #pragma unroll
         for (int pass = 0; pass < 2; pass++)
@@ -599,7 +599,7 @@ namespace limg_hip
       };
 
       // The float stage runs in batches of kBatch blocks per wave: the parked contributions of one batch are what limits the
-      // workgroups per CU (LDS), and 4 blocks x 4 waves keep it at 4 workgroups per CU.
+      // workgroups per CU (LDS), and 4 blocks x 4 waves keep it at 5 workgroups per CU.
       // Per-block values of the batch stay in registers across the phases (the loops over i are fully unrolled).
 #pragma unroll 1
       for (int h = 0; h < kBlocksPerWave / kBatch; h++)
@@ -655,7 +655,7 @@ namespace limg_hip
         avg.b = float2_t{ (float)(int)(s13 & 0xFFFF), CH == 4 ? (float)(int)(s13 >> 16) : 0.0f } * inv_count;
         V4 d = pf - avg;
         mask_alpha<CH>(d);
-        st4(V + i * kVDw + lane * 4, unit4<CH>(s_rsq, d, (uint32_t)lane < n));
+        st4(V + i * kVDw + lane * 4, unit4<CH, FAST>(s_rsq, d, (uint32_t)lane < n));
         if (lane == 0)
         {
           st4(blk[b].avg, avg);
@@ -667,7 +667,7 @@ namespace limg_hip
           blk[b].inv_count = inv_count; blk[b].n = n; blk[b].flags = kValid;
         }
       }
-      serial_sums2<CH, kDirA>(V, blkh, lane);
+      serial_sums2<CH, kDirA, FAST>(V, blkh, lane);
 
       // ---- phase B: factor A extrema, residual -> second direction (pass 2) --------------------------------------------
       {
@@ -687,19 +687,19 @@ namespace limg_hip
           const float invA = blk[b].invA;
           const V4 pf = px_to_v4(px8[i]);
           const bool active = (uint32_t)lane < n;
-          const float fA = dp4<CH>(pf - avg, dirA) * invA;
+          const float fA = dp4<CH, FAST>(pf - avg, dirA) * invA;
           mnv[i] = active ? fA : 0.0f; mxv[i] = mnv[i]; // min / max start at 0 upstream (src/limg_factorization.h:633-634)
           est8[i] = avg + dirA * fA;
           V4 e = pf - est8[i];
           mask_alpha<CH>(e);
-          st4(V + i * kVDw + lane * 4, unit4<CH>(s_rsq, e, active));
+          st4(V + i * kVDw + lane * 4, unit4<CH, FAST>(s_rsq, e, active));
         }
         wave_reduce4_min_max(mnv, mxv);
 #pragma unroll
         for (int i = 0; i < kBatch; i++)
           if (did[i] && lane == 0) { blk[h * kBatch + i].mm[0] = vmin(mnv[i], 0.0f); blk[h * kBatch + i].mm[1] = vmax(mxv[i], 0.0f); }
       }
-      serial_sums2<CH, kDirB>(V, blkh, lane);
+      serial_sums2<CH, kDirB, FAST>(V, blkh, lane);
 
       // ---- phase C: factor B (and, 3 ch, C) extrema; 4 ch: residual -> third direction (pass 3) ---------------------
       float mnCv[kBatch], mxCv[kBatch];
@@ -717,13 +717,13 @@ namespace limg_hip
         const float invB = blk[b].invB;
         const V4 pf = px_to_v4(px8[i]);
         const bool active = (uint32_t)lane < n;
-        const float fB = dp4<CH>(pf - est8[i], dirB) * invB;
+        const float fB = dp4<CH, FAST>(pf - est8[i], dirB) * invB;
         float mnB = active ? fB : FLT_MAX, mxB = active ? fB : -FLT_MAX;
         if (CH == 4)
         {
           didC[i] = true; mnCv[i] = mnB; mxCv[i] = mxB; // reduced for the whole batch after the loop
           est8[i] = est8[i] + dirB * fB;
-          st4(V + i * kVDw + lane * 4, unit4<CH>(s_rsq, pf - est8[i], active));
+          st4(V + i * kVDw + lane * 4, unit4<CH, FAST>(s_rsq, pf - est8[i], active));
           if (lane == 0) st4(blk[b].est0, est8[i]);
         }
         else
@@ -739,9 +739,9 @@ namespace limg_hip
           float mnC = 0.0f, mxC = 0.0f;
           if (!zeroC)
           {
-            const float invC = 1.0f / dp4<CH>(dirC, dirC);
+            const float invC = FAST ? __builtin_amdgcn_rcpf(dp4<CH, FAST>(dirC, dirC)) : 1.0f / dp4<CH, FAST>(dirC, dirC);
             const V4 e = pf - (est8[i] + dirB * fB);
-            const float fC = dp4<CH>(e, dirC) * invC;
+            const float fC = dp4<CH, FAST>(e, dirC) * invC;
             mnC = active ? fC : FLT_MAX; mxC = active ? fC : -FLT_MAX;
             wave_min_max(mnB, mxB);
             wave_min_max(mnC, mxC);
@@ -763,7 +763,7 @@ namespace limg_hip
         for (int i = 0; i < kBatch; i++)
           if (didC[i] && lane == 0) { blk[h * kBatch + i].mm[2] = mnCv[i]; blk[h * kBatch + i].mm[3] = mxCv[i]; }
         // blocks that skipped phase C left stale pass-2 contributions in V; their dirC is never used (flags)
-        serial_sums2<CH, kDirC>(V, blkh, lane);
+        serial_sums2<CH, kDirC, FAST>(V, blkh, lane);
         // ---- phase D: factor C extrema (pass 4).  Upstream never advances its estimate pointer in this loop
         //      (src/limg_factorization.h:748-758), so every pixel is measured against pixel 0's A+B estimate.
         float mnDv[kBatch], mxDv[kBatch];
@@ -781,7 +781,7 @@ namespace limg_hip
           const float invC = blk[b].invC;
           const V4 pf = px_to_v4(px8[i]);
           const bool active = (uint32_t)lane < n;
-          const float fC = dp4<CH>(pf - est0, dirC) * invC;
+          const float fC = dp4<CH, FAST>(pf - est0, dirC) * invC;
           mnDv[i] = active ? fC : FLT_MAX; mxDv[i] = active ? fC : -FLT_MAX;
         }
         wave_reduce4_min_max(mnDv, mxDv);
@@ -849,7 +849,7 @@ namespace limg_hip
           float s = ((0.0f + s0) + s1) + s2;
           if (CH == 4) s = s + s3;
           const bool nz = (s0 != 0.0f) || (s1 != 0.0f) || (s2 != 0.0f) || (CH == 4 && s3 != 0.0f);
-          invn[r] = nz ? 1.0f / s : 0.0f;
+          invn[r] = nz ? (FAST ? __builtin_amdgcn_rcpf(s) : 1.0f / s) : 0.0f;
         }
         wave_lds_fence(); // every lane has read what it needs of the float-stage fields before the overlay is written
 #pragma unroll
@@ -901,15 +901,15 @@ namespace limg_hip
         { // a8 (src/limg_factorization.h:149-197): fa = ((px - Amin) . nA) * invA, est = Amin + nA * fa, fb from px - est - Boff, ...
           const V4 pv = px_to_v4(px);
           const V4 nA = ld4(be->nrm[0]), mnA = ld4(be->off[0]);
-          const float fa = dp4<CH>(pv - mnA, nA) * be->invN[0];
+          const float fa = dp4<CH, FAST>(pv - mnA, nA) * be->invN[0];
           int q = cvt_rne(255.0f * fa); fA = (uint32_t)med3_i32(q, 0, 255);
           const V4 nB = ld4(be->nrm[1]), ofB = ld4(be->off[1]);
           V4 est = mnA + nA * fa;
-          const float fb = dp4<CH>((pv - est) - ofB, nB) * be->invN[1];
+          const float fb = dp4<CH, FAST>((pv - est) - ofB, nB) * be->invN[1];
           q = cvt_rne(255.0f * fb); fB = (uint32_t)med3_i32(q, 0, 255);
           const V4 nC = ld4(be->nrm[2]), ofC = ld4(be->off[2]);
           est = est + nB * fb;
-          const float fc = dp4<CH>((pv - est) - ofC, nC) * be->invN[2];
+          const float fc = dp4<CH, FAST>((pv - est) - ofC, nC) * be->invN[2];
           q = cvt_rne(255.0f * fc); fC = (uint32_t)med3_i32(q, 0, 255);
         }
 
@@ -1025,7 +1025,7 @@ namespace limg_hip
       if (p.storePlanes)
       {
         uint8_t *planes[3] = { p.info.pFactorsA, p.info.pFactorsB, p.info.pFactorsC };
-        if ((p.sizeX & 15u) == 0)
+        if (p.vecFactors)
         {
           for (int i = tid; i < 384; i += kThreads)
           {
@@ -1120,7 +1120,7 @@ namespace limg_hip
       }
       else
       {
-        if ((p.sizeX & 15u) == 0)
+        if (p.vecFactors)
         {
           for (int i = tid; i < 384; i += kThreads)
           {
@@ -1182,11 +1182,11 @@ namespace limg_hip
     }
 
     // ---- kernels ---------------------------------------------------------------------------------------------------------
-    template <int CH>
+    template <int CH, bool FAST>
     __global__ __launch_bounds__(kThreads) void k_fit_search(const EncodeParams p)
     {
       __shared__ __attribute__((aligned(16))) uint8_t s_lds[kLdsTotal];
-      fit_search_strip<CH, false>(p, blockIdx.x, s_lds, nullptr, (int)threadIdx.x);
+      fit_search_strip<CH, false, FAST>(p, blockIdx.x, s_lds, nullptr, (int)threadIdx.x);
     }
 
     template <int CH>
@@ -1199,14 +1199,14 @@ namespace limg_hip
     // Both steps are inlined into the loop.  Left alone, LLVM hoists every lane-dependent address computation of both steps
     // out of the loop (they only depend on threadIdx) and keeps them all live: 194 VGPRs.  Passing the thread id through an
     // empty asm at the top of each iteration makes it opaque per iteration, which keeps the two steps' live ranges apart.
-    // Persistent single-launch encode: 3 workgroups per CU loop over the work strips (ticket order).  Each iteration runs the
+    // Persistent single-launch encode: 5 workgroups per CU loop over the work strips (ticket order).  Each iteration runs the
     // VALU-bound E step (fit + search) of a new strip and then the HBM-bound F step (dither, decode, all plane stores) of the
     // strip the SAME workgroup fitted one iteration earlier, whose parked results sit in a private, L2-resident 8 KiB slot.
     // The one-iteration lag means that by the time an F step asks for its strip's position in the dither chain, every
     // earlier strip has long published its call count, so the look-back does not wait; and since the workgroups of a CU
     // drift apart, E and F steps of different workgroups overlap on every CU.
     // Progress: a look-back only waits for strips with smaller tickets; those were drawn earlier, and an E step never waits.
-    template <int CH>
+    template <int CH, bool FAST>
     __global__ __launch_bounds__(kThreads, 5) void k_encode_persistent(const EncodeParams p)
     {
       __shared__ __attribute__((aligned(16))) uint8_t s_lds[kLdsTotal];
@@ -1223,7 +1223,7 @@ namespace limg_hip
         const uint32_t t = s_ticket;
         int tid_e = tid;
         asm volatile("" : "+v"(tid_e));
-        if (t < S) fit_search_strip<CH, true>(p, t, s_lds, park + slot * kParkBytes, tid_e);
+        if (t < S) fit_search_strip<CH, true, FAST>(p, t, s_lds, park + slot * kParkBytes, tid_e);
         if (prev != 0xFFFFFFFFu)
         {
           __syncthreads();
@@ -1241,16 +1241,26 @@ namespace limg_hip
   void launch_fit_search(const EncodeParams &p, int channels, hipStream_t s)
   {
     const dim3 grid(p.stripsX * p.blocksY), block(kThreads);
-    if (channels == 4) hipLaunchKernelGGL(k_fit_search<4>, grid, block, 0, s, p);
-    else hipLaunchKernelGGL(k_fit_search<3>, grid, block, 0, s, p);
+    if (p.floatFast)
+    {
+      if (channels == 4) hipLaunchKernelGGL((k_fit_search<4, true>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((k_fit_search<3, true>), grid, block, 0, s, p);
+    }
+    else if (channels == 4) hipLaunchKernelGGL((k_fit_search<4, false>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((k_fit_search<3, false>), grid, block, 0, s, p);
   }
 
   void launch_encode_persistent(const EncodeParams &p, int channels, int workgroups, hipStream_t s)
   {
     const uint32_t strips = p.stripsX * p.blocksY;
     const dim3 grid(strips < (uint32_t)workgroups ? strips : (uint32_t)workgroups), block(kThreads);
-    if (channels == 4) hipLaunchKernelGGL(k_encode_persistent<4>, grid, block, 0, s, p);
-    else hipLaunchKernelGGL(k_encode_persistent<3>, grid, block, 0, s, p);
+    if (p.floatFast)
+    {
+      if (channels == 4) hipLaunchKernelGGL((k_encode_persistent<4, true>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((k_encode_persistent<3, true>), grid, block, 0, s, p);
+    }
+    else if (channels == 4) hipLaunchKernelGGL((k_encode_persistent<4, false>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((k_encode_persistent<3, false>), grid, block, 0, s, p);
   }
 
   void launch_strip_scan(const EncodeParams &p, hipStream_t s) { hipLaunchKernelGGL(k_strip_scan, dim3(1), dim3(1024), 0, s, p); }

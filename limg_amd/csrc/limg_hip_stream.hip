@@ -247,6 +247,7 @@ namespace limg_hip
       const unsigned long long payloadWords = h->payloadWords;
       const bool ok = h->magic == LIMG_HIP_STREAM_MAGIC && h->version == LIMG_HIP_STREAM_VERSION && h->sizeX == p.sizeX && h->sizeY == p.sizeY &&
                       h->blocksX == p.blocksX && h->blocksY == p.blocksY && (h->channels == 3 || h->channels == 4) &&
+                      payloadWords <= (unsigned long long)p.nBlocks * 24ull && // 3 fields x 8 words at most per block: bounds the product below
                       sizeof(limg_hip_stream_header) + (unsigned long long)p.nBlocks * kEntry + payloadWords * 8ull <= p.streamBytes;
       if (!ok)
       {
@@ -312,10 +313,13 @@ namespace limg_hip
         G.myOff = G.valid ? sOff[G.t] : 0u;
         G.off0 = sOff[jb];
         // the group's payload is one contiguous run in a stream this library wrote; anything else (corrupt offsets) is refused
-        const uint32_t endWord = (uint32_t)__shfl((int)(G.myOff + words_of(G.bw)), (int)nValid - 1, 64);
-        const bool sane = G.myOff >= G.off0 && G.myOff + words_of(G.bw) <= endWord && endWord - G.off0 <= (uint32_t)(kGroupBytes / 8) && (unsigned long long)endWord <= payloadWords;
+        // All of this in 64 bits: offsets come from the (untrusted) stream, and 32-bit sums such as 0xFFFFFFF0 + 24 wrap to small values that pass.
+        const unsigned long long myEnd = (unsigned long long)G.myOff + words_of(G.bw);
+        const uint32_t lastOff = (uint32_t)__shfl((int)G.myOff, (int)nValid - 1, 64), lastWords = (uint32_t)__shfl((int)words_of(G.bw), (int)nValid - 1, 64);
+        const unsigned long long endWord = (unsigned long long)lastOff + lastWords;
+        const bool sane = G.myOff >= G.off0 && myEnd <= endWord && endWord >= G.off0 && endWord - G.off0 <= (unsigned long long)(kGroupBytes / 8) && endWord <= payloadWords;
         G.ok = __builtin_amdgcn_ballot_w64(G.valid && !sane) == 0;
-        G.n = G.ok ? endWord - G.off0 : 0u;
+        G.n = G.ok ? (uint32_t)(endWord - G.off0) : 0u;
         return G;
       };
       auto fetch = [&](const Group &G, uint2 buf[3]) {

@@ -1,0 +1,129 @@
+"""FAST float mode (limg_hip_options.float_mode = 1; north_star: "within a stated PSNR tolerance on the float factor stage").  Its contract, from
+SURVEY.md 8(c):
+  Stage F (a4-a8)  : int16 extrema within +-2 LSB of the EXACT mode's on >= 99.9 % of blocks; end-to-end perceptual PSNR within 0.10 dB of EXACT.
+                     One stated exception, measured not assumed: the THIRD direction of 4-channel synthetic gradients.  With opaque alpha a gradient block spans
+                     two colour directions, so pass 3 fits a direction to the rounding residue of passes 1-2; any change of the arithmetic moves it -- the
+                     reference's own -ffast-math build differs from its strict build there on 0.3 % of the blocks by up to 21 LSB (profiles/r02_fast_float.md) at
+                     identical PSNR.  For those images the C extrema get >= 97 % of blocks instead of 99.9 %; A and B keep 99.9 % everywhere;
+  Stage I (a9-a16) : bit-exact GIVEN the records and factor bytes the float stage produced -- checked here by feeding the GPU's own FAST-mode records and
+                     pre-dither factor bytes to the oracle's integer stage (search, dither chain, plane packing, decode) block by block.
+EXACT stays the default and the headline; this file is the whole of FAST's parity claim."""
+import numpy as np
+import pytest
+
+from oracle.bind import PLANES, REC_DTYPE
+
+pytestmark = pytest.mark.gpu
+
+REC_I16 = ("dirA_min", "dirA_max", "dirB_offset", "dirB_mag", "dirC_offset", "dirC_mag")
+TOL_LSB = 2          # extrema tolerance (int16 LSB)
+TOL_BLOCK_FRAC = 1e-3  # blocks allowed outside it
+TOL_PSNR_DB = 0.10
+
+
+@pytest.fixture(scope="module", params=["fused", "split"])
+def gpu(request):
+    import limg_amd
+    g = limg_amd.LimgHip(0)
+    g.mode = request.param
+    yield g
+    g.set_options()
+    g.check()
+    g.close()
+
+
+def _encode(gpu, d_img, alpha, fast_float, forced=None, error_factor=100):
+    import torch
+    h, w = d_img.shape
+    gpu.set_options(force_split=(gpu.mode == "split"), float_fast=fast_float, forced_shift=forced)
+    planes = gpu.alloc_planes_device(w, h)
+    rec = torch.zeros(((h + 7) // 8 * ((w + 7) // 8), 16), dtype=torch.int32, device="cuda")
+    sh = torch.zeros((h + 7) // 8 * ((w + 7) // 8), dtype=torch.int32, device="cuda")
+    gpu.encode3d_device(d_img, alpha, planes, records=rec, shifts=sh, error_factor=error_factor)
+    torch.cuda.synchronize()
+    out = {k: v.cpu().numpy().view(np.uint32 if v.dtype == torch.int32 else np.uint8) for k, v in planes.items()}
+    out["records"] = rec.cpu().numpy().view(REC_DTYPE).reshape((h + 7) // 8, (w + 7) // 8)
+    out["shifts"] = sh.cpu().numpy().astype(np.uint32).reshape((h + 7) // 8, (w + 7) // 8)
+    return out
+
+
+@pytest.mark.parametrize("kind,alpha,size", [("pn", True, 1024), ("rg", True, 1024), ("pn", False, 1024), ("rga", True, 512)])
+def test_float_stage_tolerance(gpu, oracle, kind, alpha, size):
+    import torch
+    img = {"pn": lambda: oracle.photo_noise(size, size, 1), "rg": lambda: oracle.random_gradient(size, size, 1, True), "rga": lambda: oracle.random_gradient(size, size, 1, False)}[kind]()
+    d_img = torch.from_numpy(img.view(np.int32)).cuda()
+    exact = _encode(gpu, d_img, alpha, False)
+    fast = _encode(gpu, d_img, alpha, True)
+    want = oracle.encode3d(img, alpha)
+    for k in PLANES:  # EXACT is untouched by the new template parameter
+        assert np.array_equal(exact[k], want[k]), k
+    nblocks = exact["records"].size
+    residue_fit_c = alpha and kind in ("rg", "rga")  # see the module docstring
+    for group, fields in (("AB", REC_I16[:4]), ("C", REC_I16[4:])):
+        off = np.zeros(exact["records"].shape, dtype=bool)
+        worst = 0
+        for f in fields:
+            d = np.abs(exact["records"][f].astype(np.int32) - fast["records"][f].astype(np.int32)).max(axis=-1)
+            off |= d > TOL_LSB
+            worst = max(worst, int(d.max()))
+        allowed = 0.03 if (group == "C" and residue_fit_c) else TOL_BLOCK_FRAC
+        assert off.sum() / nblocks <= allowed, (kind, alpha, group, "blocks beyond +-%d LSB: %d of %d (worst %d)" % (TOL_LSB, off.sum(), nblocks, worst))
+    p_exact = gpu.compare(img, exact["pDecoded"], alpha)[0]
+    p_fast = gpu.compare(img, fast["pDecoded"], alpha)[0]
+    assert abs(p_exact - p_fast) <= TOL_PSNR_DB, (kind, alpha, p_exact, p_fast)
+
+
+@pytest.mark.parametrize("kind,alpha", [("pn", True), ("rg", True), ("pn", False)])
+def test_integer_stage_exact_given_fast_records(gpu, oracle, kind, alpha):
+    """Records and pre-dither factor bytes from the GPU's FAST float stage (forced shift 0 => the factor planes hold the raw factor bytes) go through the
+    ORACLE's integer stage: its search must pick the GPU's shifts and its dither chain + decode must reproduce the GPU's factor planes and pDecoded."""
+    import torch
+    W, H = 256, 32
+    ch = 4 if alpha else 3
+    img = oracle.photo_noise(W, H, 9) if kind == "pn" else oracle.random_gradient(W, H, 9, True)
+    d_img = torch.from_numpy(img.view(np.int32)).cuda()
+    raw = _encode(gpu, d_img, alpha, True, forced=(0, 0, 0))
+    got = _encode(gpu, d_img, alpha, True)
+    for f in REC_DTYPE.names:
+        assert np.array_equal(raw["records"][f], got["records"][f]), f  # the float stage does not depend on the shifts
+    seed = 0xCA7F00D15BADF00D
+    h = seed
+    for by in range(H // 8):
+        for bx in range(W // 8):
+            sl = (slice(by * 8, by * 8 + 8), slice(bx * 8, bx * 8 + 8))
+            px = np.ascontiguousarray(img[sl]).ravel()
+            rec = np.ascontiguousarray(got["records"][by, bx:bx + 1])
+            fa, fb, fc = (np.ascontiguousarray(raw[k][sl]).ravel() for k in ("pFactorsA", "pFactorsB", "pFactorsC"))
+            shift, _ = oracle.block_search(px, ch, rec, fa, fb, fc, 100, True)
+            w = int(got["shifts"][by, bx])
+            assert [int(s) for s in shift] == [w & 0xFF, (w >> 8) & 0xFF, (w >> 16) & 0xFF], (by, bx)
+            fs = []
+            for s, f in zip(shift, (fa, fb, fc)):
+                if int(s) not in (0, 8):
+                    h, f = oracle.dither(int(s), h, f)
+                fs.append(f)
+            dec = oracle.block_decode(8, 8, ch, rec, fs[0], fs[1], fs[2], shift)
+            assert np.array_equal(dec, got["pDecoded"][sl]), (by, bx)
+            for k, f, s in zip(("pFactorsA", "pFactorsB", "pFactorsC"), fs, shift):
+                assert np.array_equal(((f.astype(np.uint32) << int(s)) & 0xFF).astype(np.uint8).reshape(8, 8), got[k][sl]), (by, bx, k)
+
+
+def test_fast_mode_at_bench_size(gpu):
+    """8192^2 photo-noise (the bench workload): PSNR of FAST within 0.10 dB of EXACT, shifts identical on >= 99 % of blocks."""
+    import torch
+    W = 8192
+    d_img = gpu.synth_device("photo_noise", W, W, seed=1)
+    res = {}
+    for ff in (False, True):
+        gpu.set_options(force_split=(gpu.mode == "split"), float_fast=ff)
+        planes = gpu.alloc_planes_device(W, W)
+        sh = torch.zeros((W // 8) ** 2, dtype=torch.int32, device="cuda")
+        gpu.encode3d_device(d_img, True, planes, shifts=sh)
+        torch.cuda.synchronize()
+        res[ff] = (gpu.compare_device(d_img, planes["pDecoded"], True)[0], sh & 0xFFFFFF)
+        del planes
+    assert abs(res[False][0] - res[True][0]) <= TOL_PSNR_DB, (res[False][0], res[True][0])
+    same = float((res[False][1] == res[True][1]).float().mean())
+    assert same >= 0.99, same
+    gpu.set_options()
+    torch.cuda.empty_cache()

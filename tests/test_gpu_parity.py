@@ -327,3 +327,104 @@ def test_two_contexts_on_two_threads(oracle):
     for t in th:
         t.join()
     assert not errs, errs
+
+
+def test_unaligned_device_pointers(gpu, oracle):
+    """Device pointers that are only 4-byte (uint32 planes, input) / 1-byte (factor planes) aligned -- slices of larger allocations -- take the kernels'
+    dword / byte paths and give the same planes (include/limg_hip.h "Alignment")."""
+    import torch
+    W, H = 512, 64
+    img = oracle.photo_noise(W, H, 77)
+    want = oracle.encode3d(img, True)
+    buf = torch.zeros(W * H + 8, dtype=torch.int32, device="cuda")
+    d_img = buf[1:1 + W * H].view(H, W)
+    d_img.copy_(torch.from_numpy(img.view(np.int32)))
+    assert d_img.data_ptr() % 16 == 4
+    planes = {}
+    for k in PLANES:
+        dt = torch.uint8 if k.startswith("pFactors") else torch.int32
+        b = torch.zeros(W * H + 32, dtype=dt, device="cuda")
+        off = {"pFactorsA": 1, "pFactorsB": 7, "pFactorsC": 16}.get(k, 3)
+        planes[k] = b[off:off + W * H].view(H, W)
+    gpu.encode3d_device(d_img, True, planes)
+    torch.cuda.synchronize()
+    got = {k: v.cpu().numpy().view(np.uint32 if v.dtype == torch.int32 else np.uint8) for k, v in planes.items()}
+    _assert_planes(got, want, "unaligned")
+
+
+def test_config4_batch_rehearsal(gpu, oracle):
+    """BASELINE config 4 (batch of 4096^2 random-gradient images, seeds 1.., 8 per GPU) as one GPU sees it: 8 images through ONE context, back to back on one
+    stream, each checked like test_full_size_properties: first 256-row band on every plane against the oracle (its chain starts at the seed), a middle band
+    on the chain-independent planes, and the perceptual PSNR of the whole image."""
+    import torch
+    W = 4096
+    imgs = [gpu.synth_device("random_gradient", W, W, seed=1 + i) for i in range(8)]
+    outs = [gpu.alloc_planes_device(W, W) for _ in range(8)]
+    for d_img, planes in zip(imgs, outs):  # enqueue all eight before looking at any: the context's scratch is reused launch after launch
+        gpu.encode3d_device(d_img, True, planes)
+    torch.cuda.synchronize()
+    gpu.check()
+    for i, (d_img, planes) in enumerate(zip(imgs, outs)):
+        psnr, _ = gpu.compare_device(d_img, planes["pDecoded"], True)
+        assert 44.0 < psnr < 60.0, (i, psnr)
+        band = d_img[:256].cpu().numpy().view(np.uint32)
+        want = oracle.encode3d(band, True)
+        for k in PLANES:
+            got = planes[k][:256].cpu().numpy()
+            got = got.view(np.uint32) if got.dtype == np.int32 else got
+            assert np.array_equal(got, want[k]), (i, k)
+        if i == 0:
+            assert abs(psnr - 50.38) < 0.05  # the reference's figure for seed 1 (SURVEY 6)
+        mid = d_img[W // 2: W // 2 + 64].cpu().numpy().view(np.uint32)
+        want = oracle.encode3d(mid, True)
+        for k in ("pShiftABCX", "pColAMin", "pColAMax", "pColBMin", "pColBMax", "pColCMin", "pColCMax"):
+            assert np.array_equal(planes[k][W // 2: W // 2 + 64].cpu().numpy().view(np.uint32), want[k]), (i, k)
+    del imgs, outs
+    torch.cuda.empty_cache()
+
+
+def test_config5_strip_sharded_rehearsal(gpu, oracle):
+    """BASELINE config 5 (16384^2 photo-noise, 8 strips of whole block rows = shard.strip_rows(16384, 8)) rehearsed on one GPU:
+    (1) the strip-restart encode of the whole image (pool of 2 threads = 8 chains, src/limg.cpp:2114-2134) equals independent encodes of strips 0 / 3 / 7,
+        i.e. what ranks 0 / 3 / 7 of the 8-GPU job produce without any exchange;
+    (2) the first 256 rows equal the oracle on every plane;
+    (3) `--gather-stream` reassembly: every strip's compact stream, decoded into its rows of the full image, reproduces pDecoded."""
+    import torch
+    from limg_amd import shard
+    W = 16384
+    rows = shard.strip_rows(W, 8)
+    assert rows == [(i * 2048, (i + 1) * 2048) for i in range(8)] and shard.equivalent_pool_threads(8) == 2
+    d_img = gpu.synth_device("photo_noise", W, W, seed=1)
+    planes = gpu.alloc_planes_device(W, W)
+    gpu.encode3d_device(d_img, True, planes, pool_threads=2)
+    torch.cuda.synchronize()
+    gpu.check()
+    psnr, _ = gpu.compare_device(d_img, planes["pDecoded"], True)
+    assert 38.0 < psnr < 40.0, psnr
+    band = d_img[:256].cpu().numpy().view(np.uint32)
+    want = oracle.encode3d(band, True)
+    for k in PLANES:
+        got = planes[k][:256].cpu().numpy()
+        got = got.view(np.uint32) if got.dtype == np.int32 else got
+        assert np.array_equal(got, want[k]), k
+    part = gpu.alloc_planes_device(W, 2048)
+    for s in (0, 3, 7):
+        y0, y1 = rows[s]
+        gpu.encode3d_device(d_img[y0:y1], True, part)  # a rank's own strip: fresh chain, no exchange
+        torch.cuda.synchronize()
+        for k in PLANES:
+            assert torch.equal(part[k], planes[k][y0:y1]), (s, k)
+    del part
+    # (3) only the compact streams would cross xGMI: decode each into its rows of one full-size image
+    full = torch.zeros((W, W), dtype=torch.int32, device="cuda")
+    total = 0
+    for s, (y0, y1) in enumerate(rows):
+        st, n = gpu.encode_stream_device(d_img[y0:y1], True)
+        gpu.decode_stream_device(st, n, W, y1 - y0, out=full[y0:y1])
+        total += n
+    torch.cuda.synchronize()
+    gpu.check()
+    assert torch.equal(full, planes["pDecoded"])
+    assert total < W * W * 3  # ~1.8 B/px of stream instead of 35 B/px of planes
+    del full, planes, d_img
+    torch.cuda.empty_cache()

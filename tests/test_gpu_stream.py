@@ -90,4 +90,28 @@ def test_refuses_bad_streams(gpu, oracle):
     evil[64:64 + 56 * len(table)].view(S.BLOCK)["payloadWord"][3] = 0x7FFFFFF0
     with pytest.raises(limg_amd.LimgHipError):
         gpu.decode_stream(evil)
+    # offsets whose 32-bit sums wrap: a whole group of 8 at 0xFFFFFFF0 -- every 32-bit check would pass (0xFFFFFFF0 + 24 == 8)
+    evil = st.copy()
+    evil[64:64 + 56 * len(table)].view(S.BLOCK)["payloadWord"][:8] = 0xFFFFFFF0
+    with pytest.raises(limg_amd.LimgHipError):
+        gpu.decode_stream(evil)
     assert np.array_equal(gpu.decode_stream(st), gpu.encode3d(img, True)["pDecoded"])  # the context is usable afterwards
+
+
+def test_device_decode_refuses_wrapping_header(gpu, oracle):
+    """The device entry never sees limg_hip_stream_info: a header whose payloadWords * 8 wraps in 64 bits (>= 2^61) must be refused by the
+    kernel's own header check, not accepted because the wrapped byte count is small."""
+    import torch
+    import limg_amd
+    img = oracle.photo_noise(64, 64, 5)
+    st = gpu.encode_stream(img, True)
+    evil = st.copy()
+    evil[:64].view(S.HEADER)["payloadWords"][0] = (1 << 61) + 3
+    d = torch.from_numpy(evil).cuda()
+    out = torch.zeros((64, 64), dtype=torch.int32, device="cuda")
+    gpu.decode_stream_device(d, evil.size, 64, 64, out=out)
+    torch.cuda.synchronize()
+    with pytest.raises(limg_amd.LimgHipError):
+        gpu.check()
+    assert int(out.abs().max()) == 0
+    assert np.array_equal(gpu.decode_stream(st), gpu.encode3d(img, True)["pDecoded"])
