@@ -146,12 +146,23 @@ def run_sharded(args, g, dist, rank, world):
             units.append((g.synth_device(kind, W, y1 - y0, seed=1, y0=y0), g.alloc_planes_device(W, y1 - y0)))
         total_px = W * H
         name = ("one synthetic %dx%d RGBA %s image as 8 strips of whole block rows with restarted dither chains (== reference with a pool of 2 threads), "
-                "%d strips per rank" % (W, H, kind, per))
+                "%d strips per rank" % (W, H, kind, per)) + (" -- SINGLE CHAIN through the strips (8-byte all-gather between E and F step)" if args.single_chain else "")
     torch.cuda.synchronize()
 
+    single_chain = args.config == 5 and args.single_chain
+    if single_chain:
+        if dist is None or dist.get_backend() != "nccl" or 8 != world:
+            raise SystemExit("--single-chain: one strip per rank over RCCL (8 ranks); its exchange-free halves are covered by tests/test_gpu_collective.py")
+        g.comm_init_from_torch(dist)
+        g._comm_ready = True
+        before = [(y0 // 8) * (W // 8) for (y0, _) in strips]
+
     def step():
-        for img, planes in units:
-            g.encode3d_device(img, True, planes, error_factor=args.error_factor, pool_threads=0, fast=True)
+        for i, (img, planes) in enumerate(units):
+            if single_chain:  # ONE dither chain through the 8 strips (== the reference with pThreadPool == nullptr): an 8-byte all-gather between E and F step
+                g.encode3d_single_chain_device(img, True, planes, before[rank], error_factor=args.error_factor)
+            else:
+                g.encode3d_device(img, True, planes, error_factor=args.error_factor, pool_threads=0, fast=True)
 
     for _ in range(args.warmup):
         step()
@@ -183,18 +194,22 @@ def run_sharded(args, g, dist, rank, world):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         if args.config == 5 and args.gather_stream:
-            # the north-star's shape: only the bitstream crosses xGMI; rank 0 decodes every strip into its rows of the full image
+            # the north-star's shape: only the bitstream crosses xGMI (limg_hip_gather_stream: RCCL behind the C ABI); rank 0 decodes every strip into its rows
             per = 8 // world
             full = torch.empty((H, W), dtype=torch.int32, device="cuda") if rank == 0 else None
+            cap = sum(g.stream_bound(W, y1 - y0) + 16 for (y0, y1) in rows[::per][:world]) if rank == 0 else 0
+            gbuf = torch.empty(cap, dtype=torch.uint8, device="cuda") if rank == 0 else None
             for k in range(per):
                 st, nb = g.encode_stream_device(units[k][0], True, error_factor=args.error_factor)
-                parts = shard.gather_bytes(st if on_gpu else st.cpu(), nb, dist, dst=0)
+                res = shard.gather_streams(g, st, nb, dist, dst=0, out=gbuf)
                 if rank == 0:
+                    buf, offs = res
+                    buf = buf if buf.is_cuda else buf.cuda()
                     for r in range(world):
                         y0, y1 = rows[r * per + k]
-                        part = parts[r] if on_gpu else parts[r].cuda()
-                        g.decode_stream_device(part, part.numel(), W, y1 - y0, out=full[y0:y1])
-                        gathered_bytes += part.numel()
+                        o0 = int(offs[r]); nbr = int(offs[r + 1]) - o0
+                        g.decode_stream_device(buf[o0:o0 + nbr], nbr, W, y1 - y0, out=full[y0:y1])
+                    gathered_bytes += int(offs[world])
             torch.cuda.synchronize()
             if rank == 0:   # decoded strips == the pDecoded planes of the same strips (this rank's own, checked here)
                 for k in range(per):
@@ -232,7 +247,7 @@ def run_sharded(args, g, dist, rank, world):
 
     if rank == 0:
         kavg = kernels.mean(axis=0) if len(kernels) else np.zeros(3)
-        ksum = float(kavg.sum())
+        ksum = float(kavg[0]) if not single_chain else float(kavg.sum())  # fused: the one launch's own interval
         px_per_launch = units[0][0].numel() if units else 0
         achieved = ALGO_BYTES_PER_PX * px_per_launch / (ksum * 1e-3) / 1e9 if ksum > 0 else 0.0
         line = {
@@ -428,6 +443,8 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="--config 4/5: skip the reassembly of the planes on rank 0")
     ap.add_argument("--gather-stream", action="store_true", help="--config 5: reassemble through the compact LMG3 stream instead of the planes: every rank encodes its "
                                                                      "strips to streams, rank 0 gathers the bytes and decodes them into the full image")
+    ap.add_argument("--single-chain", action="store_true", help="--config 5 on 8 ranks: one dither chain through all strips (limg_hip_encode3d_single_chain_device) instead of "
+                                                                    "the reference's strip-restart semantics")
     ap.add_argument("--share-gpus", action="store_true", help="rehearsal only: allow more ranks than GPUs (ranks share cards, gloo instead of RCCL)")
     args = ap.parse_args()
 

@@ -229,6 +229,39 @@ limg_hip_result limg_hip_decode_stream(limg_hip_context *pCtx, const uint8_t *pS
 /* Host-only: validates a header (first 64 bytes suffice) and reports the image shape. */
 limg_hip_result limg_hip_stream_info(const uint8_t *pStream, size_t streamBytes, size_t *pSizeX, size_t *pSizeY, int *pHasAlpha, size_t *pTotalBytes);
 
+/* ---- multi-GPU (one process per GPU; RCCL over xGMI) ---------------------------------------------------------------------------------
+ * The reference's only parallelism is row strips over a std::thread pool (src/limg.cpp:2105-2138); across GPUs the same strips
+ * go one per rank.  Blocks are independent except for the dither chain, so the data path needs no collective in strip-restart mode (each strip
+ * restarts its chain like the reference's pool strips: plain limg_hip_encode3d_device on the strip).  Two things do cross xGMI:
+ *   * limg_hip_gather_stream              : reassembly of the compact streams on one rank (variable-size gather: an 8-byte all-gather of the sizes, then
+ *                                           grouped ncclSend / ncclRecv of exactly the used bytes);
+ *   * limg_hip_encode3d_single_chain_device: ONE dither chain through all strips in rank order, i.e. the result of the reference run with
+ *                                           pThreadPool == nullptr (src/limg.cpp:1893, :2110): one 8-byte all-gather of the per-strip dither-call totals
+ *                                           between the E step (fit + search) and the F step (dither + stores) of every rank.
+ * RCCL is resolved at run time from the process (dlopen "librccl.so.1"): the library has no link-time dependency on it.  Failures map to
+ * limg_hip_error_Generic.  The communicator belongs to the context; the caller only transports the 128-byte id from rank 0 to the others. */
+#define LIMG_HIP_COMM_ID_BYTES 128
+limg_hip_result limg_hip_comm_unique_id(uint8_t *pId128);                                                  /* rank 0: ncclGetUniqueId */
+limg_hip_result limg_hip_comm_init(limg_hip_context *pCtx, const uint8_t *pId128, int rank, int worldSize); /* every rank: ncclCommInitRank on the context's device */
+limg_hip_result limg_hip_comm_destroy(limg_hip_context *pCtx);
+/* pStream / pGathered are DEVICE pointers.  On `root`, piece r lands at pGathered + pOffsets[r] (16-byte aligned, ready for limg_hip_decode_stream_device);
+ * pOffsets (host, worldSize + 1 entries) also receives the total.  Blocks until the sizes are known; the transfers are asynchronous on `stream`. */
+limg_hip_result limg_hip_gather_stream(limg_hip_context *pCtx, const uint8_t *pStream, size_t streamBytes, int root, uint8_t *pGathered, size_t capacity,
+                                       uint64_t *pOffsets, void *stream);
+/* This rank's strip of `stripRows` rows (whole 8x8 blocks: sizeX, stripRows multiples of 8) of a taller image whose strips go to the ranks in order;
+ * blocksBefore = number of 8x8 blocks in the strips of the ranks before this one (sizes the dither noise table).  DEVICE pointers, asynchronous. */
+limg_hip_result limg_hip_encode3d_single_chain_device(limg_hip_context *pCtx, const uint32_t *pIn, size_t sizeX, size_t stripRows, int hasAlpha,
+                                                      const limg_hip_encode3d_info *pInfo, uint32_t errorFactor, int fastBitCrushing, size_t blocksBefore, void *stream);
+/* The two halves of the above without the exchange, for callers that move the counts themselves (and for single-GPU tests of the chain arithmetic):
+ * phase 1 = E step + scan, writes this strip's dither-call total to *pCallsDevice; phase 2 = F step, its first dither call is *pChainBaseDevice.
+ * Phase 2 must follow phase 1 of the same strip on the same context with nothing in between (the context holds the strip's intermediate results). */
+limg_hip_result limg_hip_encode3d_chain_device(limg_hip_context *pCtx, const uint32_t *pIn, size_t sizeX, size_t stripRows, int hasAlpha, const limg_hip_encode3d_info *pInfo,
+                                               uint32_t errorFactor, int fastBitCrushing, int phase, uint64_t *pCallsDevice, const uint64_t *pChainBaseDevice,
+                                               size_t blocksBefore, void *stream);
+/* Host-only helpers (no GPU): the offset arithmetic of the gather (pOffsets: count + 1 entries) and the exclusive prefix of the call totals. */
+limg_hip_result limg_hip_host_gather_offsets(const uint64_t *pSizes, int count, uint64_t *pOffsets);
+limg_hip_result limg_hip_host_chain_bases(const uint64_t *pCalls, int count, uint64_t *pBases);
+
 /* Introspection for the bench: names and launch count of the kernels one encode enqueues, bytes of context-owned HBM. */
 size_t limg_hip_context_device_bytes(const limg_hip_context *pCtx);
 const char *limg_hip_version(void);

@@ -26,7 +26,10 @@ ABI_SYMBOLS = (
     "limg_hip_stream_info",
     "limg_hip_blocked_encode3d", "limg_hip_blocked_encode3d_device", "limg_hip_blocked_regions", "limg_hip_blocked_timing", "limg_hip_host_blocked_matches",
     "limg_hip_host_blocked_merge", "limg_hip_host_blocked_match_words", "limg_hip_host_blocked_match_bits",
+    "limg_hip_comm_unique_id", "limg_hip_comm_init", "limg_hip_comm_destroy", "limg_hip_gather_stream", "limg_hip_encode3d_single_chain_device",
+    "limg_hip_encode3d_chain_device", "limg_hip_host_gather_offsets", "limg_hip_host_chain_bases",
 )
+COMM_ID_BYTES = 128
 
 # limg_blocked_encode3d_info (src/limg.h:39-44), member order
 BLOCKED_PLANES = (("pDecoded", np.uint32), ("pFactorsA", np.uint8), ("pFactorsB", np.uint8), ("pFactorsC", np.uint8), ("pBlockError", np.uint8), ("pBitsPerPixel", np.uint8),
@@ -134,6 +137,23 @@ def load_library(path=None):
     L.limg_hip_decode_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     L.limg_hip_stream_info.restype = C.c_int
     L.limg_hip_stream_info.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
+    L.limg_hip_comm_unique_id.restype = C.c_int
+    L.limg_hip_comm_unique_id.argtypes = [C.c_void_p]
+    L.limg_hip_comm_init.restype = C.c_int
+    L.limg_hip_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.limg_hip_comm_destroy.restype = C.c_int
+    L.limg_hip_comm_destroy.argtypes = [C.c_void_p]
+    L.limg_hip_gather_stream.restype = C.c_int
+    L.limg_hip_gather_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.limg_hip_encode3d_single_chain_device.restype = C.c_int
+    L.limg_hip_encode3d_single_chain_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_size_t, C.c_void_p]
+    L.limg_hip_encode3d_chain_device.restype = C.c_int
+    L.limg_hip_encode3d_chain_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                 C.c_void_p]
+    L.limg_hip_host_gather_offsets.restype = C.c_int
+    L.limg_hip_host_gather_offsets.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.limg_hip_host_chain_bases.restype = C.c_int
+    L.limg_hip_host_chain_bases.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     return L
 
 
@@ -153,6 +173,24 @@ def stream_info(stream, lib=None):
     sx, sy, tb, ha = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_int(0)
     _check(lib.limg_hip_stream_info(_np_ptr(stream), stream.size, C.byref(sx), C.byref(sy), C.byref(ha), C.byref(tb)), "limg_hip_stream_info")
     return sx.value, sy.value, bool(ha.value), tb.value
+
+
+def host_gather_offsets(sizes, lib=None):
+    """Offsets (len + 1 entries, the last is the total) of the variable-size stream gather; host only."""
+    lib = lib or load_library()
+    sizes = np.ascontiguousarray(sizes, dtype=np.uint64)
+    out = np.zeros(sizes.size + 1, dtype=np.uint64)
+    _check(lib.limg_hip_host_gather_offsets(_np_ptr(sizes), sizes.size, _np_ptr(out)), "limg_hip_host_gather_offsets")
+    return out
+
+
+def host_chain_bases(calls, lib=None):
+    """Every rank's first dither-call index in a chain that runs through all strips in rank order; host only."""
+    lib = lib or load_library()
+    calls = np.ascontiguousarray(calls, dtype=np.uint64)
+    out = np.zeros(calls.size, dtype=np.uint64)
+    _check(lib.limg_hip_host_chain_bases(_np_ptr(calls), calls.size, _np_ptr(out)), "limg_hip_host_chain_bases")
+    return out
 
 
 def host_blocked_matches(channels, seed, cand, lib=None):
@@ -185,6 +223,7 @@ class LimgHip:
     def __init__(self, device=-1):
         self.lib = load_library()
         self.ctx = C.c_void_p()
+        self.comm_rank, self.comm_world = 0, 1
         _check(self.lib.limg_hip_init(device, C.byref(self.ctx)), "limg_hip_init")
 
     def close(self):
@@ -352,6 +391,55 @@ class LimgHip:
 
     def check(self):
         _check(self.lib.limg_hip_check_device_status(self.ctx), "limg_hip_check_device_status")
+
+    # ---- multi-GPU: RCCL behind the C ABI ---------------------------------------------------------------------------------------------
+    def comm_unique_id(self):
+        buf = np.zeros(COMM_ID_BYTES, dtype=np.uint8)
+        _check(self.lib.limg_hip_comm_unique_id(_np_ptr(buf)), "limg_hip_comm_unique_id")
+        return buf
+
+    def comm_init(self, comm_id, rank, world):
+        comm_id = np.ascontiguousarray(comm_id, dtype=np.uint8)
+        assert comm_id.size == COMM_ID_BYTES
+        _check(self.lib.limg_hip_comm_init(self.ctx, _np_ptr(comm_id), rank, world), "limg_hip_comm_init")
+        self.comm_rank, self.comm_world = rank, world
+
+    def comm_init_from_torch(self, dist):
+        """Create the context's RCCL communicator inside a torch.distributed job: rank 0 makes the id, the process group only carries its 128 bytes."""
+        import torch
+        rank, world = dist.get_rank(), dist.get_world_size()
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.from_numpy(self.comm_unique_id() if rank == 0 else np.zeros(COMM_ID_BYTES, dtype=np.uint8)).to(dev)
+        dist.broadcast(t, src=0)
+        self.comm_init(t.cpu().numpy(), rank, world)
+
+    def comm_destroy(self):
+        _check(self.lib.limg_hip_comm_destroy(self.ctx), "limg_hip_comm_destroy")
+
+    def gather_stream(self, stream, nbytes, root=0, out=None):
+        """stream: torch uint8 CUDA tensor holding this rank's LMG3 stream.  On root returns (gathered CUDA tensor, offsets[world + 1]); None elsewhere."""
+        import torch
+        world = self.comm_world
+        offs = np.zeros(world + 1, dtype=np.uint64)
+        if self.comm_rank == root and out is None:
+            raise ValueError("root needs an output buffer (worst case: the sum of the ranks' stream bounds)")
+        _check(self.lib.limg_hip_gather_stream(self.ctx, C.c_void_p(stream.data_ptr()), int(nbytes), root, C.c_void_p(out.data_ptr()) if out is not None else None,
+                                               out.numel() if out is not None else 0, _np_ptr(offs), self._stream()), "limg_hip_gather_stream")
+        return (out, offs) if self.comm_rank == root else None
+
+    def encode3d_single_chain_device(self, strip, has_alpha, planes, blocks_before, error_factor=100, fast=True):
+        h, w = strip.shape
+        info = Info(*[planes[k].data_ptr() for k in PLANES])
+        _check(self.lib.limg_hip_encode3d_single_chain_device(self.ctx, C.c_void_p(strip.data_ptr()), w, h, int(has_alpha), C.byref(info), error_factor, int(fast),
+                                                              int(blocks_before), self._stream()), "limg_hip_encode3d_single_chain_device")
+
+    def encode3d_chain_device(self, strip, has_alpha, planes, phase, calls=None, base=None, blocks_before=0, error_factor=100, fast=True):
+        """phase 1: E step + scan, `calls` (torch int64 CUDA, 1 element) receives the strip's dither-call total; phase 2: F step from `base` (same kind of tensor)."""
+        h, w = strip.shape
+        info = Info(*[planes[k].data_ptr() for k in PLANES])
+        _check(self.lib.limg_hip_encode3d_chain_device(self.ctx, C.c_void_p(strip.data_ptr()), w, h, int(has_alpha), C.byref(info), error_factor, int(fast), phase,
+                                                       C.c_void_p(calls.data_ptr()) if calls is not None else None, C.c_void_p(base.data_ptr()) if base is not None else None,
+                                                       int(blocks_before), self._stream()), "limg_hip_encode3d_chain_device")
 
     def profile_begin(self):
         _check(self.lib.limg_hip_profile_begin(self.ctx), "limg_hip_profile_begin")

@@ -1,6 +1,7 @@
 // limg_hip_api.hip -- host side of liblimg_hip.so: context, buffers, launch sequencing, the C ABI of include/limg_hip.h.
 // Mirrors the reference's driver (src/limg.cpp:2175-2265 threshold/flag setup, :2105-2138 strip partition).
 #include "limg_hip_internal.h"
+#include "limg_hip_rccl.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -92,6 +93,10 @@ struct limg_hip_context
   std::vector<hipEvent_t> bandEvents;
   std::vector<HostRegion> lastRegions;
   double blockedMs[6] = { 0, 0, 0, 0, 0, 0 };
+  // multi-GPU (RCCL over xGMI): one communicator per context, created by limg_hip_comm_init
+  ncclComm_t comm = nullptr;
+  int commRank = 0, commWorld = 1;
+  DevBuf commWords; // [0] this rank's value, [1] its chain base, [8 ...] the all-gathered values
   DevBuf streamFac, streamTiles, streamStatus, streamBuf; // stream packer: 3 factor planes, per-tile payload words; decode status word; host-entry staging
   // optional per-kernel timing (bench): 4 events per encode, recorded on the caller's stream, read back in one go
   int persistentWorkgroups = 1280; // 5 per CU (LDS- and VGPR-limited), set from the device's CU count at init
@@ -165,8 +170,10 @@ namespace
   }
 
   limg_hip_result encode_device(limg_hip_context *c, const uint32_t *dIn, size_t sizeX, size_t sizeY, int hasAlpha, const limg_hip_encode3d_info *dInfo,
-                                const limg_hip_compact_out *compact, uint32_t errorFactor, int poolThreads, int fast, hipStream_t stream, bool streamRaw = false, bool fitOnly = false)
+                                const limg_hip_compact_out *compact, uint32_t errorFactor, int poolThreads, int fast, hipStream_t stream, bool streamRaw = false, bool fitOnly = false,
+                                int chainPhase = 0, unsigned long long *dChainCalls = nullptr, const unsigned long long *dChainBase = nullptr, size_t chainBlocksBefore = 0)
   {
+    // chainPhase: 0 = whole encode; 1 = E step + scan only (writes *dChainCalls); 2 = F step only (reads *dChainBase).  1 and 2 always take the split path.
     if (!c || !dIn) return limg_hip_error_ArgumentNull;
     if (sizeX == 0 || sizeY == 0 || sizeX > 0x7FFFFFF8ull || sizeY > 0x7FFFFFF8ull) return limg_hip_error_InvalidParameter;
     bool fullPlanes = true;
@@ -230,11 +237,14 @@ namespace
       // longest chain, in blocks: every block makes at most 3 dither calls
       uint32_t maxRows = p.blocksY;
       if (pt.chainCount > 1) maxRows = p.blocksY - (pt.chainCount - 1) * pt.chainRows; // the last chain takes the remainder, never fewer rows than the others
-      if ((r = grow_noise_table(c, (size_t)maxRows * p.blocksX * 3, stream)) != limg_hip_success) return r;
+      if ((r = grow_noise_table(c, ((size_t)maxRows * p.blocksX + chainBlocksBefore) * 3, stream)) != limg_hip_success) return r;
       p.noise = (const uint8_t *)c->noise.p;
     }
 
-    const bool fused = dInfo != nullptr && !ragged && !c->forceSplit;
+    if (chainPhase != 0 && (ragged || !dInfo || poolThreads != 0)) return limg_hip_error_InvalidParameter; // a chain shared between GPUs: whole 8x8 blocks, one chain
+    p.chainCallsOut = chainPhase == 1 ? dChainCalls : nullptr;
+    p.chainBase = chainPhase == 2 ? dChainBase : nullptr;
+    const bool fused = dInfo != nullptr && !ragged && !c->forceSplit && chainPhase == 0;
     if (fused)
     {
       // one launch does everything: zero the look-back words, go
@@ -258,6 +268,12 @@ namespace
       return limg_hip_success;
     }
 
+    if (chainPhase == 2)
+    { // the E step and the scan of this very image ran in phase 1: records, shift words, strip bases and the pre-dither factor bytes are where they left them
+      launch_dither_store(p, channels, stream);
+      HIP_TRY(hipGetLastError());
+      return limg_hip_success;
+    }
     mark(c, stream);
     launch_fit_search(p, channels, stream);
     mark(c, stream);
@@ -271,6 +287,11 @@ namespace
     if (!ragged)
     {
       launch_strip_scan(p, stream);
+      if (chainPhase == 1)
+      {
+        HIP_TRY(hipGetLastError());
+        return limg_hip_success;
+      }
     }
     else
     {
@@ -350,12 +371,13 @@ extern "C"
     limg_hip_context *c = *ppCtx;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = { &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->lookback, &c->devStatus, &c->park, &c->in, &c->planes, &c->cmp,
+    DevBuf *bufs[] = { &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->lookback, &c->devStatus, &c->commWords, &c->park, &c->in, &c->planes, &c->cmp,
                        &c->streamFac, &c->streamTiles, &c->streamStatus, &c->streamBuf,
                        &c->bFlags, &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bV, &c->bFac, &c->bNoise, &c->bNoiseBase };
     for (DevBuf *b : bufs) b->release();
     HostBuf *hbufs[] = { &c->hFlags, &c->hRec, &c->hBits, &c->hDesc, &c->hOut, &c->hNoise, &c->hNoiseBase };
     for (HostBuf *b : hbufs) b->release();
+    if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
     if (c->workStream) (void)hipStreamDestroy(c->workStream);
     for (hipEvent_t e : c->workEvent) if (e) (void)hipEventDestroy(e);
     if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
@@ -466,6 +488,16 @@ extern "C"
                                            const limg_hip_compact_out *pCompact, uint32_t errorFactor, int poolThreads, int fastBitCrushing, void *stream)
   {
     return encode_device(c, pIn, sizeX, sizeY, hasAlpha, pInfo, pCompact, errorFactor, poolThreads, fastBitCrushing, (hipStream_t)stream);
+  }
+
+  limg_hip_result limg_hip_encode3d_chain_device(limg_hip_context *c, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, const limg_hip_encode3d_info *pInfo,
+                                                 uint32_t errorFactor, int fastBitCrushing, int phase, uint64_t *pCallsDevice, const uint64_t *pChainBaseDevice,
+                                                 size_t blocksBefore, void *stream)
+  {
+    if (phase != 1 && phase != 2) return limg_hip_error_InvalidParameter;
+    if ((phase == 1 && !pCallsDevice) || (phase == 2 && !pChainBaseDevice) || !pInfo) return limg_hip_error_ArgumentNull;
+    return encode_device(c, pIn, sizeX, sizeY, hasAlpha, pInfo, nullptr, errorFactor, 0, fastBitCrushing, (hipStream_t)stream, false, false, phase,
+                         (unsigned long long *)pCallsDevice, (const unsigned long long *)pChainBaseDevice, blocksBefore);
   }
 
   limg_hip_result limg_hip_encode3d(limg_hip_context *c, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, limg_hip_encode3d_info *pInfo, uint32_t errorFactor,
@@ -1028,5 +1060,141 @@ extern "C"
     if ((r = limg_hip_check_device_status(c)) != limg_hip_success) return r;
     for (int i = 0; i < 13; i++) HIP_TRY(hipMemcpy(*hostp[i], *devp[i], is8[i] ? px : px * 4, hipMemcpyDeviceToHost));
     return limg_hip_success;
+  }
+
+  // ---- multi-GPU: RCCL behind the C ABI ----------------------------------------------------------------------
+#define NCCL_TRY(expr)                                                                                                    \
+  do                                                                                                                      \
+  {                                                                                                                       \
+    const ncclResult_t e_ = (expr);                                                                                       \
+    if (e_ != ncclSuccess)                                                                                                \
+    {                                                                                                                     \
+      fprintf(stderr, "limg_hip: %s failed: %s (%s:%d)\n", #expr, rccl().GetErrorString(e_), __FILE__, __LINE__);        \
+      return limg_hip_error_Generic;                                                                                      \
+    }                                                                                                                     \
+  } while (0)
+
+  limg_hip_result limg_hip_comm_unique_id(uint8_t *pId)
+  {
+    if (!pId) return limg_hip_error_ArgumentNull;
+    static_assert(sizeof(ncclUniqueId) == LIMG_HIP_COMM_ID_BYTES, "ncclUniqueId size");
+    if (!rccl().ok) return limg_hip_error_Generic;
+    ncclUniqueId id;
+    NCCL_TRY(rccl().GetUniqueId(&id));
+    memcpy(pId, &id, sizeof(id));
+    return limg_hip_success;
+  }
+
+  limg_hip_result limg_hip_comm_init(limg_hip_context *c, const uint8_t *pId, int rank, int worldSize)
+  {
+    if (!c || !pId) return limg_hip_error_ArgumentNull;
+    if (worldSize < 1 || rank < 0 || rank >= worldSize || c->comm) return limg_hip_error_InvalidParameter;
+    if (!rccl().ok) return limg_hip_error_Generic;
+    HIP_TRY(hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(&id, pId, sizeof(id));
+    NCCL_TRY(rccl().CommInitRank(&c->comm, worldSize, id, rank));
+    c->commRank = rank; c->commWorld = worldSize;
+    const limg_hip_result r = c->commWords.ensure((8 + (size_t)worldSize) * 8);
+    if (r != limg_hip_success) return r;
+    HIP_TRY(hipMemset(c->commWords.p, 0, (8 + (size_t)worldSize) * 8));
+    return limg_hip_success;
+  }
+
+  limg_hip_result limg_hip_comm_destroy(limg_hip_context *c)
+  {
+    if (!c) return limg_hip_error_ArgumentNull;
+    if (c->comm)
+    {
+      HIP_TRY(hipSetDevice(c->device));
+      HIP_TRY(hipDeviceSynchronize());
+      NCCL_TRY(rccl().CommDestroy(c->comm));
+      c->comm = nullptr; c->commRank = 0; c->commWorld = 1;
+    }
+    return limg_hip_success;
+  }
+
+  // Offsets of a variable-size gather: piece r starts at the sum of the earlier sizes, each rounded up to 16 bytes (the decoder wants 16-byte aligned streams).
+  limg_hip_result limg_hip_host_gather_offsets(const uint64_t *pSizes, int count, uint64_t *pOffsets)
+  {
+    if (!pSizes || !pOffsets) return limg_hip_error_ArgumentNull;
+    if (count < 1) return limg_hip_error_InvalidParameter;
+    uint64_t off = 0;
+    for (int r = 0; r < count; r++)
+    {
+      pOffsets[r] = off;
+      off += (pSizes[r] + 15ull) & ~15ull;
+    }
+    pOffsets[count] = off;
+    return limg_hip_success;
+  }
+
+  // Exclusive prefix of the per-rank dither-call totals = every rank's first call index in the one chain that runs through all strips (rank order = strip order).
+  limg_hip_result limg_hip_host_chain_bases(const uint64_t *pCalls, int count, uint64_t *pBases)
+  {
+    if (!pCalls || !pBases) return limg_hip_error_ArgumentNull;
+    if (count < 1) return limg_hip_error_InvalidParameter;
+    uint64_t run = 0;
+    for (int r = 0; r < count; r++) { pBases[r] = run; run += pCalls[r]; }
+    return limg_hip_success;
+  }
+
+  limg_hip_result limg_hip_gather_stream(limg_hip_context *c, const uint8_t *pStream, size_t streamBytes, int root, uint8_t *pGathered, size_t capacity, uint64_t *pOffsets,
+                                         void *stream)
+  {
+    if (!c || !pStream) return limg_hip_error_ArgumentNull;
+    if (!c->comm) return limg_hip_error_InvalidParameter;
+    if (root < 0 || root >= c->commWorld) return limg_hip_error_InvalidParameter;
+    const bool isRoot = c->commRank == root;
+    if (isRoot && (!pGathered || !pOffsets)) return limg_hip_error_ArgumentNull;
+    if (isRoot && ((uintptr_t)pGathered & 15u) != 0) return limg_hip_error_InvalidParameter;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int world = c->commWorld;
+    unsigned long long *words = (unsigned long long *)c->commWords.p;
+    // 1. every rank learns every size: one 8-byte all-gather
+    const unsigned long long mine = streamBytes;
+    HIP_TRY(hipMemcpyAsync(words, &mine, 8, hipMemcpyHostToDevice, s));
+    NCCL_TRY(rccl().AllGather(words, words + 8, 1, ncclUint64, c->comm, s));
+    std::vector<uint64_t> sizes(world), offs(world + 1);
+    HIP_TRY(hipMemcpyAsync(sizes.data(), words + 8, (size_t)world * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    limg_hip_host_gather_offsets(sizes.data(), world, offs.data());
+    if (isRoot && offs[world] > capacity) return limg_hip_error_OutOfBounds; // every rank sees the same sizes: the peers would send into nothing
+    // 2. exactly the used bytes, point to point: each peer -> root transfer rides one xGMI link
+    NCCL_TRY(rccl().GroupStart());
+    if (isRoot)
+    {
+      for (int r = 0; r < world; r++)
+        if (r != root && sizes[r]) NCCL_TRY(rccl().Recv(pGathered + offs[r], sizes[r], ncclUint8, r, c->comm, s));
+    }
+    else if (streamBytes)
+      NCCL_TRY(rccl().Send(pStream, streamBytes, ncclUint8, root, c->comm, s));
+    NCCL_TRY(rccl().GroupEnd());
+    if (isRoot)
+    {
+      if (streamBytes) HIP_TRY(hipMemcpyAsync(pGathered + offs[root], pStream, streamBytes, hipMemcpyDeviceToDevice, s));
+      memcpy(pOffsets, offs.data(), (size_t)(world + 1) * 8);
+      for (int r = 0; r < world; r++) pOffsets[r] = offs[r];
+    }
+    return limg_hip_success;
+  }
+
+  limg_hip_result limg_hip_encode3d_single_chain_device(limg_hip_context *c, const uint32_t *pIn, size_t sizeX, size_t stripRows, int hasAlpha, const limg_hip_encode3d_info *pInfo,
+                                                        uint32_t errorFactor, int fastBitCrushing, size_t blocksBefore, void *stream)
+  {
+    if (!c || !pIn || !pInfo) return limg_hip_error_ArgumentNull;
+    if (!c->comm) return limg_hip_error_InvalidParameter;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long *words = (unsigned long long *)c->commWords.p;
+    limg_hip_result r;
+    // E step + scan: this strip's dither calls land in words[0] ...
+    if ((r = limg_hip_encode3d_chain_device(c, pIn, sizeX, stripRows, hasAlpha, pInfo, errorFactor, fastBitCrushing, 1, (uint64_t *)words, nullptr, blocksBefore, s)) != limg_hip_success) return r;
+    // ... one 8-byte all-gather, the exclusive prefix over the ranks before this one on the device (stream-ordered, no host round trip) ...
+    NCCL_TRY(rccl().AllGather(words, words + 8, 1, ncclUint64, c->comm, s));
+    launch_chain_base(words + 8, c->commRank, words + 1, s);
+    // ... and the F step indexes the noise stream from there: the 8-GPU result equals the single-threaded reference's (src/limg.cpp:1893, :2110)
+    return limg_hip_encode3d_chain_device(c, pIn, sizeX, stripRows, hasAlpha, pInfo, errorFactor, fastBitCrushing, 2, nullptr, (const uint64_t *)(words + 1), blocksBefore, s);
   }
 }

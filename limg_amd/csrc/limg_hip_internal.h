@@ -47,6 +47,9 @@ namespace limg_hip
     int32_t compactOut; // persistent kernel: also write records / shift words to the raster-order arrays
     int32_t streamRaw;  // compact mode only: factors with shift 8 store their raw byte instead of 0 (input of the stream packer)
     int32_t fitOnly;    // split path: stop after the records (pass 1 of the merged-block encoder, src/limg.cpp:1088-1119)
+    // cross-GPU single dither chain (split path only): the scan writes this image strip's dither-call total; the F step adds the strip's first call index
+    unsigned long long *chainCallsOut;
+    const unsigned long long *chainBase;
     int32_t floatFast;  // host dispatch only: FAST float stage (limg_hip_options.float_mode = 1)
     int32_t vecIn;      // rows of pIn may be read 16 bytes per lane (sizeX % 4 == 0 and pIn 16-byte aligned); otherwise dword loads
     int32_t vecFactors; // the three factor planes may be accessed 16 bytes per lane (sizeX % 16 == 0 and all three 16-byte aligned)
@@ -76,6 +79,7 @@ namespace limg_hip
   void launch_encode_persistent(const EncodeParams &p, int channels, int workgroups, hipStream_t s);
   void launch_strip_scan(const EncodeParams &p, hipStream_t s);
   void launch_dither_store(const EncodeParams &p, int channels, hipStream_t s);
+  void launch_chain_base(const unsigned long long *dCalls, int rank, unsigned long long *dBase, hipStream_t s);
 
   // ---- merged-block encoder (limg_hip_blocked.hip; reference: limg_blocked_encode3d_test, src/limg.cpp:1774-1885, :2329-2453) ----
   // similarity bits are precomputed for candidate offsets dx, dy in [-kMatchLo, +kMatchHi] blocks around every seed: rectangles grow right / down from

@@ -1089,6 +1089,8 @@ namespace limg_hip
         p.stripBase[e] = run;
         run += p.stripCalls[e];
       }
+      // cross-GPU single chain (limg_hip_encode3d_chain_device): the dither calls of this whole image strip, for the exchange between the E and the F step
+      if (p.chainCallsOut && end == total && begin < end) *p.chainCallsOut = run;
     }
 
     // =====================================================================================================================
@@ -1174,7 +1176,10 @@ namespace limg_hip
           }
         }
         else
+        {
           base = p.stripBase[id];
+          if (p.chainBase) base += (uint32_t)*p.chainBase; // first dither call of this image strip inside a chain that started on another GPU
+        }
         phase_f_first_calls(L, base, lane);
       }
       __syncthreads();
@@ -1262,6 +1267,18 @@ namespace limg_hip
     else if (channels == 4) hipLaunchKernelGGL((k_encode_persistent<4, false>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((k_encode_persistent<3, false>), grid, block, 0, s, p);
   }
+
+  namespace
+  {
+    // exclusive prefix over the ranks before `rank` of the all-gathered per-rank dither-call totals
+    __global__ void k_chain_base(const unsigned long long *calls, int rank, unsigned long long *base)
+    {
+      unsigned long long run = 0;
+      for (int r = 0; r < rank; r++) run += calls[r];
+      *base = run;
+    }
+  }
+  void launch_chain_base(const unsigned long long *dCalls, int rank, unsigned long long *dBase, hipStream_t s) { hipLaunchKernelGGL(k_chain_base, dim3(1), dim3(1), 0, s, dCalls, rank, dBase); }
 
   void launch_strip_scan(const EncodeParams &p, hipStream_t s) { hipLaunchKernelGGL(k_strip_scan, dim3(1), dim3(1024), 0, s, p); }
 

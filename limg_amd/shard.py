@@ -5,11 +5,14 @@ over xGMI on the GPU node, "gloo" in the CPU tests).  Blocks are independent exc
   * one big image (BASELINE configs[4]):     `world` contiguous strips of whole block rows with the reference's own
     strip rule (src/limg.cpp:2114-2134 with thread_count == world, i.e. a pool of world/4 threads when world % 4 == 0):
     every rank restarts the dither chain at the seed, exactly like the reference's strips -- again no exchange.
-  * the only collective is the optional reassembly of the planes on rank 0 (`gather_planes`): one variable-size gather
-    per plane; on xGMI each peer->root transfer rides one link, so this is reported separately from the encode.
+  * the only collective is the optional reassembly on rank 0; on xGMI each peer->root transfer rides one link, so it is reported
+    separately from the encode.  The product path for it is the C ABI (`limg_hip_gather_stream`: RCCL behind liblimg_hip.so, only the
+    compact streams cross the links) -- `gather_streams` below is a thin caller of it; on a gloo group (CPU tests, one-card rehearsals)
+    the same offsets (`limg_hip_host_gather_offsets`) are filled by torch point-to-point transfers instead.
+  * one chain through all strips (== the reference with pThreadPool == nullptr) is `limg_hip_encode3d_single_chain_device`
+    (`LimgHip.encode3d_single_chain_device`): an 8-byte all-gather between the E and the F step, also inside the library.
 
-The encoder itself is passed in as a callable (the HIP path on the GPU box, the CPU oracle in the gloo tests), so the
-sharding logic is identical in both."""
+`gather_planes` (the 35 B/px reassembly) stays a torch.distributed helper: it is a rehearsal / comparison path, not what the north-star ships."""
 import numpy as np
 
 PLANES32 = ("pDecoded", "pShiftABCX", "pColAMin", "pColAMax", "pColBMin", "pColBMax", "pColCMin", "pColCMax")
@@ -40,9 +43,41 @@ def batch_assignment(n_images, world, rank):
     return [i for i in range(n_images) if i % world == rank]
 
 
-def encode_strip_sharded(encode, img_strip, has_alpha, **kw):
-    """Every rank encodes its own strip with a fresh dither chain (pool_threads = 0 on the strip)."""
-    return encode(img_strip, has_alpha, **kw)
+def gather_streams(g, stream, nbytes, dist, dst=0, out=None):
+    """Variable-size gather of every rank's LMG3 stream on rank `dst`.  Returns (buffer, offsets[world + 1]) on `dst` (piece r = buffer[offsets[r] : offsets[r] + size_r],
+    16-byte aligned, ready for decode_stream_device), None elsewhere.  RCCL group: the C ABI does all of it (the context's own communicator, created on first
+    use from 128 bytes broadcast over `dist`); gloo group: same layout, torch point-to-point."""
+    import torch
+    from . import host_gather_offsets
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if dist.get_backend() == "nccl":
+        if getattr(g, "comm_world", 1) != world or not getattr(g, "_comm_ready", False):
+            g.comm_init_from_torch(dist)
+            g._comm_ready = True
+        return g.gather_stream(stream, nbytes, root=dst, out=out)
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([int(nbytes)], dtype=torch.int64))
+    sizes = np.array([int(t.item()) for t in sizes], dtype=np.uint64)
+    offs = host_gather_offsets(sizes)
+    mine = stream[:int(nbytes)].cpu().contiguous()
+    if rank != dst:
+        if nbytes:
+            dist.send(mine, dst=dst)
+        return None
+    buf = torch.zeros(int(offs[world]), dtype=torch.uint8)
+    reqs = []
+    for r in range(world):
+        piece = buf[int(offs[r]): int(offs[r]) + int(sizes[r])]
+        if r == dst:
+            piece.copy_(mine)
+        elif sizes[r]:
+            reqs.append(dist.irecv(piece, src=r))
+    for q in reqs:
+        q.wait()
+    if out is not None:
+        out[:buf.numel()].copy_(buf)
+        buf = out
+    return buf, offs
 
 
 def gather_planes(planes, rows, width, dist, dst=0):
@@ -66,22 +101,3 @@ def gather_planes(planes, rows, width, dist, dst=0):
         else:
             dist.send(t.contiguous(), dst=dst)
     return out if rank == dst else None
-
-
-def gather_bytes(buf, nbytes, dist, dst=0):
-    """Variable-size gather of one byte tensor per rank (the compact LMG3 stream of a rank's strip / image) to rank `dst`: sizes first
-    (one all_gather of an int64 per rank), then grouped point-to-point transfers of exactly the used bytes.  Returns the list of tensors on `dst`."""
-    import torch
-    world, rank = dist.get_world_size(), dist.get_rank()
-    dev = buf.device
-    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([int(nbytes)], dtype=torch.int64, device=dev))
-    sizes = [int(t.item()) for t in sizes]
-    if rank == dst:
-        parts = [buf[:sizes[r]] if r == dst else torch.empty(sizes[r], dtype=torch.uint8, device=dev) for r in range(world)]
-        reqs = [dist.irecv(parts[r], src=r) for r in range(world) if r != dst]
-        for q in reqs:
-            q.wait()
-        return parts
-    dist.send(buf[:sizes[rank]].contiguous(), dst=dst)
-    return None

@@ -89,22 +89,26 @@ def _bytes_worker(rank, world, port, tmp):
     n = 1000 + 37 * rank                       # every rank's stream has its own size
     buf = torch.zeros(4096, dtype=torch.uint8)  # worst-case buffer, only the first n bytes are meaningful
     buf[:n] = torch.arange(n, dtype=torch.int64).remainder(251).to(torch.uint8) + rank
-    parts = shard.gather_bytes(buf, n, dist, dst=0)
+    res = shard.gather_streams(None, buf, n, dist, dst=0)   # gloo group: same piece layout as limg_hip_gather_stream (limg_hip_host_gather_offsets), torch transfers
     if rank == 0:
-        assert len(parts) == world
+        got, offs = res
+        assert len(offs) == world + 1 and int(offs[0]) == 0
         for r in range(world):
-            want = (torch.arange(1000 + 37 * r, dtype=torch.int64).remainder(251).to(torch.uint8) + r)
-            assert parts[r].numel() == 1000 + 37 * r and torch.equal(parts[r], want), r
+            size = 1000 + 37 * r
+            want = (torch.arange(size, dtype=torch.int64).remainder(251).to(torch.uint8) + r)
+            assert int(offs[r]) % 16 == 0 and int(offs[r + 1]) - int(offs[r]) == (size + 15) // 16 * 16
+            assert torch.equal(got[int(offs[r]): int(offs[r]) + size], want), r
         open(os.path.join(tmp, "ok"), "w").write("1")
     else:
-        assert parts is None
+        assert res is None
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_variable_size_stream_gather(tmp_path, world):
-    """What config 5's `--gather-stream` does between the ranks: only the used bytes of every rank's compact stream travel to rank 0."""
+    """What config 5's `--gather-stream` does between the ranks: only the used bytes of every rank's compact stream travel to rank 0, each piece to a
+    16-byte aligned offset.  On the GPU node the same call goes through limg_hip_gather_stream (RCCL behind the C ABI)."""
     port = _free_port()
     mp.spawn(_bytes_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert os.path.exists(os.path.join(str(tmp_path), "ok"))

@@ -1,0 +1,105 @@
+"""Multi-GPU entries of the C ABI (include/limg_hip.h "multi-GPU") on ONE GPU: everything but the wire.
+  * the cross-GPU single dither chain (== the reference with pThreadPool == nullptr, src/limg.cpp:1893,2110) through its two exchange-free halves
+    `limg_hip_encode3d_chain_device`: four contexts play four ranks, the per-strip call totals are prefix-summed on the host exactly as the all-gather +
+    k_chain_base would, and the assembled planes must equal the single-chain encode of the whole image;
+  * a world-size-1 RCCL communicator (the real library, resolved at run time): `limg_hip_gather_stream` as a self-gather and
+    `limg_hip_encode3d_single_chain_device` == the plain encode.
+RCCL with more than one rank needs more than one GPU: unmeasured here (the driver's 8-GPU node runs bench.py --config 5 --single-chain)."""
+import numpy as np
+import pytest
+
+from oracle.bind import PLANES
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(planes):
+    import torch
+    return {k: v.cpu().numpy().view(np.uint32 if v.dtype == torch.int32 else np.uint8) for k, v in planes.items()}
+
+
+@pytest.mark.parametrize("kind,alpha,ranks", [("pn", True, 4), ("rg", True, 2), ("pn", False, 8)])
+def test_single_chain_across_emulated_ranks(oracle, kind, alpha, ranks):
+    import torch
+    import limg_amd
+    from limg_amd import shard
+    W, H = 512, 256
+    img = oracle.photo_noise(W, H, 21) if kind == "pn" else oracle.random_gradient(W, H, 21, True)
+    want = oracle.encode3d(img, alpha)  # pool_threads = 0: ONE chain over the whole image
+    d_img = torch.from_numpy(img.view(np.int32)).cuda()
+    rows = shard.strip_rows(H, ranks)
+    ctxs = [limg_amd.LimgHip(0) for _ in range(ranks)]
+    try:
+        planes = [c.alloc_planes_device(W, y1 - y0) for c, (y0, y1) in zip(ctxs, rows)]
+        calls = torch.zeros(ranks, dtype=torch.int64, device="cuda")
+        before = [(y0 // 8) * (W // 8) for (y0, _) in rows]
+        for r, (c, (y0, y1)) in enumerate(zip(ctxs, rows)):  # E step + scan on every "rank"
+            c.encode3d_chain_device(d_img[y0:y1], alpha, planes[r], 1, calls=calls[r:r + 1], blocks_before=before[r])
+        torch.cuda.synchronize()
+        bases = limg_amd.host_chain_bases(calls.cpu().numpy().astype(np.uint64))  # what all-gather + k_chain_base compute on the device
+        assert int(bases[0]) == 0 and all(int(bases[r + 1]) - int(bases[r]) == int(calls[r]) for r in range(ranks - 1))
+        d_bases = torch.from_numpy(bases.astype(np.int64)).cuda()
+        for r, (c, (y0, y1)) in enumerate(zip(ctxs, rows)):  # F step from the exchanged chain position
+            c.encode3d_chain_device(d_img[y0:y1], alpha, planes[r], 2, base=d_bases[r:r + 1], blocks_before=before[r])
+        torch.cuda.synchronize()
+        for r, (y0, y1) in enumerate(rows):
+            got = _np(planes[r])
+            for k in PLANES:
+                assert np.array_equal(got[k], want[k][y0:y1]), (r, k)
+        # and the contexts are still good for ordinary encodes afterwards
+        g = ctxs[0].encode3d(img, alpha)
+        for k in PLANES:
+            assert np.array_equal(g[k], want[k]), k
+    finally:
+        for c in ctxs:
+            c.check()
+            c.close()
+
+
+def test_chain_entry_refuses_what_it_cannot_chain(oracle):
+    import torch
+    import limg_amd
+    g = limg_amd.LimgHip(0)
+    try:
+        img = torch.zeros((20, 30), dtype=torch.int32, device="cuda")  # partial edge blocks: the chain position is not a table index
+        planes = g.alloc_planes_device(30, 20)
+        calls = torch.zeros(1, dtype=torch.int64, device="cuda")
+        with pytest.raises(limg_amd.LimgHipError):
+            g.encode3d_chain_device(img, True, planes, 1, calls=calls)
+        with pytest.raises(limg_amd.LimgHipError):
+            g.encode3d_single_chain_device(torch.zeros((64, 64), dtype=torch.int32, device="cuda"), True, g.alloc_planes_device(64, 64), 0)  # no communicator yet
+    finally:
+        g.close()
+
+
+def test_rccl_world_of_one(oracle):
+    """The real RCCL through the C ABI with a communicator of one rank: id, init, the gather (degenerates to the local copy after the size all-gather),
+    the single-chain encode (its all-gather is a copy), destroy.  Checks the dlopen path, the argument plumbing and the stream ordering."""
+    import torch
+    import limg_amd
+    g = limg_amd.LimgHip(0)
+    try:
+        g.comm_init(g.comm_unique_id(), 0, 1)
+        W, H = 512, 128
+        img = oracle.photo_noise(W, H, 31)
+        want = oracle.encode3d(img, True)
+        d_img = torch.from_numpy(img.view(np.int32)).cuda()
+        st, n = g.encode_stream_device(d_img, True)
+        out = torch.zeros(g.stream_bound(W, H) + 64, dtype=torch.uint8, device="cuda")
+        got, offs = g.gather_stream(st, n, root=0, out=out)
+        torch.cuda.synchronize()
+        assert int(offs[0]) == 0 and int(offs[1]) == (n + 15) // 16 * 16
+        assert torch.equal(got[:n], st[:n])
+        dec = g.decode_stream_device(got, n, W, H)
+        torch.cuda.synchronize()
+        assert np.array_equal(dec.cpu().numpy().view(np.uint32), want["pDecoded"])
+        planes = g.alloc_planes_device(W, H)
+        g.encode3d_single_chain_device(d_img, True, planes, 0)
+        torch.cuda.synchronize()
+        got = _np(planes)
+        for k in PLANES:
+            assert np.array_equal(got[k], want[k]), k
+        g.comm_destroy()
+        g.check()
+    finally:
+        g.close()

@@ -220,3 +220,16 @@ def test_host_blocked_merge_equals_oracle(oracle, use_bits):
         assert len(got) == len(want["regions"])
         for f in ("ox", "oy", "rx", "ry"):
             assert np.array_equal(got[f], want["regions"][f]), f
+
+
+def test_gather_offsets_and_chain_bases():
+    """Host arithmetic of the multi-GPU entries (include/limg_hip.h "multi-GPU"): 16-byte aligned piece offsets of the variable-size stream gather and
+    the exclusive prefix of the per-rank dither-call totals."""
+    import limg_amd
+    sizes = np.array([100, 0, 16, 4097, 1, 123456789012], dtype=np.uint64)
+    offs = limg_amd.host_gather_offsets(sizes)
+    assert offs.tolist() == [0, 112, 112, 128, 4240, 4256, 4256 + 123456789024]
+    assert all(int(o) % 16 == 0 for o in offs)
+    calls = np.array([5, 0, 7, 2 ** 40, 1], dtype=np.uint64)
+    assert limg_amd.host_chain_bases(calls).tolist() == [0, 5, 5, 12, 12 + 2 ** 40]
+    assert limg_amd.host_gather_offsets(np.array([33], dtype=np.uint64)).tolist() == [0, 48]
