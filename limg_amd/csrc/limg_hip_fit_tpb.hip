@@ -1,0 +1,254 @@
+// limg_hip_fit_tpb.hip -- the float stage (a4-a6: channel sums, 3/4-pass direction fit, extrema, record) with ONE LANE PER 8x8 BLOCK.
+//
+// reference: limg_encode_sum_to_decomposition_state src/limg.cpp:466-497, limg_encode_get_block_factors_accurate_from_state_3d_{3,4}
+// src/limg_factorization.h:382-576 / :578-794, record rounding :764-790.
+//
+// Why a second mapping.  With lane == pixel (limg_hip_kernels.hip) every per-block quantity of the fit is a wave reduction: two channel sums, six extrema and --
+// the expensive one, because the reference accumulates in pixel order -- three direction sums that have to be parked in LDS and walked by 16 lanes.  The float
+// stage is a chain of four passes whose per-pixel arithmetic is tiny next to that bookkeeping (~510 of the kernel's ~1060 VALU instructions per block).  With
+// lane == block the same per-pixel arithmetic is issued once per pixel for 64 blocks (identical cost per block), and every reduction disappears: a direction sum
+// is four plain `v_add_f32` per pixel in the natural loop order (which IS the reference's order), extrema are `v_min/v_max` in the loop, per-block "uniform" values
+// are ordinary registers.  No barrier, no DPP, no readlane: a workgroup is one wave that owns 64 adjacent blocks (512 x 8 pixels).
+// The per-pixel helpers (unit4, dp4: DPPS order, captured RSQRTPS table, no contraction) are the very functions of limg_hip_device.h, so the records are
+// bit-identical to the lane == pixel path's -- the parity tests run both.  Only whole 8x8 blocks: images with partial edge blocks keep the other path.
+//
+// LDS: the 64 blocks' pixels, block-major with a stride of 68 dwords (16-byte aligned rows; 68 = 4 mod 64 makes every 16-lane group of a ds_read_b128 hit 64
+// distinct banks).  17 KiB per wave => 9 waves per CU.  The passes re-read the pixels from LDS (2 x ds_read_b128 per row).
+#include "limg_hip_device.h"
+
+namespace limg_hip
+{
+  namespace
+  {
+    constexpr int kTpbStride = 68;
+
+    template <int CH, bool FAST>
+    __global__ __launch_bounds__(64) void k_fit_tpb(const EncodeParams p)
+    {
+      __shared__ __attribute__((aligned(16))) uint32_t s_px[64 * kTpbStride];
+      const unsigned short *tab = d_rsqrt_x86_tab;
+      const int lane = (int)threadIdx.x;
+      const uint32_t unitsX = (p.blocksX + 63u) / 64u;
+      const uint32_t unit = blockIdx.x % unitsX, by = blockIdx.x / unitsX;
+      const uint32_t bx0 = unit * 64u, x0 = bx0 * kBlock, y0 = by * kBlock;
+      const uint32_t nBlocks = min(p.blocksX - bx0, 64u), widthPx = nBlocks * kBlock;
+
+      // ---- stage the 8 pixel rows (coalesced 16 bytes per lane) into the block-major layout ----
+      if (p.vecIn)
+      {
+#pragma unroll
+        for (int row = 0; row < 8; row++)
+          for (uint32_t col = (uint32_t)lane * 4u; col < widthPx; col += 256u)
+          {
+            const uint4 v = *reinterpret_cast<const uint4 *>(p.in + (size_t)(y0 + row) * p.sizeX + x0 + col);
+            *reinterpret_cast<uint4 *>(&s_px[(col >> 3) * kTpbStride + row * 8 + (col & 7u)]) = v;
+          }
+      }
+      else
+      {
+        for (int row = 0; row < 8; row++)
+          for (uint32_t col = (uint32_t)lane; col < widthPx; col += 64u)
+            s_px[(col >> 3) * kTpbStride + row * 8 + (col & 7u)] = p.in[(size_t)(y0 + row) * p.sizeX + x0 + col];
+      }
+      wave_lds_fence();
+      if ((uint32_t)lane >= nBlocks) return;
+      const uint32_t *my = s_px + lane * kTpbStride;
+
+      // ---- a4: channel sums (src/limg.cpp:466-497); two channels per 32-bit accumulator, 64 * 255 < 2^16 ----
+      uint32_t s02 = 0, s13 = 0;
+#pragma unroll
+      for (int r = 0; r < 8; r++)
+      {
+        const uint4 u = *reinterpret_cast<const uint4 *>(my + r * 8), w = *reinterpret_cast<const uint4 *>(my + r * 8 + 4);
+        const uint32_t q[8] = { u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w };
+#pragma unroll
+        for (int i = 0; i < 8; i++) { s02 += q[i] & 0x00FF00FFu; s13 += (q[i] >> 8) & 0x00FF00FFu; }
+      }
+      const float inv_count = 0.015625f;
+      V4 avg;
+      avg.a = float2_t{ (float)(int)(s02 & 0xFFFF), (float)(int)(s02 >> 16) } * inv_count;
+      avg.b = float2_t{ (float)(int)(s13 & 0xFFFF), CH == 4 ? (float)(int)(s13 >> 16) : 0.0f } * inv_count;
+      const V4 zero4 = { float2_t{ 0.0f, 0.0f }, float2_t{ 0.0f, 0.0f } };
+
+      // the epilogue of a direction sum: dir = sum / N, 1 / (dir . dir) in DPPS order, all-zero test (== serial_sums2 of limg_hip_kernels.hip)
+      auto finish_dir = [&](const V4 &acc, V4 &dir, float &inv, bool &zero)
+      {
+        dir = acc * inv_count;
+        const float pp = dp4<CH>(dir, dir); // plain products even in FAST mode: the lane == pixel path does the same
+        zero = dir.a.x == 0.0f && dir.a.y == 0.0f && dir.b.x == 0.0f && dir.b.y == 0.0f;
+        inv = FAST ? __builtin_amdgcn_rcpf(pp) : 1.0f / pp;
+      };
+
+      // ---- pass 1 (src/limg_factorization.h:602-628): sign-normalised unit vectors of px - avg, summed in pixel order ----
+      V4 dirA, dirB = zero4, dirC = zero4, est0 = zero4;
+      float invA, invB = 0.0f, invC = 0.0f;
+      bool zeroA, zeroB = true, zeroC = true;
+      float mm[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+      {
+        V4 acc = zero4;
+#pragma unroll 1
+        for (int r = 0; r < 8; r++)
+        {
+          const uint4 u = *reinterpret_cast<const uint4 *>(my + r * 8), w = *reinterpret_cast<const uint4 *>(my + r * 8 + 4);
+          const uint32_t q[8] = { u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w };
+#pragma unroll
+          for (int i = 0; i < 8; i++)
+          {
+            V4 d = px_to_v4(q[i]) - avg;
+            mask_alpha<CH>(d);
+            acc = acc + unit4<CH, FAST>(tab, d, true);
+          }
+        }
+        finish_dir(acc, dirA, invA, zeroA);
+      }
+
+      // ---- pass 2 (:652-688): factor A extrema, residual -> second direction ----
+      if (!zeroA)
+      {
+        V4 acc = zero4;
+        float mn = 0.0f, mx = 0.0f; // upstream starts them at 0 (:633-634)
+#pragma unroll 1
+        for (int r = 0; r < 8; r++)
+        {
+          const uint4 u = *reinterpret_cast<const uint4 *>(my + r * 8), w = *reinterpret_cast<const uint4 *>(my + r * 8 + 4);
+          const uint32_t q[8] = { u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w };
+#pragma unroll
+          for (int i = 0; i < 8; i++)
+          {
+            const V4 pf = px_to_v4(q[i]);
+            const float fA = dp4<CH, FAST>(pf - avg, dirA) * invA;
+            mn = vmin(mn, fA); mx = vmax(mx, fA);
+            V4 e = pf - (avg + dirA * fA);
+            mask_alpha<CH>(e);
+            acc = acc + unit4<CH, FAST>(tab, e, true);
+          }
+        }
+        mm[0] = mn; mm[1] = mx;
+        finish_dir(acc, dirB, invB, zeroB);
+      }
+
+      // ---- pass 3 ----
+      if (!zeroA && !zeroB)
+      {
+        float mnB = FLT_MAX, mxB = -FLT_MAX;
+        if (CH == 4)
+        { // :701-738: factor B extrema, residual -> third direction; the A+B estimate of pixel 0 is what pass 4 measures every pixel against (:748-758)
+          V4 acc = zero4;
+#pragma unroll 1
+          for (int r = 0; r < 8; r++)
+          {
+            const uint4 u = *reinterpret_cast<const uint4 *>(my + r * 8), w = *reinterpret_cast<const uint4 *>(my + r * 8 + 4);
+            const uint32_t q[8] = { u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w };
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+            {
+              const V4 pf = px_to_v4(q[i]);
+              const float fA = dp4<CH, FAST>(pf - avg, dirA) * invA; // recomputed, same operations => same bits as pass 2's
+              const V4 estA = avg + dirA * fA;
+              const float fB = dp4<CH, FAST>(pf - estA, dirB) * invB;
+              mnB = vmin(mnB, fB); mxB = vmax(mxB, fB);
+              const V4 estB = estA + dirB * fB;
+              if (r == 0 && i == 0) est0 = estB;
+              acc = acc + unit4<CH, FAST>(tab, pf - estB, true);
+            }
+          }
+          mm[2] = mnB; mm[3] = mxB;
+          finish_dir(acc, dirC, invC, zeroC);
+          // ---- pass 4 (:748-758) ----
+          if (!zeroC)
+          {
+            float mnC = FLT_MAX, mxC = -FLT_MAX;
+#pragma unroll 1
+            for (int r = 0; r < 8; r++)
+            {
+              const uint4 u = *reinterpret_cast<const uint4 *>(my + r * 8), w = *reinterpret_cast<const uint4 *>(my + r * 8 + 4);
+              const uint32_t q[8] = { u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w };
+#pragma unroll
+              for (int i = 0; i < 8; i++)
+              {
+                const float fC = dp4<CH, FAST>(px_to_v4(q[i]) - est0, dirC) * invC;
+                mnC = vmin(mnC, fC); mxC = vmax(mxC, fC);
+              }
+            }
+            mm[4] = mnC; mm[5] = mxC;
+          }
+        }
+        else
+        { // 3 channels (:498-541): dirC = dirA x dirB, B and C extrema in one pass; slots: a = (x0, x2), b = (x1, x3)
+          dirC.a.x = dirA.b.x * dirB.a.y - dirA.a.y * dirB.b.x; // A1 B2 - A2 B1
+          dirC.b.x = dirA.a.y * dirB.a.x - dirA.a.x * dirB.a.y; // A2 B0 - A0 B2
+          dirC.a.y = dirA.a.x * dirB.b.x - dirA.b.x * dirB.a.x; // A0 B1 - A1 B0
+          dirC.b.y = 0.0f;
+          zeroC = dirC.a.x == 0.0f && dirC.b.x == 0.0f && dirC.a.y == 0.0f;
+          if (!zeroC) invC = FAST ? __builtin_amdgcn_rcpf(dp4<CH, FAST>(dirC, dirC)) : 1.0f / dp4<CH, FAST>(dirC, dirC);
+          float mnC = zeroC ? 0.0f : FLT_MAX, mxC = zeroC ? 0.0f : -FLT_MAX;
+#pragma unroll 1
+          for (int r = 0; r < 8; r++)
+          {
+            const uint4 u = *reinterpret_cast<const uint4 *>(my + r * 8), w = *reinterpret_cast<const uint4 *>(my + r * 8 + 4);
+            const uint32_t q[8] = { u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w };
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+            {
+              const V4 pf = px_to_v4(q[i]);
+              const float fA = dp4<CH, FAST>(pf - avg, dirA) * invA;
+              const V4 estA = avg + dirA * fA;
+              const float fB = dp4<CH, FAST>(pf - estA, dirB) * invB;
+              mnB = vmin(mnB, fB); mxB = vmax(mxB, fB);
+              if (!zeroC)
+              {
+                const V4 e = pf - (estA + dirB * fB);
+                const float fC = dp4<CH, FAST>(e, dirC) * invC;
+                mnC = vmin(mnC, fC); mxC = vmax(mxC, fC);
+              }
+            }
+          }
+          mm[2] = mnB; mm[3] = mxB; mm[4] = mnC; mm[5] = mxC;
+        }
+      }
+
+      // ---- record (src/limg_factorization.h:764-790): avg + extreme * dir for A, extreme * dir for B and C, round to nearest even, int16 ----
+      const bool deadA = zeroA, deadB = zeroA || zeroB, deadC = zeroA || zeroB || zeroC;
+      auto comp = [](const V4 &v, int c) -> float { return c == 0 ? v.a.x : (c == 1 ? v.b.x : (c == 2 ? v.a.y : v.b.y)); };
+      uint32_t words[16];
+#pragma unroll
+      for (int c = 0; c < 4; c++) words[c] = __float_as_uint(comp(avg, c));
+      int16_t rec[24];
+#pragma unroll
+      for (int k = 0; k < 6; k++)
+      {
+        const int r = k >> 1;
+        const bool dead = r == 0 ? deadA : (r == 1 ? deadB : deadC);
+        const V4 &dir = r == 0 ? dirA : (r == 1 ? dirB : dirC);
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+        {
+          float m = mm[k], dv = comp(dir, c);
+          if (dead) { m = 0.0f; dv = 0.0f; }
+          float val = m * dv;
+          if (r == 0) val = comp(avg, c) + val;
+          int q = cvt_rne(val);
+          if (CH == 3 && c == 3) q = 0;
+          rec[k * 4 + c] = (int16_t)q;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 12; i++) words[4 + i] = (uint32_t)(uint16_t)rec[2 * i] | ((uint32_t)(uint16_t)rec[2 * i + 1] << 16);
+      uint4 *dst = reinterpret_cast<uint4 *>(p.records + (size_t)by * p.blocksX + bx0 + lane);
+#pragma unroll
+      for (int i = 0; i < 4; i++) dst[i] = make_uint4(words[4 * i], words[4 * i + 1], words[4 * i + 2], words[4 * i + 3]);
+    }
+  }
+
+  void launch_fit_tpb(const EncodeParams &p, int channels, hipStream_t s)
+  {
+    const dim3 grid(((p.blocksX + 63u) / 64u) * p.blocksY), block(64);
+    if (p.floatFast)
+    {
+      if (channels == 4) hipLaunchKernelGGL((k_fit_tpb<4, true>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((k_fit_tpb<3, true>), grid, block, 0, s, p);
+    }
+    else if (channels == 4) hipLaunchKernelGGL((k_fit_tpb<4, false>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((k_fit_tpb<3, false>), grid, block, 0, s, p);
+  }
+}

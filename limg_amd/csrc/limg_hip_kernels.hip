@@ -871,7 +871,9 @@ namespace limg_hip
 
       uint8_t *stage = reinterpret_cast<uint8_t *>(s_V); // [3 planes][8 rows][256 px]
       uint32_t waveCalls = 0;
-      if (PERSIST && lane < kBlocksPerWave) reinterpret_cast<uint32_t *>(park + kParkShift)[wave * kBlocksPerWave + lane] = 0u; // blocks past the right edge
+      // (No zeroing of the parked shift words of blocks past the right edge here: with the dynamic queue below another wave may already have parked a real
+      //  word for a block of this wave's range by the time this wave gets to issue such a store -- a rare lost update, found in round 2.  The F step masks
+      //  the words of blocks that do not exist instead.)
 
       // ---- phase E: per-pixel factors (a8) + shift search (a10-a12) ----------------------------------------------------
       // The strip's 32 blocks are handed out dynamically: the number of trials differs from block to block (2 .. 20), and with a fixed 8 blocks per wave
@@ -1118,7 +1120,7 @@ namespace limg_hip
       {
         for (int i = tid; i < 384; i += kThreads) reinterpret_cast<uint4 *>(L.fac)[i] = reinterpret_cast<const uint4 *>(park + kParkFac)[i];
         for (int i = tid; i < kStripBlocks * 12; i += kThreads) reinterpret_cast<uint32_t *>(s_rec)[i] = reinterpret_cast<const uint32_t *>(park + kParkRec)[i];
-        if (tid < kStripBlocks) L.shift[tid] = reinterpret_cast<const uint32_t *>(park + kParkShift)[tid];
+        if (tid < kStripBlocks) L.shift[tid] = (uint32_t)tid < nBlocks ? reinterpret_cast<const uint32_t *>(park + kParkShift)[tid] : 0u; // nothing is parked for blocks past the right edge
       }
       else
       {

@@ -428,3 +428,47 @@ def test_config5_strip_sharded_rehearsal(gpu, oracle):
     assert total < W * W * 3  # ~1.8 B/px of stream instead of 35 B/px of planes
     del full, planes, d_img
     torch.cuda.empty_cache()
+
+
+def test_host_entry_at_4096(gpu, oracle):
+    """The drop-in entry itself (host pointers: what the shim's limg_encode3d_test calls) at a BASELINE size: every plane equals the device entry's, the first
+    band equals the oracle, and the reference's PSNR figure for config 2 comes out of limg_hip_compare on host pointers."""
+    import torch
+    W = 4096
+    d_img = gpu.synth_device("random_gradient", W, W, seed=1)
+    img = d_img.cpu().numpy().view(np.uint32)
+    got = gpu.encode3d(img, True)
+    planes = gpu.alloc_planes_device(W, W)
+    gpu.encode3d_device(d_img, True, planes)
+    torch.cuda.synchronize()
+    for k in PLANES:
+        dev = planes[k].cpu().numpy()
+        dev = dev.view(np.uint32) if dev.dtype == np.int32 else dev
+        assert np.array_equal(got[k], dev), k
+    want = oracle.encode3d(np.ascontiguousarray(img[:128]), True)
+    for k in PLANES:
+        assert np.array_equal(got[k][:128], want[k]), k
+    psnr, _ = gpu.compare(img, got["pDecoded"], True)
+    assert abs(psnr - 50.38) < 0.05
+    del planes, d_img
+    torch.cuda.empty_cache()
+
+
+def test_repeat_determinism_at_4096(gpu):
+    """The same 4096^2 gradient image 32 times through one context: every run must give the same planes.  Fast searches (2 trials per block) and 16 K work
+    strips per image are what exposed a lost update in the persistent kernel (a late store zeroing an already parked shift word, about one strip in 500 K):
+    invisible to band-limited full-size checks, so all planes of all runs are compared here, on the device."""
+    import torch
+    W = 4096
+    d_img = gpu.synth_device("random_gradient", W, W, seed=3)
+    ref = gpu.alloc_planes_device(W, W)
+    gpu.encode3d_device(d_img, True, ref)
+    cur = gpu.alloc_planes_device(W, W)
+    for it in range(32):
+        gpu.encode3d_device(d_img, True, cur)
+        torch.cuda.synchronize()
+        for k in PLANES:
+            assert torch.equal(cur[k], ref[k]), (it, k)
+    gpu.check()
+    del ref, cur, d_img
+    torch.cuda.empty_cache()
