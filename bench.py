@@ -49,7 +49,7 @@ def pmc_entry(key):
 def workload_key(args, W, H):
     mode = "split" if args.split else "fused"
     return "%dx%d_%s_ef%d_%s%s%s%s" % (W, H, args.workload, args.error_factor, mode, "" if args.forced_shift < 0 else "_shift%d" % args.forced_shift,
-                                       "_compact" if args.compact else "", "_fastfloat" if args.float_mode == "fast" else "")
+                                       "_compact" if args.compact else "", ("_fastfloat" if args.float_mode == "fast" else "") + ("_legacyfit" if args.legacy_float_stage else ""))
 
 
 def cpu_model():
@@ -466,6 +466,7 @@ def main():
     ap.add_argument("--compact", action="store_true", help="compact mode: factor planes + records + shift words only (8.05 B/px)")
     ap.add_argument("--float-mode", default="exact", choices=["exact", "fast"],
                     help="exact (headline): the float stage op for op as the reference's strict SSE build; fast: native rsq / fused multiply-adds, PSNR-tolerance contract")
+    ap.add_argument("--legacy-float-stage", action="store_true", help="float stage inside the E step with lane == pixel (round-1 mapping) instead of k_fit_tpb")
     ap.add_argument("--forced-shift", type=int, default=-1, help="bypass the shift search with this shift on all three factors (bit-crush sweep)")
     ap.add_argument("--config", type=int, default=3, choices=[3, 4, 5],
                     help="BASELINE.json configs, 1-based: 3 = headline (default), 4 = batch of 64 x 4096^2 images over the ranks + gather, "
@@ -540,7 +541,7 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
-    g.set_options(forced_shift=(args.forced_shift,) * 3 if args.forced_shift >= 0 else None, force_split=args.split, float_fast=(args.float_mode == "fast"))
+    g.set_options(forced_shift=(args.forced_shift,) * 3 if args.forced_shift >= 0 else None, force_split=args.split, float_fast=(args.float_mode == "fast"), legacy_float_stage=args.legacy_float_stage)
     img = g.synth_device(args.workload, W, H, seed=1 + rank)
     planes = g.alloc_planes_device(W, H)
     rec = sh = None
@@ -596,7 +597,7 @@ def main():
         perf_ms = float(kperf[1:, 0].mean()) if len(kperf) > 1 else None
 
         kavg = kernels.mean(axis=0) if len(kernels) else np.zeros(3)
-        kms = float(kavg.sum()) if args.split else float(kavg[0])  # fused: the one launch's own interval
+        kms = float(kavg.sum())  # fused: k_fit_tpb + k_encode_persistent (or the one persistent launch with --legacy-float-stage); split: the three intervals
         achieved = bytes_per_px * px / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         pmc = pmc_entry(workload_key(args, W, H))
         traffic = None if not pmc or pmc.get("fetch_kib") is None else int((2 * pmc["fetch_kib"] + pmc["write_kib"]) * 1024)  # gfx950: FETCH_SIZE counts half the bytes
@@ -627,10 +628,12 @@ def main():
                          "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(bytes_per_px * px),
                          "kernels_ms": ({"k_fit_search": round(float(kavg[0]), 4), "k_strip_scan": round(float(kavg[1]), 4), "k_dither_store": round(float(kavg[2]), 4)}
-                                        if args.split else {"k_encode_persistent": round(float(kavg[0]), 4)}),
+                                        if args.split else ({"k_encode_persistent": round(float(kavg[0]), 4)} if args.legacy_float_stage else
+                                                            {"k_fit_tpb": round(float(kavg[0]), 4), "k_encode_persistent": round(float(kavg[1]), 4)})),
                          "valu": valu, "pmc_key": workload_key(args, W, H),
                          "note": ("whole encode = 3 launches; achieved = 39 B/px * pixels / sum of the three average kernel durations (HIP events)" if args.split else
-                                  "whole encode = one persistent launch; achieved = 39 B/px * pixels / its average duration (HIP events on the launch stream). "
+                                  "whole encode = k_fit_tpb (float stage, one lane per block) + one persistent launch; achieved = 39 B/px * pixels / the sum of their average durations "
+                                  "(HIP events on the launch stream). "
                                   "The kernel is VALU-issue-bound, not HBM-bound: see `valu`")},
         }
         if n_gpus == 1 and not args.no_host_rate:

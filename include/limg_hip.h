@@ -68,7 +68,8 @@ typedef struct limg_hip_options
                                   rounded divisions): every plane bit-identical to the reference.  1 = FAST: hardware v_rsq_f32 / v_rcp_f32 and fused multiply-adds;
                                   contract: the integer stage stays bit-exact given the same records, extrema within +-2 LSB on >= 99.9 % of blocks, perceptual PSNR
                                   within 0.10 dB of EXACT; the 8x8 path only (the merged-block encoder always runs EXACT) */
-  int32_t reserved[1];
+  int32_t legacy_float_stage;  /* non-0: run the float stage inside the E step with lane == pixel (round-1 mapping; what images with partial edge blocks always use)
+                                  instead of the one-lane-per-block kernel k_fit_tpb.  Same bits either way; A/B switch for tests and the bench */
 } limg_hip_options;
 
 typedef struct limg_hip_context limg_hip_context;

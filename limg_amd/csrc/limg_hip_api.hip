@@ -244,6 +244,19 @@ namespace
     if (chainPhase != 0 && (ragged || !dInfo || poolThreads != 0)) return limg_hip_error_InvalidParameter; // a chain shared between GPUs: whole 8x8 blocks, one chain
     p.chainCallsOut = chainPhase == 1 ? dChainCalls : nullptr;
     p.chainBase = chainPhase == 2 ? dChainBase : nullptr;
+    // The float stage as its own launch, one lane per block (limg_hip_fit_tpb.hip), wherever every block is a whole 8x8: the E step then starts from the records.
+    p.prefit = (!ragged && c->opt.legacy_float_stage == 0) ? 1 : 0;
+    if (p.prefit && chainPhase != 2)
+    {
+      mark(c, stream);
+      launch_fit_tpb(p, channels, stream);
+      if (p.fitOnly)
+      { // pass 1 of the merged-block encoder: the records are all it wants
+        mark(c, stream); mark(c, stream); mark(c, stream);
+        HIP_TRY(hipGetLastError());
+        return limg_hip_success;
+      }
+    }
     const bool fused = dInfo != nullptr && !ragged && !c->forceSplit && chainPhase == 0;
     if (fused)
     {
@@ -259,11 +272,12 @@ namespace
       p.timeout = (uint32_t *)c->devStatus.p;
       p.desc = (unsigned long long *)((uint8_t *)c->lookback.p + 16);
       p.compactOut = compact != nullptr;
-      if ((r = c->park.ensure((size_t)c->persistentWorkgroups * 2 * 8192)) != limg_hip_success) return r;
+      if ((r = c->park.ensure((size_t)(c->persistentWorkgroups / 5 * 6) * 2 * 8192)) != limg_hip_success) return r;
       p.park = (uint8_t *)c->park.p;
       mark(c, stream);
-      launch_encode_persistent(p, channels, c->persistentWorkgroups, stream);
-      mark(c, stream); mark(c, stream); mark(c, stream);
+      launch_encode_persistent(p, channels, p.prefit ? c->persistentWorkgroups / 5 * 6 : c->persistentWorkgroups, stream); // 6 workgroups per CU fit once the float stage is out
+      mark(c, stream); mark(c, stream);
+      if (!p.prefit) mark(c, stream); // 4 events per encode: with the float stage as its own launch the intervals are {k_fit_tpb, k_encode_persistent, -}
       HIP_TRY(hipGetLastError());
       return limg_hip_success;
     }
@@ -274,7 +288,7 @@ namespace
       HIP_TRY(hipGetLastError());
       return limg_hip_success;
     }
-    mark(c, stream);
+    if (!p.prefit) mark(c, stream); // split path intervals: {k_fit_tpb + k_fit_search, scan, k_dither_store}
     launch_fit_search(p, channels, stream);
     mark(c, stream);
     if (!dInfo)

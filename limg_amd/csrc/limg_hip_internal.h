@@ -50,6 +50,7 @@ namespace limg_hip
     // cross-GPU single dither chain (split path only): the scan writes this image strip's dither-call total; the F step adds the strip's first call index
     unsigned long long *chainCallsOut;
     const unsigned long long *chainBase;
+    int32_t prefit;     // host dispatch only: p.records already hold the fit (k_fit_tpb ran first)
     int32_t floatFast;  // host dispatch only: FAST float stage (limg_hip_options.float_mode = 1)
     int32_t vecIn;      // rows of pIn may be read 16 bytes per lane (sizeX % 4 == 0 and pIn 16-byte aligned); otherwise dword loads
     int32_t vecFactors; // the three factor planes may be accessed 16 bytes per lane (sizeX % 16 == 0 and all three 16-byte aligned)
@@ -75,6 +76,7 @@ namespace limg_hip
     uint32_t *status; // bit 0: header mismatch, bit 1: inconsistent payload offsets
   };
 
+  void launch_fit_tpb(const EncodeParams &p, int channels, hipStream_t s);
   void launch_fit_search(const EncodeParams &p, int channels, hipStream_t s);
   void launch_encode_persistent(const EncodeParams &p, int channels, int workgroups, hipStream_t s);
   void launch_strip_scan(const EncodeParams &p, hipStream_t s);

@@ -537,6 +537,17 @@ namespace limg_hip
     constexpr int kLdsStrip = 0, kLdsV = kLdsStrip + 8 * kRowDw * 4, kLdsVBytes = kWaves * kBatch * kVDw * 4;
     constexpr int kLdsBlk = kLdsV + kLdsVBytes, kLdsCalls = kLdsBlk + kStripBlocks * 192, kLdsTotal = kLdsCalls + 32; // 4 per-wave call counts + the phase-E block queue
     static_assert(kLdsTotal <= 32768 - 16, "5 workgroups per CU");
+    // PREFIT (float stage done by k_fit_tpb): the parked-contribution area shrinks to the 6 KiB factor-byte staging area, and what sets the size is the F
+    // step's overlay (26 KiB) => 6 workgroups per CU
+    struct LdsLayout { int v, blk, calls, total; };
+    template <bool PREFIT> __device__ __host__ constexpr LdsLayout lds_layout()
+    {
+      if (!PREFIT) return LdsLayout{ kLdsV, kLdsBlk, kLdsCalls, kLdsTotal };
+      const int v = kLdsStrip + 8 * kRowDw * 4, blk = v + 6144, calls = blk + kStripBlocks * 192, e = calls + 32;
+      const int f = kLdsStrip + 6144 + 8192 + 6144 + 896 + 3072 + 128 + 128 + kStripBlocks * 48 + 16; // kPhaseFBytes + the F step's record copy
+      return LdsLayout{ v, blk, calls, e > f ? e : f };
+    }
+    static_assert(lds_layout<true>().total <= 163840 / 6, "6 workgroups per CU with the float stage in its own kernel");
 
 
     // PERSIST == false: split path, the strip's call count goes to p.stripCalls for k_strip_scan.
@@ -544,16 +555,18 @@ namespace limg_hip
     // parked results of one strip (persistent kernel): pre-dither factor bytes, records (int16 part), shift words
     constexpr int kParkFac = 0, kParkRec = 6144, kParkShift = 6144 + 1536, kParkBytes = 8192;
 
-    template <int CH, bool PERSIST, bool FAST>
+    // PREFIT: the float stage already ran in k_fit_tpb (limg_hip_fit_tpb.hip, one lane per block); this step loads the records and goes on with phase E.
+    template <int CH, bool PERSIST, bool FAST, bool PREFIT>
     __device__ __forceinline__ void fit_search_strip(const EncodeParams &p, const uint32_t id, uint8_t *lds, uint8_t *park, const int tid)
     {
       // the 4 KiB RSQRTPS table is read straight from global memory (it lives in the CU's vector L1): keeping a copy in LDS would
       // cost the fifth workgroup per CU
       const unsigned short *s_rsq = d_rsqrt_x86_tab;
       uint32_t *s_strip = reinterpret_cast<uint32_t *>(lds + kLdsStrip);
-      float *s_V = reinterpret_cast<float *>(lds + kLdsV);
-      BlkF *s_blk = reinterpret_cast<BlkF *>(lds + kLdsBlk);
-      uint32_t *s_calls = reinterpret_cast<uint32_t *>(lds + kLdsCalls);
+      constexpr LdsLayout LL = lds_layout<PREFIT>();
+      float *s_V = reinterpret_cast<float *>(lds + LL.v);
+      BlkF *s_blk = reinterpret_cast<BlkF *>(lds + LL.blk);
+      uint32_t *s_calls = reinterpret_cast<uint32_t *>(lds + LL.calls);
 
       const int lane = tid & 63, wave = tid >> 6;
       const uint32_t strip = id % p.stripsX, by = id / p.stripsX;
@@ -598,6 +611,33 @@ namespace limg_hip
         return true;
       };
 
+      if (PREFIT)
+      {
+        // records of the wave's 8 blocks as k_fit_tpb left them (16 dwords per block: avg, then the 24 int16); 16 lanes per block
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+        {
+          const int b = r * 4 + (lane >> 4), w = lane & 15;
+          const uint32_t sb = wave * kBlocksPerWave + b, bx = strip * kStripBlocks + sb;
+          uint32_t val = 0;
+          if (bx < p.blocksX) val = reinterpret_cast<const uint32_t *>(p.records + (size_t)by * p.blocksX + bx)[w];
+          if (w >= 4)
+          {
+            reinterpret_cast<uint32_t *>(blk[b].rec)[w - 4] = val;
+            if (PERSIST) reinterpret_cast<uint32_t *>(park + kParkRec)[sb * 12 + (w - 4)] = val;
+          }
+          const int lo = (int)(int16_t)(val & 0xFFFFu), hi = (int)(int16_t)(val >> 16);
+          uint32_t big = (w >= 4 && (lo > p.recordLimit || lo < -p.recordLimit || hi > p.recordLimit || hi < -p.recordLimit)) ? 1u : 0u;
+          big |= (uint32_t)dpp<0xB1, 0xF>(0, (int)big);  // OR over the block's 16 lanes (one DPP row)
+          big |= (uint32_t)dpp<0x4E, 0xF>(0, (int)big);
+          big |= (uint32_t)dpp<0x141, 0xF>(0, (int)big);
+          big |= (uint32_t)dpp<0x140, 0xF>(0, (int)big);
+          if (w == 0) { blk[b].flags = (bx < p.blocksX ? kValid : 0u) | (big ? kBig : 0u); blk[b].n = bx < p.blocksX ? 64u : 0u; }
+        }
+        wave_lds_fence();
+      }
+      else
+      {
       // The float stage runs in batches of kBatch blocks per wave: the parked contributions of one batch are what limits the
       // workgroups per CU (LDS), and 4 blocks x 4 waves keep it at 5 workgroups per CU.
       // Per-block values of the batch stay in registers across the phases (the loops over i are fully unrolled).
@@ -831,6 +871,7 @@ namespace limg_hip
           if (PERSIST && w >= 4) reinterpret_cast<uint32_t *>(park + kParkRec)[sb * 12 + (w - 4)] = val;
         }
       }
+      } // !PREFIT
       if (!PERSIST && p.fitOnly) return; // pass 1 of the merged-block encoder: the records are all it needs (uniform for the workgroup)
       // phase-E view (overlays the dead float-stage fields): float normals / offsets and 1 / |n|^2 in the serial limg_dot
       // order (src/limg_internal.h:426-452).  One lane per (block, factor, channel): 96 of 128 lane slots.
@@ -1189,11 +1230,11 @@ namespace limg_hip
     }
 
     // ---- kernels ---------------------------------------------------------------------------------------------------------
-    template <int CH, bool FAST>
+    template <int CH, bool FAST, bool PREFIT>
     __global__ __launch_bounds__(kThreads) void k_fit_search(const EncodeParams p)
     {
-      __shared__ __attribute__((aligned(16))) uint8_t s_lds[kLdsTotal];
-      fit_search_strip<CH, false, FAST>(p, blockIdx.x, s_lds, nullptr, (int)threadIdx.x);
+      __shared__ __attribute__((aligned(16))) uint8_t s_lds[lds_layout<PREFIT>().total];
+      fit_search_strip<CH, false, FAST, PREFIT>(p, blockIdx.x, s_lds, nullptr, (int)threadIdx.x);
     }
 
     template <int CH>
@@ -1213,10 +1254,10 @@ namespace limg_hip
     // earlier strip has long published its call count, so the look-back does not wait; and since the workgroups of a CU
     // drift apart, E and F steps of different workgroups overlap on every CU.
     // Progress: a look-back only waits for strips with smaller tickets; those were drawn earlier, and an E step never waits.
-    template <int CH, bool FAST>
-    __global__ __launch_bounds__(kThreads, 5) void k_encode_persistent(const EncodeParams p)
+    template <int CH, bool FAST, bool PREFIT>
+    __global__ __launch_bounds__(kThreads, PREFIT ? 6 : 5) void k_encode_persistent(const EncodeParams p)
     {
-      __shared__ __attribute__((aligned(16))) uint8_t s_lds[kLdsTotal];
+      __shared__ __attribute__((aligned(16))) uint8_t s_lds[lds_layout<PREFIT>().total];
       __shared__ uint32_t s_ticket;
       const int tid = (int)threadIdx.x;
       const uint32_t S = p.stripsX * p.blocksY;
@@ -1230,7 +1271,7 @@ namespace limg_hip
         const uint32_t t = s_ticket;
         int tid_e = tid;
         asm volatile("" : "+v"(tid_e));
-        if (t < S) fit_search_strip<CH, true, FAST>(p, t, s_lds, park + slot * kParkBytes, tid_e);
+        if (t < S) fit_search_strip<CH, true, FAST, PREFIT>(p, t, s_lds, park + slot * kParkBytes, tid_e);
         if (prev != 0xFFFFFFFFu)
         {
           __syncthreads();
@@ -1245,29 +1286,35 @@ namespace limg_hip
     }
   } // namespace
 
+  // kernel variant by (channels, float mode, float stage already done by k_fit_tpb)
+#define LIMG_DISPATCH(KERNEL, GRID, BLOCK, S, P)                                                        \
+  do                                                                                                    \
+  {                                                                                                     \
+    const int v_ = (channels == 4 ? 4 : 0) | ((P).floatFast ? 2 : 0) | ((P).prefit ? 1 : 0);            \
+    switch (v_)                                                                                         \
+    {                                                                                                   \
+    case 0: hipLaunchKernelGGL((KERNEL<3, false, false>), GRID, BLOCK, 0, S, P); break;                 \
+    case 1: hipLaunchKernelGGL((KERNEL<3, false, true>), GRID, BLOCK, 0, S, P); break;                  \
+    case 2: hipLaunchKernelGGL((KERNEL<3, true, false>), GRID, BLOCK, 0, S, P); break;                  \
+    case 3: hipLaunchKernelGGL((KERNEL<3, true, true>), GRID, BLOCK, 0, S, P); break;                   \
+    case 4: hipLaunchKernelGGL((KERNEL<4, false, false>), GRID, BLOCK, 0, S, P); break;                 \
+    case 5: hipLaunchKernelGGL((KERNEL<4, false, true>), GRID, BLOCK, 0, S, P); break;                  \
+    case 6: hipLaunchKernelGGL((KERNEL<4, true, false>), GRID, BLOCK, 0, S, P); break;                  \
+    default: hipLaunchKernelGGL((KERNEL<4, true, true>), GRID, BLOCK, 0, S, P); break;                  \
+    }                                                                                                   \
+  } while (0)
+
   void launch_fit_search(const EncodeParams &p, int channels, hipStream_t s)
   {
     const dim3 grid(p.stripsX * p.blocksY), block(kThreads);
-    if (p.floatFast)
-    {
-      if (channels == 4) hipLaunchKernelGGL((k_fit_search<4, true>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((k_fit_search<3, true>), grid, block, 0, s, p);
-    }
-    else if (channels == 4) hipLaunchKernelGGL((k_fit_search<4, false>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((k_fit_search<3, false>), grid, block, 0, s, p);
+    LIMG_DISPATCH(k_fit_search, grid, block, s, p);
   }
 
   void launch_encode_persistent(const EncodeParams &p, int channels, int workgroups, hipStream_t s)
   {
     const uint32_t strips = p.stripsX * p.blocksY;
     const dim3 grid(strips < (uint32_t)workgroups ? strips : (uint32_t)workgroups), block(kThreads);
-    if (p.floatFast)
-    {
-      if (channels == 4) hipLaunchKernelGGL((k_encode_persistent<4, true>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((k_encode_persistent<3, true>), grid, block, 0, s, p);
-    }
-    else if (channels == 4) hipLaunchKernelGGL((k_encode_persistent<4, false>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((k_encode_persistent<3, false>), grid, block, 0, s, p);
+    LIMG_DISPATCH(k_encode_persistent, grid, block, s, p);
   }
 
   namespace

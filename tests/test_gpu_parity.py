@@ -13,14 +13,22 @@ from oracle.bind import PLANES, REC_DTYPE
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["fused", "split"])
+@pytest.fixture(scope="module", params=["fused", "split", "legacy"])
 def gpu(request):
-    """`fused` = the single-kernel path (decoupled look-back for the dither chain) where it applies;
-    `split` = the three-launch path (fit+search, scan, dither+store) that ragged images always take."""
+    """`fused`  = k_fit_tpb (float stage, one lane per block) + the persistent kernel (decoupled look-back for the dither chain) where they apply;
+    `split`  = the three-launch path (fit+search, scan, dither+store) that ragged images always take;
+    `legacy` = the float stage inside the persistent kernel's E step with lane == pixel (the round-1 mapping, still what images with partial blocks run)."""
     import limg_amd
     g = limg_amd.LimgHip(0)  # raises if the HIP library or the device is missing: no fallback
-    g.set_options(force_split=(request.param == "split"))
     g.mode = request.param
+    plain = g.set_options
+
+    def set_options(**kw):  # every options change inside a test keeps the fixture's mode
+        kw.setdefault("force_split", request.param == "split")
+        kw["legacy_float_stage"] = request.param == "legacy"
+        plain(**kw)
+    g.set_options = set_options
+    g.set_options()
     yield g
     g.check()
     g.close()

@@ -19,4 +19,4 @@ for SET in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD S
 done
 mkdir -p "$R/gpurun_out/profiles"
 cp -n "$R/profiles/pmc_by_workload.json" "$R/gpurun_out/profiles/pmc_by_workload.json" 2>/dev/null || true
-python3 "$R/tools/prof_summary.py" "$OUT" --update-json "$R/gpurun_out/profiles/pmc_by_workload.json" --kernel "${PROF_KERNEL:-k_encode_persistent}" --source "prof_$TAG" | tee "$OUT/summary.txt"
+python3 "$R/tools/prof_summary.py" "$OUT" --update-json "$R/gpurun_out/profiles/pmc_by_workload.json" --kernel "${PROF_KERNEL:-k_encode_persistent,k_fit_tpb}" --source "prof_$TAG" | tee "$OUT/summary.txt"

@@ -39,11 +39,20 @@ if "--update-json" in sys.argv:
     except Exception:
         pass
     m = None
-    for k, d in acc.items():
-        if want in k:
-            m = {c: sum(v) / len(v) for c, v in d.items()}
+    per_kernel = {}
+    for w in want.split(","):  # several kernels make up one encode: their per-dispatch means add up
+        for k, d in acc.items():
+            if w in k:
+                one = {c: sum(v) / len(v) for c, v in d.items()}
+                per_kernel[w] = {"valu_instr": one.get("SQ_INSTS_VALU"), "salu_instr": one.get("SQ_INSTS_SALU"), "lds_instr": one.get("SQ_INSTS_LDS"),
+                                 "fetch_kib": one.get("FETCH_SIZE"), "write_kib": one.get("WRITE_SIZE")}
+                if m is None:
+                    m = dict(one)
+                else:
+                    for c, v in one.items():
+                        m[c] = m.get(c, 0.0) + v
     if key and m:
-        entry = {"source": source, "kernel": want,
+        entry = {"source": source, "kernel": want, "per_kernel": per_kernel,
                  "fetch_kib": m.get("FETCH_SIZE"), "write_kib": m.get("WRITE_SIZE"), "valu_instr_per_launch": m.get("SQ_INSTS_VALU"),
                  "salu_instr_per_launch": m.get("SQ_INSTS_SALU"), "lds_instr_per_launch": m.get("SQ_INSTS_LDS")}
         if m.get("SQ_ACTIVE_INST_VALU") and m.get("GRBM_GUI_ACTIVE"):
