@@ -28,4 +28,18 @@ def ref():
     from oracle.bind import Ref, ref_available
     if not ref_available():
         pytest.skip("oracle/_ref not built (no /root/reference here)")
-    return Ref()
+    r = Ref()
+    # The bit-exact pin is to the reference executing Intel's RSQRTPS (captured in limg_rsqrt_x86_table.h).  On a host whose RSQRTPS gives other bits (AMD
+    # EPYC: the GPU boxes, where oracle/_ref rides along) the real reference legitimately differs from the oracle in the float stage: skip, do not fail.
+    import ctypes as C
+    import numpy as np
+    from oracle.bind import Oracle
+    o = Oracle()
+    probe = np.concatenate([np.linspace(1e-6, 4.0, 4099, dtype=np.float32), np.float32(2.0) ** np.arange(-20, 20, dtype=np.float32) * np.float32(1.2345)]).astype(np.float32)
+    hw = np.zeros_like(probe)
+    r.lib.ref_rsqrtps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    r.lib.ref_rsqrtps(probe.ctypes.data_as(C.c_void_p), hw.ctypes.data_as(C.c_void_p), probe.size)
+    table = np.array([o.lib.limg_oracle_rsqrt_x86(float(x)) for x in probe], dtype=np.float32)
+    if not np.array_equal(hw.view(np.uint32), table.view(np.uint32)):
+        pytest.skip("this host's RSQRTPS differs from the captured Intel table: reference-vs-oracle bit comparisons do not apply here")
+    return r

@@ -94,3 +94,37 @@ def test_benchmark_modes(cli):
     assert re.search(r"Mean Elapsed Time:\s+[0-9.]+ ms \(", r.stdout) and re.search(r"Throughput: [0-9.]+ Mpx/s \(", r.stdout)
     r = subprocess.run([cli, "--", "--count", "2", "--", PNG, PNG], capture_output=True, text=True)
     assert r.returncode == 0 and "Complete." in r.stdout and re.search(r"Processed 2\.531 Mpx in", r.stdout)
+
+
+def _png(width, height, depth, ctype, raw_rows, interlace=0, extra=()):
+    import struct
+    import zlib
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, depth, ctype, 0, 0, interlace))
+    for t, d in extra:
+        out += chunk(t, d)
+    return out + chunk(b"IDAT", zlib.compress(b"".join(b"\x00" + r for r in raw_rows))) + chunk(b"IEND", b"")
+
+
+def test_png_variants_the_reader_refuses_say_why(cli, tmp_path):
+    """The built-in PNG reader reads fewer variants than upstream's stb_image; each refusal names its reason instead of a generic load failure,
+    and absurd IHDR sizes are refused before anything is allocated."""
+    cases = {
+        "deep.png": (_png(4, 2, 16, 2, [b"\x00" * 24] * 2), "bit depth other than 8"),
+        "lace.png": (_png(4, 2, 8, 2, [b"\x00" * 12] * 2, interlace=1), "interlaced PNG"),
+        "huge.png": (_png(0x7FFFFFFF, 0x7FFFFFFF, 8, 2, [b"\x00" * 12]), "larger than 2^30 pixels"),
+        "nopal.png": (_png(4, 2, 8, 3, [b"\x00" * 4] * 2), "PLTE"),
+        "short.png": (_png(4, 4, 8, 2, [b"\x00" * 12] * 2), "does not inflate to the image size"),
+    }
+    for name, (data, why) in cases.items():
+        path = tmp_path / name
+        path.write_bytes(data)
+        r = subprocess.run([cli, str(path), "--no-output"], capture_output=True, text=True)
+        assert r.returncode == 1 and "Failed to read source image" in r.stdout and why in r.stdout, (name, r.stdout)
+    # a readable one gets as far as the size line (and, without a GPU, the loud no-fallback failure)
+    ok = tmp_path / "key.png"
+    ok.write_bytes(_png(8, 8, 8, 2, [bytes([10, 20, 30] * 8)] * 8, extra=[(b"tRNS", bytes([0, 10, 0, 20, 0, 30]))]))
+    r = subprocess.run([cli, str(ok), "--no-output"], capture_output=True, text=True)
+    assert "8 x 8 pixels." in r.stdout

@@ -73,7 +73,7 @@ def test_golden_cases(gpu):
         _assert_planes(got, want, (i, m))
 
 
-@pytest.mark.parametrize("name", ["original_rgb", "original_as_rgba", "rg1024", "rga1024", "pn1024", "pn1024_ef25", "pn1024_pool2", "pn1024_pcg", "original_rgb_ef0"])
+@pytest.mark.parametrize("name", ["original_rgb", "original_as_rgba", "rg1024", "rga1024", "pn1024", "pn1024_ef25", "pn1024_pool2", "pn1024_pcg", "original_rgb_ef0", "pn1024_accurate", "rg1024_accurate"])
 def test_full_image_hashes(gpu, oracle, name):
     """Plane hashes of the real reference on original.png (config #1) and on 1024x1024 of each synthetic generator."""
     e = gu.hashes()[name]

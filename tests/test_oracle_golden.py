@@ -17,7 +17,7 @@ def test_cases_bit_exact(oracle):
         assert oracle.compare(img, o["pDecoded"], m["alpha"])[0] == pytest.approx(m["psnr"], abs=1e-9)
 
 
-@pytest.mark.parametrize("name", ["original_rgb", "original_as_rgba", "rg1024", "rga1024", "pn1024", "pn1024_ef25", "pn1024_pool2", "pn1024_pcg", "original_rgb_ef0"])
+@pytest.mark.parametrize("name", ["original_rgb", "original_as_rgba", "rg1024", "rga1024", "pn1024", "pn1024_ef25", "pn1024_pool2", "pn1024_pcg", "original_rgb_ef0", "pn1024_accurate", "rg1024_accurate"])
 def test_full_image_hashes(oracle, name):
     e = gu.hashes()[name]
     img = gu.big_input(name, oracle)

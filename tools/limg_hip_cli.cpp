@@ -10,7 +10,7 @@
 // benchmark modes run `limg_encode3d_test_perf`.  Differences: images are read by a small built-in PNG (zlib) / TGA / PPM reader instead
 // of stb_image; TGAs are written uncompressed (upstream's stb writer uses RLE); the block-error plane upstream allocates but never
 // fills is not written.  Extras: `--fixed-blocks` (single-file mode with `limg_encode3d_test`, fixed 8x8 blocks, instead), `--threads <T>`
-// (size of the pool whose strip partition the 8x8 path reproduces; default: hardware threads, like limg_threading_max_threads),
+// (size of the pool whose strip partition the 8x8 path reproduces; default: limg_threading_max_threads()),
 // `--out-dir <dir>`, `--stream <file>` (also write the compact LMG3 stream of the 8x8 path and verify that it decodes to that path's image),
 // and the extra mode `limg_hip_cli --decode <file.lmg3> [<out.tga>]`.
 #include <inttypes.h>
@@ -36,21 +36,29 @@ static int64_t CurrentTimeNs()
   return (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec;
 }
 
-// ---- image readers: 8-bit PNG (non-interlaced; gray, gray+alpha, RGB, RGBA, palette), uncompressed TGA, binary PPM -------------
+// ---- image readers: 8-bit PNG (non-interlaced; gray, gray+alpha, RGB, RGBA, palette; tRNS colour keys honoured like stb_image does), uncompressed TGA,
+//      binary PPM.  NOT read (a specific message says so): 16-bit and 1/2/4-bit PNGs, interlaced PNGs, anything above 2^30 pixels. ------------------------
 static uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 
 static bool read_file(const char *path, std::vector<uint8_t> &out)
 {
   FILE *f = fopen(path, "rb");
   if (!f) return false;
-  fseek(f, 0, SEEK_END);
-  const long n = ftell(f);
-  fseek(f, 0, SEEK_SET);
-  out.resize(n > 0 ? (size_t)n : 0);
-  const bool ok = n >= 0 && fread(out.data(), 1, out.size(), f) == out.size();
+  long n = -1;
+  const bool sized = fseek(f, 0, SEEK_END) == 0 && (n = ftell(f)) >= 0 && fseek(f, 0, SEEK_SET) == 0;
+  bool ok = false;
+  if (sized)
+  {
+    out.resize((size_t)n);
+    ok = fread(out.data(), 1, out.size(), f) == out.size();
+  }
   fclose(f);
   return ok;
 }
+
+// why the last load_image() failed, for the error line (stb_image, which upstream uses, reads more PNG variants than this reader)
+static const char *g_loadError = "unknown format";
+static const size_t kMaxPixels = (size_t)1 << 30; // 32768^2: far above anything the encoder is sized for, far below where size arithmetic could wrap
 
 static bool load_png(const std::vector<uint8_t> &file, std::vector<uint32_t> &px, size_t &w, size_t &h, int &channels)
 {
@@ -73,13 +81,21 @@ static bool load_png(const std::vector<uint8_t> &file, std::vector<uint32_t> &px
     else if (!memcmp(type, "IEND", 4)) break;
     pos += 12 + len;
   }
-  if (!width || !height || depth != 8 || interlace != 0) return false;
+  if (!width || !height) { g_loadError = "PNG without a valid IHDR"; return false; }
+  if ((size_t)width * height > kMaxPixels || width > 0x7FFFFFF8u || height > 0x7FFFFFF8u) { g_loadError = "PNG larger than 2^30 pixels"; return false; }
+  if (depth != 8) { g_loadError = "PNG bit depth other than 8 (16-bit and sub-byte PNGs are not supported by this reader; upstream's stb_image reads them)"; return false; }
+  if (interlace != 0) { g_loadError = "interlaced PNG (not supported by this reader)"; return false; }
   int spp;
-  switch (ctype) { case 0: spp = 1; break; case 2: spp = 3; break; case 3: spp = 1; break; case 4: spp = 2; break; case 6: spp = 4; break; default: return false; }
+  switch (ctype) { case 0: spp = 1; break; case 2: spp = 3; break; case 3: spp = 1; break; case 4: spp = 2; break; case 6: spp = 4; break; default: g_loadError = "PNG colour type"; return false; }
+  if (ctype == 3)
+  { // every palette index must exist: check before decoding instead of in the per-pixel loop
+    if (plte.size() < 3 || plte.size() % 3 != 0) { g_loadError = "palette PNG without a valid PLTE chunk"; return false; }
+  }
   const size_t stride = (size_t)width * spp;
   std::vector<uint8_t> raw((stride + 1) * height);
   uLongf rawLen = (uLongf)raw.size();
-  if (uncompress(raw.data(), &rawLen, idat.data(), (uLong)idat.size()) != Z_OK || rawLen != raw.size()) return false;
+  if ((uint64_t)raw.size() > 0xFFFFFFF0ull || (uint64_t)idat.size() > 0xFFFFFFF0ull) { g_loadError = "PNG data larger than 4 GB"; return false; }
+  if (uncompress(raw.data(), &rawLen, idat.data(), (uLong)idat.size()) != Z_OK || rawLen != raw.size()) { g_loadError = "PNG data does not inflate to the image size"; return false; }
   std::vector<uint8_t> img(stride * height);
   for (size_t y = 0; y < height; y++)
   {
@@ -104,8 +120,10 @@ static bool load_png(const std::vector<uint8_t> &file, std::vector<uint32_t> &px
     }
   }
   w = width; h = height;
-  // upstream: hasAlpha = (stb_image's channel count of the file == 4), src/main.cpp:194 -- RGBA, or a palette with tRNS; gray+alpha counts 2
-  channels = (ctype == 6 || (ctype == 3 && !trns.empty())) ? 4 : 3;
+  // upstream: hasAlpha = (stb_image's channel count of the file == 4), src/main.cpp:194.  stb counts RGBA, a palette with tRNS and RGB with a tRNS colour key
+  // as 4; gray+alpha (2) and gray with a tRNS key (2) as not 4 -- the alpha they carry is still delivered in the pixels, as stb does when asked for 4 channels.
+  const bool grayKey = ctype == 0 && trns.size() >= 2, rgbKey = ctype == 2 && trns.size() >= 6;
+  channels = (ctype == 6 || (ctype == 3 && !trns.empty()) || rgbKey) ? 4 : 3;
   px.resize((size_t)width * height);
   for (size_t i = 0; i < px.size(); i++)
   {
@@ -113,12 +131,12 @@ static bool load_png(const std::vector<uint8_t> &file, std::vector<uint32_t> &px
     uint32_t r, g, b, a = 255;
     switch (ctype)
     {
-    case 0: r = g = b = s[0]; break;
+    case 0: r = g = b = s[0]; if (grayKey && s[0] == trns[1]) a = 0; break;
     case 4: r = g = b = s[0]; a = s[1]; break;
-    case 2: r = s[0]; g = s[1]; b = s[2]; break;
+    case 2: r = s[0]; g = s[1]; b = s[2]; if (rgbKey && s[0] == trns[1] && s[1] == trns[3] && s[2] == trns[5]) a = 0; break;
     case 6: r = s[0]; g = s[1]; b = s[2]; a = s[3]; break;
     default:
-      if ((size_t)s[0] * 3 + 2 >= plte.size()) return false;
+      if ((size_t)s[0] * 3 + 2 >= plte.size()) { g_loadError = "palette index outside PLTE"; return false; }
       r = plte[s[0] * 3]; g = plte[s[0] * 3 + 1]; b = plte[s[0] * 3 + 2];
       if (s[0] < trns.size()) a = trns[s[0]];
       break;
@@ -132,7 +150,7 @@ static bool load_tga(const std::vector<uint8_t> &f, std::vector<uint32_t> &px, s
 {
   if (f.size() < 18 || f[1] != 0 || (f[2] != 2 && f[2] != 3)) return false;
   const size_t width = f[12] | (f[13] << 8), height = f[14] | (f[15] << 8), bpp = f[16] / 8;
-  if ((bpp != 1 && bpp != 3 && bpp != 4) || f.size() < 18 + f[0] + width * height * bpp) return false;
+  if ((bpp != 1 && bpp != 3 && bpp != 4) || width == 0 || height == 0 || f.size() < 18 + f[0] + width * height * bpp) return false;
   const uint8_t *s = &f[18 + f[0]];
   const bool topDown = (f[17] & 0x20) != 0;
   px.resize(width * height);
@@ -159,7 +177,7 @@ static bool load_ppm(const std::vector<uint8_t> &f, std::vector<uint32_t> &px, s
     vals[n++] = v;
   }
   pos++;
-  if (n != 3 || vals[2] != 255 || f.size() < pos + vals[0] * vals[1] * 3) return false;
+  if (n != 3 || vals[2] != 255 || vals[0] == 0 || vals[1] == 0 || vals[0] > kMaxPixels || vals[1] > kMaxPixels || vals[0] * vals[1] > kMaxPixels || f.size() < pos + vals[0] * vals[1] * 3) return false;
   w = vals[0]; h = vals[1]; channels = 3;
   px.resize(w * h);
   for (size_t i = 0; i < px.size(); i++) px[i] = f[pos + 3 * i] | (f[pos + 3 * i + 1] << 8) | (f[pos + 3 * i + 2] << 16) | 0xFF000000u;
@@ -169,7 +187,9 @@ static bool load_ppm(const std::vector<uint8_t> &f, std::vector<uint32_t> &px, s
 static bool load_image(const char *path, std::vector<uint32_t> &px, size_t &w, size_t &h, int &channels)
 {
   std::vector<uint8_t> f;
+  g_loadError = "cannot read the file";
   if (!read_file(path, f)) return false;
+  g_loadError = "not an 8-bit PNG, binary PPM or uncompressed TGA";
   return load_png(f, px, w, h, channels) || load_ppm(f, px, w, h, channels) || load_tga(f, px, w, h, channels);
 }
 
@@ -198,258 +218,288 @@ static bool write_tga(const std::string &path, size_t w, size_t h, int comp, con
   return ok;
 }
 
-static uint64_t ParseUInt(const char *text)
+// ---- command line -------------------------------------------------------------------------------------------------------------------
+// Option names and report lines are upstream's interface (src/main.cpp:75-86 and its printf formats) and are reproduced; the program around them is this file's own.
+struct Options
 {
-  uint64_t ret = 0;
-  for (; *text >= '0' && *text <= '9'; text++) ret = ret * 10 + (uint64_t)(*text - '0');
-  return ret;
-}
-
-static const char Arg_NoWrite[] = "--no-output";
-static const char Arg_ErrorFactor[] = "--error-factor";
-static const char Arg_AccurateBitCrushing[] = "--accurate-bit-crushing";
-static const char Arg_SingleThreaded[] = "--single-thread";
-static const char Arg_ListCount[] = "--count";
-static const char Arg_List[] = "--";
-static const char Arg_Threads[] = "--threads";
-static const char Arg_OutDir[] = "--out-dir";
-static const char Arg_Stream[] = "--stream";
-static const char Arg_FixedBlocks[] = "--fixed-blocks";
-
-// src/main.cpp:46-54: colours the block-index plane for viewing
-static int32_t Hash(const int32_t value)
-{
-  const uint64_t oldstate = value * 6364136223846793005ULL + (value | 1);
-  const uint32_t xorshifted = (uint32_t)(((oldstate >> 18) ^ oldstate) >> 27);
-  const uint32_t rot = (uint32_t)(oldstate >> 59);
-  return (int32_t)((xorshifted >> rot) | (xorshifted << (uint32_t)((-(int32_t)rot) & 31)));
-}
-
-int main(const int argc, const char **pArgv)
-{
-  if (argc == 1)
-    FAIL(EXIT_SUCCESS, "Usage:\nlimg_hip_cli [<InputFile> | --] [%s | %s <Factor> | %s | %s | %s | %s <T> | %s <dir> | %s <file>] \n  if input file is --:\n    [%s <Count>] -- <list of files>)\n",
-         Arg_NoWrite, Arg_ErrorFactor, Arg_AccurateBitCrushing, Arg_SingleThreaded, Arg_FixedBlocks, Arg_Threads, Arg_OutDir, Arg_Stream, Arg_ListCount);
-
-  // extra mode: limg_hip_cli --decode <file.lmg3> [<out.tga>]   (limg_decode of a compact stream written by --stream)
-  if (!strcmp(pArgv[1], "--decode"))
-  {
-    if (argc < 3) FAIL(EXIT_FAILURE, "Usage: limg_hip_cli --decode <file.lmg3> [<out.tga>]\n");
-    std::vector<uint8_t> stream;
-    if (!read_file(pArgv[2], stream)) FAIL(EXIT_FAILURE, "Failed to read '%s'.\n", pArgv[2]);
-    size_t sx = 0, sy = 0;
-    bool alpha = false;
-    limg_result r = limg_decode_info(stream.data(), stream.size(), &sx, &sy, &alpha);
-    if (r != limg_success) FAIL(EXIT_FAILURE, "'%s' is not an LMG3 stream (0x%" PRIX32 ").\n", pArgv[2], (uint32_t)r);
-    std::vector<uint32_t> image(sx * sy);
-    r = limg_decode(stream.data(), stream.size(), image.data(), image.size());
-    if (r != limg_success) FAIL(EXIT_FAILURE, "limg_decode failed with exit code 0x%" PRIX32 ".\n", (uint32_t)r);
-    const std::string out = argc > 3 ? pArgv[3] : "limg_out.tga";
-    printf("%" PRIu64 " x %" PRIu64 " pixels, %s.\n", (uint64_t)sx, (uint64_t)sy, alpha ? "RGBA" : "RGB");
-    puts(write_tga(out, sx, sy, 4, image.data()) ? "Wrote decoded file." : "Failed to write decoded file.");
-    return EXIT_SUCCESS;
-  }
-
-  const char *sourceImagePath = pArgv[1];
-  bool writeEncodedImages = true, fastBitCrushing = true, useThreadPool = true, fixedBlocks = false;
+  enum Mode { SingleFile, BenchmarkOneFile, BenchmarkList } mode = SingleFile;
+  std::vector<std::string> files;
+  bool writeImages = true, fastBitCrushing = true, usePool = true, fixedBlocks = false;
   uint32_t errorFactor = 100;
-  size_t listCount = 1, threads = std::thread::hardware_concurrency();
+  size_t repeat = 1, threads = 0;
   std::string outDir = ".", streamPath;
-  if (threads == 0) threads = 1;
+};
 
-  int argIndex = 2;
-  while (argc - argIndex > 0)
+static const char *const kUsage =
+    "Usage:\nlimg_hip_cli [<InputFile> | --] [--no-output | --error-factor <Factor> | --accurate-bit-crushing | --single-thread | --fixed-blocks | --threads <T> | --out-dir <dir> | "
+    "--stream <file>] \n  if input file is --:\n    [--count <Count>] -- <list of files>)\n";
+
+static bool parse_number(const char *text, uint64_t &value)
+{
+  if (*text < '0' || *text > '9') return false;
+  value = 0;
+  for (; *text >= '0' && *text <= '9'; text++) value = value * 10 + (uint64_t)(*text - '0');
+  return true; // trailing characters are ignored, as upstream's parser does
+}
+
+// Returns false after printing the reason.  Grammar: the first argument is the input file or "--" (list mode); flags follow in any order; in list mode a second
+// "--" ends the flags and the rest are files.
+static bool parse_args(int argc, const char **argv, Options &o)
+{
+  const bool listMode = !strcmp(argv[1], "--");
+  if (!listMode) o.files.push_back(argv[1]);
+  int i = 2;
+  bool sawSeparator = false;
+  for (; i < argc && !sawSeparator; i++)
   {
-    const int remaining = argc - argIndex;
-    const char *a = pArgv[argIndex];
-    if (!strcmp(a, Arg_NoWrite)) { argIndex++; writeEncodedImages = false; }
-    else if (!strcmp(a, Arg_AccurateBitCrushing)) { argIndex++; fastBitCrushing = false; }
-    else if (!strcmp(a, Arg_SingleThreaded)) { argIndex++; useThreadPool = false; }
-    else if (!strcmp(a, Arg_FixedBlocks)) { argIndex++; fixedBlocks = true; }
-    else if (remaining >= 2 && !strcmp(a, Arg_ErrorFactor)) { errorFactor = (uint32_t)ParseUInt(pArgv[argIndex + 1]); argIndex += 2; }
-    else if (remaining >= 2 && !strcmp(a, Arg_Threads)) { threads = (size_t)ParseUInt(pArgv[argIndex + 1]); argIndex += 2; if (!threads) useThreadPool = false; }
-    else if (remaining >= 2 && !strcmp(a, Arg_OutDir)) { outDir = pArgv[argIndex + 1]; argIndex += 2; }
-    else if (remaining >= 2 && !strcmp(a, Arg_Stream)) { streamPath = pArgv[argIndex + 1]; argIndex += 2; }
-    else if (remaining > 1 && !strcmp(a, Arg_List))
+    const std::string a = argv[i];
+    const bool hasValue = i + 1 < argc;
+    uint64_t v = 0;
+    if (a == "--no-output") o.writeImages = false;
+    else if (a == "--accurate-bit-crushing") o.fastBitCrushing = false;
+    else if (a == "--single-thread") o.usePool = false;
+    else if (a == "--fixed-blocks") o.fixedBlocks = true;
+    else if (a == "--error-factor" && hasValue && parse_number(argv[i + 1], v)) { o.errorFactor = (uint32_t)v; i++; }
+    else if (a == "--threads" && hasValue && parse_number(argv[i + 1], v)) { o.threads = (size_t)v; if (v == 0) o.usePool = false; i++; }
+    else if (a == "--out-dir" && hasValue) o.outDir = argv[++i];
+    else if (a == "--stream" && hasValue) o.streamPath = argv[++i];
+    else if ((a == "--count" || a == "--") && hasValue)
     {
-      if (strcmp(sourceImagePath, Arg_List) != 0) FAIL(EXIT_FAILURE, "'%s' is only supported with input file '%s', found '%s'.\n", a, Arg_List, sourceImagePath);
-      writeEncodedImages = false;
-      sourceImagePath = nullptr;
-      argIndex++;
-      break;
+      if (!listMode) { printf("'%s' is only supported with input file '--', found '%s'.\n", a.c_str(), argv[1]); return false; }
+      if (a == "--") sawSeparator = true;
+      else if (parse_number(argv[i + 1], v)) { o.repeat = (size_t)v; i++; }
+      else { printf("Invalid Parameter: '%s'. Aborting.\n", a.c_str()); return false; }
     }
-    else if (remaining > 1 && !strcmp(a, Arg_ListCount))
-    {
-      if (strcmp(sourceImagePath, Arg_List) != 0) FAIL(EXIT_FAILURE, "'%s' is only supported with input file '%s', found '%s'.\n", a, Arg_List, sourceImagePath);
-      listCount = (size_t)ParseUInt(pArgv[argIndex + 1]);
-      argIndex += 2;
-    }
-    else FAIL(EXIT_FAILURE, "Invalid Parameter: '%s'. Aborting.\n", a);
+    else { printf("Invalid Parameter: '%s'. Aborting.\n", a.c_str()); return false; }
   }
-  if (sourceImagePath && !strcmp(sourceImagePath, Arg_List)) FAIL(EXIT_FAILURE, "No files given after '%s'.\n", Arg_List);
-
-  limg_thread_pool *pThreadPool = useThreadPool ? limg_thread_pool_new(threads) : nullptr;
-
-  size_t pixels = 0, nanosecs = 0;
-  const bool singlePerfEval = sourceImagePath == nullptr && argc == argIndex + 1 && listCount > 1;
-
-  do
+  if (listMode)
   {
-    const char *filename = sourceImagePath;
-    if (filename == nullptr)
-    {
-      filename = pArgv[argIndex++];
-      if (!singlePerfEval) printf("\r'%s' (%d remaining) (~ %8.4f Mpx/s) ...", filename, argc - argIndex, (pixels * 1e-6) / (nanosecs * 1e-9f));
-    }
+    for (; i < argc; i++) o.files.push_back(argv[i]);
+    if (o.files.empty()) { printf("No files given after '--'.\n"); return false; }
+    o.writeImages = false;
+    o.mode = (o.files.size() == 1 && o.repeat > 1) ? Options::BenchmarkOneFile : Options::BenchmarkList;
+  }
+  if (o.threads == 0 && o.usePool) o.threads = limg_threading_max_threads() ? limg_threading_max_threads() : 1;
+  return true;
+}
 
-    std::vector<uint32_t> source;
-    size_t sizeX = 0, sizeY = 0;
-    int channels = 0;
-    if (!load_image(filename, source, sizeX, sizeY, channels)) FAIL(EXIT_FAILURE, "Failed to read source image from '%s'.\n", filename);
-    const bool hasAlpha = channels == 4;
-    const size_t count = sizeX * sizeY;
+struct Image
+{
+  std::vector<uint32_t> px;
+  size_t w = 0, h = 0;
+  bool hasAlpha = false;
+  size_t count() const { return w * h; }
+};
 
-    if (sourceImagePath != nullptr)
-    {
-      std::vector<uint32_t> target(count), planes32[7], blockIndex(count);
-      std::vector<uint8_t> fac[3], bitsPerPixel(count);
-      for (auto &p : planes32) p.assign(count, 0);
-      for (auto &p : fac) p.assign(count, 0);
-      printf("%" PRIu64 " x %" PRIu64 " pixels.\n", (uint64_t)sizeX, (uint64_t)sizeY);
+static void load_or_die(const std::string &path, Image &img)
+{
+  int channels = 0;
+  if (!load_image(path.c_str(), img.px, img.w, img.h, channels)) FAIL(EXIT_FAILURE, "Failed to read source image from '%s' (%s).\n", path.c_str(), g_loadError);
+  img.hasAlpha = channels == 4;
+}
 
-      limg_result result;
-      const int64_t before = CurrentTimeNs();
-      if (fixedBlocks)
-      {
-        limg_encode3d_info info;
-        info.pDecoded = target.data(); info.pShiftABCX = planes32[0].data();
-        info.pColAMin = planes32[1].data(); info.pColAMax = planes32[2].data(); info.pColBMin = planes32[3].data(); info.pColBMax = planes32[4].data();
-        info.pColCMin = planes32[5].data(); info.pColCMax = planes32[6].data();
-        info.pFactorsA = fac[0].data(); info.pFactorsB = fac[1].data(); info.pFactorsC = fac[2].data();
-        result = limg_encode3d_test(source.data(), sizeX, sizeY, hasAlpha, &info, errorFactor, pThreadPool, fastBitCrushing);
-      }
-      else
-      {
-        limg_blocked_encode3d_info info;
-        info.pDecoded = target.data(); info.pShiftABCX = planes32[0].data();
-        info.pColAMin = planes32[1].data(); info.pColAMax = planes32[2].data(); info.pColBMin = planes32[3].data(); info.pColBMax = planes32[4].data();
-        info.pColCMin = planes32[5].data(); info.pColCMax = planes32[6].data();
-        info.pFactorsA = fac[0].data(); info.pFactorsB = fac[1].data(); info.pFactorsC = fac[2].data();
-        info.pBlockError = nullptr; info.pBitsPerPixel = bitsPerPixel.data(); info.pBlockIndex = blockIndex.data();
-        result = limg_blocked_encode3d_test(source.data(), sizeX, sizeY, hasAlpha, &info, errorFactor, pThreadPool, fastBitCrushing);
-      }
-      const int64_t after = CurrentTimeNs();
+// view colours for the block-index plane: any integer mix will do (upstream hashes the index with a PCG step, src/main.cpp:46-54; the raw plane is what is compared)
+static uint32_t index_colour(uint32_t v)
+{
+  v ^= v >> 16; v *= 0x7FEB352Du; v ^= v >> 15; v *= 0x846CA68Bu; v ^= v >> 16;
+  return v | 0xFF000000u;
+}
 
-      printf("limg_encode_test completed with exit code 0x%" PRIX32 ".\n", (uint32_t)result);
-      printf("Elapsed Time: %f ms\n", (after - before) * 1e-6);
-      printf("Throughput: %f Mpx/s\n", (count * 1e-6) / ((after - before) * 1e-9));
-      if (result != limg_success) FAIL(EXIT_FAILURE, "Encode failed with exit code 0x%" PRIX32 ".\n", (uint32_t)result);
-      if (!fixedBlocks)
-      {
-        uint64_t bits = 0;
-        for (size_t i = 0; i < count; i++) bits += bitsPerPixel[i];
-        printf("Compression Average: ~%7.4f bits per pixel\n", bits / (double)count); // upstream prints this from inside the library (src/limg.cpp:2433-2440)
-      }
+// every output plane of one encode, owned in one place
+struct Planes
+{
+  std::vector<uint32_t> decoded, shift, col[6], blockIndex;
+  std::vector<uint8_t> fac[3], bitsPerPixel;
+  explicit Planes(size_t n) : decoded(n), shift(n), blockIndex(n), bitsPerPixel(n)
+  {
+    for (auto &c : col) c.assign(n, 0);
+    for (auto &f : fac) f.assign(n, 0);
+  }
+  limg_encode3d_info fixed_info()
+  {
+    limg_encode3d_info i;
+    i.pDecoded = decoded.data(); i.pShiftABCX = shift.data();
+    i.pColAMin = col[0].data(); i.pColAMax = col[1].data(); i.pColBMin = col[2].data(); i.pColBMax = col[3].data(); i.pColCMin = col[4].data(); i.pColCMax = col[5].data();
+    i.pFactorsA = fac[0].data(); i.pFactorsB = fac[1].data(); i.pFactorsC = fac[2].data();
+    return i;
+  }
+  limg_blocked_encode3d_info merged_info()
+  {
+    limg_blocked_encode3d_info i;
+    i.pDecoded = decoded.data(); i.pShiftABCX = shift.data();
+    i.pColAMin = col[0].data(); i.pColAMax = col[1].data(); i.pColBMin = col[2].data(); i.pColBMax = col[3].data(); i.pColCMin = col[4].data(); i.pColCMax = col[5].data();
+    i.pFactorsA = fac[0].data(); i.pFactorsB = fac[1].data(); i.pFactorsC = fac[2].data();
+    i.pBlockError = nullptr; i.pBitsPerPixel = bitsPerPixel.data(); i.pBlockIndex = blockIndex.data();
+    return i;
+  }
+};
 
-      double mean, max;
-      const double psnr = limg_compare(source.data(), target.data(), sizeX, sizeY, hasAlpha, &mean, &max);
-      printf("\nImage Perceptual RGB(A) PSNR: %4.2f dB (mean: %5.3f => %7.5f%% | sqrt: %5.3f%%)\n\n", psnr, mean, (mean / max) * 100.0, (sqrt(mean) / sqrt(max)) * 100.0);
+static void write_planes(const Options &o, const Image &img, Planes &p)
+{
+  const std::string d = o.outDir + "/";
+  puts(write_tga(d + "limg_out.tga", img.w, img.h, 4, p.decoded.data()) ? "Wrote decoded file." : "Failed to write decoded file.");
+  static const char *const facNames[3] = { "limg_fac_a", "limg_fac_b", "limg_fac_c" };
+  for (int k = 0; k < 3; k++) write_tga(d + facNames[k] + ".tga", img.w, img.h, 1, p.fac[k].data());
+  write_tga(d + "limg_bits.tga", img.w, img.h, 4, p.shift.data());
+  static const char *const colNames[6] = { "limg_col_a_min", "limg_col_a_max", "limg_col_b_min", "limg_col_b_max", "limg_col_c_min", "limg_col_c_max" };
+  for (int k = 0; k < 6; k++) write_tga(d + colNames[k] + ".tga", img.w, img.h, 4, p.col[k].data());
+  if (o.fixedBlocks) return;
+  write_tga(d + "limg_bpp.tga", img.w, img.h, 1, p.bitsPerPixel.data());
+  write_tga(d + "limg_block_idx_raw.tga", img.w, img.h, 4, p.blockIndex.data());
+  for (uint32_t &v : p.blockIndex)
+    if (v >> 31) v = index_colour(v); // only indices with the top bit set are recoloured upstream too (src/main.cpp:264-267)
+  write_tga(d + "limg_block_idx.tga", img.w, img.h, 4, p.blockIndex.data());
+}
 
-      if (!streamPath.empty())
-      {
-        std::vector<uint8_t> stream(limg_encode_bound(sizeX, sizeY));
-        size_t bytes = 0;
-        limg_result r = limg_encode(source.data(), sizeX, sizeY, hasAlpha, stream.data(), stream.size(), &bytes, errorFactor, pThreadPool, fastBitCrushing);
-        if (r != limg_success) FAIL(EXIT_FAILURE, "limg_encode failed with exit code 0x%" PRIX32 ".\n", (uint32_t)r);
-        std::vector<uint32_t> again(count);
-        r = limg_decode(stream.data(), bytes, again.data(), again.size());
-        if (r != limg_success) FAIL(EXIT_FAILURE, "limg_decode failed with exit code 0x%" PRIX32 ".\n", (uint32_t)r);
-        // the stream belongs to the fixed-8x8 path: compare with that path's decoded image
-        std::vector<uint32_t> fixedDecoded;
-        if (!fixedBlocks)
-        {
-          std::vector<uint32_t> tmp32[7];
-          std::vector<uint8_t> tmp8[3];
-          fixedDecoded.assign(count, 0);
-          for (auto &p : tmp32) p.assign(count, 0);
-          for (auto &p : tmp8) p.assign(count, 0);
-          limg_encode3d_info fi;
-          fi.pDecoded = fixedDecoded.data(); fi.pShiftABCX = tmp32[0].data(); fi.pColAMin = tmp32[1].data(); fi.pColAMax = tmp32[2].data(); fi.pColBMin = tmp32[3].data();
-          fi.pColBMax = tmp32[4].data(); fi.pColCMin = tmp32[5].data(); fi.pColCMax = tmp32[6].data(); fi.pFactorsA = tmp8[0].data(); fi.pFactorsB = tmp8[1].data(); fi.pFactorsC = tmp8[2].data();
-          r = limg_encode3d_test(source.data(), sizeX, sizeY, hasAlpha, &fi, errorFactor, pThreadPool, fastBitCrushing);
-          if (r != limg_success) FAIL(EXIT_FAILURE, "limg_encode3d_test failed with exit code 0x%" PRIX32 ".\n", (uint32_t)r);
-        }
-        const bool same = memcmp(again.data(), fixedBlocks ? target.data() : fixedDecoded.data(), count * 4) == 0;
-        printf("Stream: %" PRIu64 " bytes (%5.3f bits per pixel); decoding it %s the decoded image.\n", (uint64_t)bytes, bytes * 8.0 / count, same ? "reproduces" : "DOES NOT reproduce");
-        FILE *f = fopen(streamPath.c_str(), "wb");
-        if (!f || fwrite(stream.data(), 1, bytes, f) != bytes) FAIL(EXIT_FAILURE, "Failed to write '%s'.\n", streamPath.c_str());
-        fclose(f);
-        if (!same) return EXIT_FAILURE;
-      }
+// `--stream`: the compact stream belongs to the fixed-8x8 path, so its decode is checked against that path's image
+static bool write_and_check_stream(const Options &o, const Image &img, limg_thread_pool *pool, const std::vector<uint32_t> *fixedDecoded)
+{
+  std::vector<uint8_t> stream(limg_encode_bound(img.w, img.h));
+  size_t bytes = 0;
+  limg_result r = limg_encode(img.px.data(), img.w, img.h, img.hasAlpha, stream.data(), stream.size(), &bytes, o.errorFactor, pool, o.fastBitCrushing);
+  if (r != limg_success) FAIL(EXIT_FAILURE, "limg_encode failed with exit code 0x%" PRIX32 ".\n", (uint32_t)r);
+  std::vector<uint32_t> again(img.count());
+  r = limg_decode(stream.data(), bytes, again.data(), again.size());
+  if (r != limg_success) FAIL(EXIT_FAILURE, "limg_decode failed with exit code 0x%" PRIX32 ".\n", (uint32_t)r);
+  std::vector<uint32_t> own;
+  if (!fixedDecoded)
+  {
+    Planes tmp(img.count());
+    limg_encode3d_info fi = tmp.fixed_info();
+    r = limg_encode3d_test(img.px.data(), img.w, img.h, img.hasAlpha, &fi, o.errorFactor, pool, o.fastBitCrushing);
+    if (r != limg_success) FAIL(EXIT_FAILURE, "limg_encode3d_test failed with exit code 0x%" PRIX32 ".\n", (uint32_t)r);
+    own.swap(tmp.decoded);
+    fixedDecoded = &own;
+  }
+  const bool same = memcmp(again.data(), fixedDecoded->data(), img.count() * 4) == 0;
+  printf("Stream: %" PRIu64 " bytes (%5.3f bits per pixel); decoding it %s the decoded image.\n", (uint64_t)bytes, bytes * 8.0 / img.count(), same ? "reproduces" : "DOES NOT reproduce");
+  FILE *f = fopen(o.streamPath.c_str(), "wb");
+  if (!f || fwrite(stream.data(), 1, bytes, f) != bytes) FAIL(EXIT_FAILURE, "Failed to write '%s'.\n", o.streamPath.c_str());
+  fclose(f);
+  return same;
+}
 
-      if (writeEncodedImages)
-      {
-        puts(write_tga(outDir + "/limg_out.tga", sizeX, sizeY, 4, target.data()) ? "Wrote decoded file." : "Failed to write decoded file.");
-        write_tga(outDir + "/limg_fac_a.tga", sizeX, sizeY, 1, fac[0].data());
-        write_tga(outDir + "/limg_fac_b.tga", sizeX, sizeY, 1, fac[1].data());
-        write_tga(outDir + "/limg_fac_c.tga", sizeX, sizeY, 1, fac[2].data());
-        static const char *names[7] = { "limg_bits", "limg_col_a_min", "limg_col_a_max", "limg_col_b_min", "limg_col_b_max", "limg_col_c_min", "limg_col_c_max" };
-        for (int i = 0; i < 7; i++) write_tga(outDir + "/" + names[i] + ".tga", sizeX, sizeY, 4, planes32[i].data());
-        if (!fixedBlocks)
-        {
-          write_tga(outDir + "/limg_bpp.tga", sizeX, sizeY, 1, bitsPerPixel.data());
-          write_tga(outDir + "/limg_block_idx_raw.tga", sizeX, sizeY, 4, blockIndex.data());
-          for (size_t i = 0; i < count; i++) // src/main.cpp:264-267
-            if (blockIndex[i] & ((uint32_t)1 << 31)) blockIndex[i] = (uint32_t)Hash((int32_t)blockIndex[i]) | 0xFF000000;
-          write_tga(outDir + "/limg_block_idx.tga", sizeX, sizeY, 4, blockIndex.data());
-        }
-      }
-    }
-    else if (singlePerfEval)
-    {
-      std::vector<uint64_t> timeNs(listCount);
-      uint64_t timeSum = 0, min = UINT64_MAX, max = 0;
-      const double megapixels = count * 1e-6;
-      printf("\rDry Run...");
-      limg_result result = limg_encode3d_test_perf(source.data(), sizeX, sizeY, hasAlpha, errorFactor, pThreadPool, fastBitCrushing);
-      if (result != limg_success) FAIL(EXIT_FAILURE, "Encode failed with exit code 0x%" PRIX32 ".\n", (uint32_t)result);
-      for (size_t i = 0; i < listCount; i++)
-      {
-        const int64_t before = CurrentTimeNs();
-        result = limg_encode3d_test_perf(source.data(), sizeX, sizeY, hasAlpha, errorFactor, pThreadPool, fastBitCrushing);
-        const int64_t after = CurrentTimeNs();
-        if (result != limg_success) FAIL(EXIT_FAILURE, "Encode failed with exit code 0x%" PRIX32 ".\n", (uint32_t)result);
-        timeNs[i] = (uint64_t)(after - before);
-        timeSum += timeNs[i];
-        if (timeNs[i] > max) max = timeNs[i];
-        if (timeNs[i] < min) min = timeNs[i];
-        printf("\rThroughput: ~%5.3f Mpx/s", megapixels / (timeNs[i] * 1e-9));
-      }
-      const double mean = timeSum / (double)listCount;
-      double std_dev = 0;
-      for (size_t i = 0; i < listCount; i++) { const double d = timeNs[i] - mean; std_dev += d * d; }
-      std_dev = sqrt(std_dev / (double)(listCount - 1));
-      printf("\rMean Elapsed Time: %8.4f ms (%8.4f - %8.4f ms | %8.4f - %8.4f ms std dev)\n", mean * 1e-6, min * 1e-6, max * 1e-6, (mean - std_dev) * 1e-6, (mean + std_dev) * 1e-6);
-      printf("Throughput: %5.3f Mpx/s (%5.3f - %5.3f Mpx/s | %5.3f - %5.3f Mpx/s std dev)\n", megapixels / (mean * 1e-9), megapixels / (max * 1e-9), megapixels / (min * 1e-9),
-             megapixels / ((mean + std_dev) * 1e-9), megapixels / ((mean - std_dev) * 1e-9));
-    }
-    else
-    {
-      const int64_t before = CurrentTimeNs();
-      for (size_t i = 0; i < listCount; i++)
-      {
-        const limg_result result = limg_encode3d_test_perf(source.data(), sizeX, sizeY, hasAlpha, errorFactor, pThreadPool, fastBitCrushing);
-        if (result != limg_success) FAIL(EXIT_FAILURE, "Encode failed with exit code 0x%" PRIX32 ".\n", (uint32_t)result);
-      }
-      const int64_t after = CurrentTimeNs();
-      pixels += count * listCount;
-      nanosecs += (size_t)(after - before);
-    }
-  } while (sourceImagePath == nullptr && argIndex < argc);
-
-  if (sourceImagePath == nullptr && !singlePerfEval)
-    printf("\rComplete.   \nProcessed %5.3f Mpx in %5.3f sec / %5.3f mins \nThroughput: %8.5f MPx/s\n\n\n", pixels * 1e-6, nanosecs * 1e-9, (nanosecs * 1e-9) / 60.0, (pixels * 1e-6) / (nanosecs * 1e-9));
-
-  limg_thread_pool_destroy(&pThreadPool);
+// single-file mode (src/main.cpp:235-267, :342-370): the merged-block encoder like upstream, or the fixed 8x8 path with --fixed-blocks
+static int run_single_file(const Options &o, limg_thread_pool *pool)
+{
+  Image img;
+  load_or_die(o.files[0], img);
+  Planes p(img.count());
+  printf("%" PRIu64 " x %" PRIu64 " pixels.\n", (uint64_t)img.w, (uint64_t)img.h);
+  const int64_t t0 = CurrentTimeNs();
+  limg_result result;
+  if (o.fixedBlocks)
+  {
+    limg_encode3d_info info = p.fixed_info();
+    result = limg_encode3d_test(img.px.data(), img.w, img.h, img.hasAlpha, &info, o.errorFactor, pool, o.fastBitCrushing);
+  }
+  else
+  {
+    limg_blocked_encode3d_info info = p.merged_info();
+    result = limg_blocked_encode3d_test(img.px.data(), img.w, img.h, img.hasAlpha, &info, o.errorFactor, pool, o.fastBitCrushing);
+  }
+  const double seconds = (CurrentTimeNs() - t0) * 1e-9;
+  printf("limg_encode_test completed with exit code 0x%" PRIX32 ".\n", (uint32_t)result);
+  printf("Elapsed Time: %f ms\n", seconds * 1e3);
+  printf("Throughput: %f Mpx/s\n", img.count() * 1e-6 / seconds);
+  if (result != limg_success) FAIL(EXIT_FAILURE, "Encode failed with exit code 0x%" PRIX32 ".\n", (uint32_t)result);
+  if (!o.fixedBlocks)
+  { // upstream prints this from inside the library (src/limg.cpp:2433-2440)
+    uint64_t bits = 0;
+    for (const uint8_t b : p.bitsPerPixel) bits += b;
+    printf("Compression Average: ~%7.4f bits per pixel\n", bits / (double)img.count());
+  }
+  double mse = 0, maxError = 0;
+  const double psnr = limg_compare(img.px.data(), p.decoded.data(), img.w, img.h, img.hasAlpha, &mse, &maxError);
+  printf("\nImage Perceptual RGB(A) PSNR: %4.2f dB (mean: %5.3f => %7.5f%% | sqrt: %5.3f%%)\n\n", psnr, mse, (mse / maxError) * 100.0, (sqrt(mse) / sqrt(maxError)) * 100.0);
+  if (!o.streamPath.empty() && !write_and_check_stream(o, img, pool, o.fixedBlocks ? &p.decoded : nullptr)) return EXIT_FAILURE;
+  if (o.writeImages) write_planes(o, img, p);
   return EXIT_SUCCESS;
+}
+
+static void perf_or_die(const Options &o, const Image &img, limg_thread_pool *pool)
+{
+  const limg_result r = limg_encode3d_test_perf(img.px.data(), img.w, img.h, img.hasAlpha, o.errorFactor, pool, o.fastBitCrushing);
+  if (r != limg_success) FAIL(EXIT_FAILURE, "Encode failed with exit code 0x%" PRIX32 ".\n", (uint32_t)r);
+}
+
+// `-- --count N -- file`: N timed runs of limg_encode3d_test_perf after a dry run, with upstream's statistics lines (src/main.cpp:278-323)
+static int run_benchmark_one_file(const Options &o, limg_thread_pool *pool)
+{
+  Image img;
+  load_or_die(o.files[0], img);
+  const double megapixels = img.count() * 1e-6;
+  printf("\rDry Run...");
+  perf_or_die(o, img, pool);
+  std::vector<double> ns(o.repeat);
+  for (double &t : ns)
+  {
+    const int64_t t0 = CurrentTimeNs();
+    perf_or_die(o, img, pool);
+    t = (double)(CurrentTimeNs() - t0);
+    printf("\rThroughput: ~%5.3f Mpx/s", megapixels / (t * 1e-9));
+  }
+  double sum = 0, lo = ns[0], hi = ns[0], var = 0;
+  for (const double t : ns) { sum += t; lo = t < lo ? t : lo; hi = t > hi ? t : hi; }
+  const double mean = sum / ns.size();
+  for (const double t : ns) var += (t - mean) * (t - mean);
+  const double dev = sqrt(var / (double)(ns.size() - 1));
+  printf("\rMean Elapsed Time: %8.4f ms (%8.4f - %8.4f ms | %8.4f - %8.4f ms std dev)\n", mean * 1e-6, lo * 1e-6, hi * 1e-6, (mean - dev) * 1e-6, (mean + dev) * 1e-6);
+  printf("Throughput: %5.3f Mpx/s (%5.3f - %5.3f Mpx/s | %5.3f - %5.3f Mpx/s std dev)\n", megapixels / (mean * 1e-9), megapixels / (hi * 1e-9), megapixels / (lo * 1e-9),
+         megapixels / ((mean + dev) * 1e-9), megapixels / ((mean - dev) * 1e-9));
+  return EXIT_SUCCESS;
+}
+
+// `-- [--count N] -- files...`: every file N times through limg_encode3d_test_perf, one running total (src/main.cpp:325-339, :414-417)
+static int run_benchmark_list(const Options &o, limg_thread_pool *pool)
+{
+  double pixels = 0, seconds = 0;
+  for (size_t k = 0; k < o.files.size(); k++)
+  {
+    printf("\r'%s' (%d remaining) (~ %8.4f Mpx/s) ...", o.files[k].c_str(), (int)(o.files.size() - k - 1), seconds > 0 ? pixels * 1e-6 / seconds : 0.0);
+    Image img;
+    load_or_die(o.files[k], img);
+    const int64_t t0 = CurrentTimeNs();
+    for (size_t i = 0; i < o.repeat; i++) perf_or_die(o, img, pool);
+    seconds += (CurrentTimeNs() - t0) * 1e-9;
+    pixels += (double)img.count() * (double)o.repeat;
+  }
+  printf("\rComplete.   \nProcessed %5.3f Mpx in %5.3f sec / %5.3f mins \nThroughput: %8.5f MPx/s\n\n\n", pixels * 1e-6, seconds, seconds / 60.0, pixels * 1e-6 / seconds);
+  return EXIT_SUCCESS;
+}
+
+// extra mode: limg_hip_cli --decode <file.lmg3> [<out.tga>]   (limg_decode of a compact stream written by --stream)
+static int run_decode(int argc, const char **argv)
+{
+  if (argc < 3) FAIL(EXIT_FAILURE, "Usage: limg_hip_cli --decode <file.lmg3> [<out.tga>]\n");
+  std::vector<uint8_t> stream;
+  if (!read_file(argv[2], stream)) FAIL(EXIT_FAILURE, "Failed to read '%s'.\n", argv[2]);
+  size_t sx = 0, sy = 0;
+  bool alpha = false;
+  limg_result r = limg_decode_info(stream.data(), stream.size(), &sx, &sy, &alpha);
+  if (r != limg_success) FAIL(EXIT_FAILURE, "'%s' is not an LMG3 stream (0x%" PRIX32 ").\n", argv[2], (uint32_t)r);
+  std::vector<uint32_t> image(sx * sy);
+  r = limg_decode(stream.data(), stream.size(), image.data(), image.size());
+  if (r != limg_success) FAIL(EXIT_FAILURE, "limg_decode failed with exit code 0x%" PRIX32 ".\n", (uint32_t)r);
+  printf("%" PRIu64 " x %" PRIu64 " pixels, %s.\n", (uint64_t)sx, (uint64_t)sy, alpha ? "RGBA" : "RGB");
+  puts(write_tga(argc > 3 ? argv[3] : "limg_out.tga", sx, sy, 4, image.data()) ? "Wrote decoded file." : "Failed to write decoded file.");
+  return EXIT_SUCCESS;
+}
+
+int main(const int argc, const char **argv)
+{
+  if (argc == 1) FAIL(EXIT_SUCCESS, "%s", kUsage);
+  if (!strcmp(argv[1], "--decode")) return run_decode(argc, argv);
+  Options o;
+  if (!parse_args(argc, argv, o)) return EXIT_FAILURE;
+  limg_thread_pool *pool = o.usePool ? limg_thread_pool_new(o.threads) : nullptr;
+  int rc;
+  switch (o.mode)
+  {
+  case Options::SingleFile: rc = run_single_file(o, pool); break;
+  case Options::BenchmarkOneFile: rc = run_benchmark_one_file(o, pool); break;
+  default: rc = run_benchmark_list(o, pool); break;
+  }
+  limg_thread_pool_destroy(&pool);
+  return rc;
 }
