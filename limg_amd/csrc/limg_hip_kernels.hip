@@ -539,13 +539,14 @@ namespace limg_hip
     static_assert(kLdsTotal <= 32768 - 16, "5 workgroups per CU");
     // PREFIT (float stage done by k_fit_tpb): the parked-contribution area shrinks to the 6 KiB factor-byte staging area, and what sets the size is the F
     // step's overlay (26 KiB) => 6 workgroups per CU
-    struct LdsLayout { int v, blk, calls, total; };
+    struct LdsLayout { int v, blk, calls, trialc, total; };
+    constexpr int kTrialConstDw = 20; // per block: nA[3] nB[3] nC[3] mA[3] mB[3] mC[3] (+2 pad): the integer view of the record the packed trial multiplies with
     template <bool PREFIT> __device__ __host__ constexpr LdsLayout lds_layout()
     {
-      if (!PREFIT) return LdsLayout{ kLdsV, kLdsBlk, kLdsCalls, kLdsTotal };
-      const int v = kLdsStrip + 8 * kRowDw * 4, blk = v + 6144, calls = blk + kStripBlocks * 192, e = calls + 32;
+      if (!PREFIT) return LdsLayout{ kLdsV, kLdsBlk, kLdsCalls, kLdsV, kLdsTotal }; // (no trial-constant table in this layout)
+      const int v = kLdsStrip + 8 * kRowDw * 4, blk = v + 6144, calls = blk + kStripBlocks * 192, tc = calls + 32, e = tc + kStripBlocks * kTrialConstDw * 4;
       const int f = kLdsStrip + 6144 + 8192 + 6144 + 896 + 3072 + 128 + 128 + kStripBlocks * 48 + 16; // kPhaseFBytes + the F step's record copy
-      return LdsLayout{ v, blk, calls, e > f ? e : f };
+      return LdsLayout{ v, blk, calls, tc, e > f ? e : f };
     }
     static_assert(lds_layout<true>().total <= 163840 / 6, "6 workgroups per CU with the float stage in its own kernel");
 
@@ -567,6 +568,7 @@ namespace limg_hip
       float *s_V = reinterpret_cast<float *>(lds + LL.v);
       BlkF *s_blk = reinterpret_cast<BlkF *>(lds + LL.blk);
       uint32_t *s_calls = reinterpret_cast<uint32_t *>(lds + LL.calls);
+      int *s_trialc = reinterpret_cast<int *>(lds + LL.trialc);
 
       const int lane = tid & 63, wave = tid >> 6;
       const uint32_t strip = id % p.stripsX, by = id / p.stripsX;
@@ -903,6 +905,12 @@ namespace limg_hip
             BlkE *e = reinterpret_cast<BlkE *>(&blk[b]);
             e->nrm[f][slot_of(c)] = nrm[r]; e->off[f][slot_of(c)] = off[r]; // slot order x0 x2 x1 x3, see V4
             if (c == 0) e->invN[f] = invn[r];
+            if (PREFIT && c < 3)
+            { // the packed trial's integer operands, once per block here instead of per lane in phase E: n = max - min, m = (min << 8) + 128 (+ the R bias)
+              int *tc = s_trialc + (wave * kBlocksPerWave + b) * kTrialConstDw;
+              tc[f * 3 + c] = (int)nrm[r];
+              tc[9 + f * 3 + c] = ((int)off[r] << 8) + 128 + (c == 0 ? (kTermBias << 8) : 0);
+            }
           }
         }
       }
@@ -978,13 +986,26 @@ namespace limg_hip
             t.loRG = ((R - 255u) & 0xFFFFu) | ((G - 255u) << 16);
             t.pxB = (int)((px >> 16) & 0xFF);
             t.pxBlo = t.pxB - 255;
+            if (PREFIT)
+            { // uniform values, kept in VGPRs (they are operands of v_mad_i32_i24); prepared lane-parallel with the phase-E view above
+              const int *tc = s_trialc + sb * kTrialConstDw;
 #pragma unroll
-            for (int c = 0; c < 3; c++)
-            { // uniform values, kept in VGPRs: they are operands of v_mad_i32_i24
-              const int bias = c == 0 ? (kTermBias << 8) : 0;
-              const int loA = blkE->rec[c], hiA = blkE->rec[4 + c], loB = blkE->rec[8 + c], hiB = blkE->rec[12 + c], loC = blkE->rec[16 + c], hiC = blkE->rec[20 + c];
-              t.nA[c] = hiA - loA; t.nB[c] = hiB - loB; t.nC[c] = hiC - loC;
-              t.mA[c] = (loA << 8) + 128 + bias; t.mB[c] = (loB << 8) + 128 + bias; t.mC[c] = (loC << 8) + 128 + bias;
+              for (int c = 0; c < 3; c++)
+              {
+                t.nA[c] = tc[c]; t.nB[c] = tc[3 + c]; t.nC[c] = tc[6 + c];
+                t.mA[c] = tc[9 + c]; t.mB[c] = tc[12 + c]; t.mC[c] = tc[15 + c];
+              }
+            }
+            else
+            { // lane == pixel float stage: no LDS left over for the table (other waves' parked contributions are still live when this wave gets here)
+#pragma unroll
+              for (int c = 0; c < 3; c++)
+              {
+                const int bias = c == 0 ? (kTermBias << 8) : 0;
+                const int loA = blkE->rec[c], hiA = blkE->rec[4 + c], loB = blkE->rec[8 + c], hiB = blkE->rec[12 + c], loC = blkE->rec[16 + c], hiC = blkE->rec[20 + c];
+                t.nA[c] = hiA - loA; t.nB[c] = hiB - loB; t.nC[c] = hiC - loC;
+                t.mA[c] = (loA << 8) + 128 + bias; t.mB[c] = (loB << 8) + 128 + bias; t.mC[c] = (loC << 8) + 128 + bias;
+              }
             }
             t.cA = t.cB = t.cC = 0xFFu;
             t.tA_RG = t.tB_RG = t.tC_RG = 0; t.tA_B = t.tB_B = t.tC_B = 0;
