@@ -278,30 +278,35 @@ namespace limg_hip
     {
       uint32_t *dec = L.dec + wave * 512;
       uint8_t *out = L.out; // [3 planes][8 rows][256 px]: strip-wide rows, so that the stores below write whole 128-byte lines
-      // All noise bytes of the wave's 8 blocks are requested up front (up to 24 independent 64-byte loads in flight): fetched
-      // block by block, each block would expose a full memory round trip.
-      uint32_t nz8[kBlocksPerWave][3];
+      // The noise bytes are requested for a group of kNoiseGroup blocks at a time (up to 3 independent 64-byte loads per block in flight): fetched block by
+      // block, each block would expose a full memory round trip; all 8 at once (24 registers) pushes the kernel over the 80 VGPRs that 6 workgroups per CU allow.
+      constexpr int kNoiseGroup = 4;
 #pragma unroll
-      for (int b = 0; b < kBlocksPerWave; b++)
+      for (int g0 = 0; g0 < kBlocksPerWave; g0 += kNoiseGroup)
       {
-        const uint32_t sb = wave * kBlocksPerWave + b;
+      uint32_t nz8[kNoiseGroup][3];
+#pragma unroll
+      for (int bb = 0; bb < kNoiseGroup; bb++)
+      {
+        const uint32_t sb = wave * kBlocksPerWave + g0 + bb;
         const uint32_t w = (uint32_t)sgpr((int)L.shift[sb]);
         uint32_t call = (uint32_t)sgpr((int)L.first[sb]);
 #pragma unroll
         for (int k = 0; k < 3; k++)
         {
           const uint32_t s = (w >> (8 * k)) & 0xFF;
-          nz8[b][k] = 0;
+          nz8[bb][k] = 0;
           if (s != 0 && s != 8)
           {
-            nz8[b][k] = p.noise[(size_t)call * 64 + lane];
+            nz8[bb][k] = p.noise[(size_t)call * 64 + lane];
             call++;
           }
         }
       }
 #pragma unroll
-      for (int b = 0; b < kBlocksPerWave; b++)
+      for (int bb = 0; bb < kNoiseGroup; bb++)
       {
+        const int b = g0 + bb;
         const uint32_t sb = wave * kBlocksPerWave + b;
         const uint32_t bx = strip * kStripBlocks + sb;
         if (bx >= p.blocksX) continue;
@@ -322,7 +327,7 @@ namespace limg_hip
           const uint32_t s = shift[k];
           if (s != 0 && s != 8)
           { // src/limg.cpp:824-879: (lane16 & ditherSize) - ditherOffset, add, clamp, shift
-            int t = (int)v + ((int)(nz8[b][k] & ((1u << s) - 1u)) - (int)(1u << (s - 1)));
+            int t = (int)v + ((int)(nz8[bb][k] & ((1u << s) - 1u)) - (int)(1u << (s - 1)));
             t = t < 0 ? 0 : (t > 255 ? 255 : t);
             v = (uint32_t)t >> s;
           }
@@ -362,6 +367,7 @@ namespace limg_hip
           for (int k = 0; k < 3; k++) out[k * 2048 + o] = (uint8_t)(f[k] << shift[k]); // shift 8 => 0 (src/limg.cpp:2054-2062)
         }
       }
+      } // noise groups
       wave_lds_fence();
 
       const uint32_t wx0 = x0 + wave * 64;
