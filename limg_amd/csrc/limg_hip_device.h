@@ -14,7 +14,7 @@ namespace limg_hip
 {
   namespace
   {
-    __device__ const unsigned short d_rsqrt_x86_tab[2048] = LIMG_RSQRT_X86_TAB_INIT;
+    __device__ __attribute__((aligned(16))) const unsigned short d_rsqrt_x86_tab[2048] = LIMG_RSQRT_X86_TAB_INIT;
 
     enum : uint32_t { kZeroA = 1u, kZeroB = 2u, kZeroC = 4u, kValid = 8u };
 

@@ -26,8 +26,17 @@ namespace limg_hip
     __global__ __launch_bounds__(64) void k_fit_tpb(const EncodeParams p)
     {
       __shared__ __attribute__((aligned(16))) uint32_t s_px[64 * kTpbStride];
-      const unsigned short *tab = d_rsqrt_x86_tab;
+      // the RSQRTPS table in LDS: a per-lane gather of 64 unrelated 2-byte entries costs the texture path ~64 address cycles per wave instruction from global
+      // memory, but only a few LDS cycles (random banks); 4 KiB per wave => 7 waves per CU instead of 9, a good trade (measured)
+      __shared__ __attribute__((aligned(16))) unsigned short s_tab[FAST ? 8 : 2048];
       const int lane = (int)threadIdx.x;
+      if (!FAST)
+      {
+        const uint4 *src = reinterpret_cast<const uint4 *>(d_rsqrt_x86_tab);
+#pragma unroll
+        for (int i = 0; i < 4; i++) reinterpret_cast<uint4 *>(s_tab)[i * 64 + lane] = src[i * 64 + lane];
+      }
+      const unsigned short *tab = s_tab;
       const uint32_t unitsX = (p.blocksX + 63u) / 64u;
       const uint32_t unit = blockIdx.x % unitsX, by = blockIdx.x / unitsX;
       const uint32_t bx0 = unit * 64u, x0 = bx0 * kBlock, y0 = by * kBlock;
