@@ -245,7 +245,7 @@ namespace
     p.chainCallsOut = chainPhase == 1 ? dChainCalls : nullptr;
     p.chainBase = chainPhase == 2 ? dChainBase : nullptr;
     // The float stage as its own launch, one lane per block (limg_hip_fit_tpb.hip), wherever every block is a whole 8x8: the E step then starts from the records.
-    p.prefit = (!ragged && c->opt.legacy_float_stage == 0) ? 1 : 0;
+    p.prefit = (!ragged && c->opt.legacy_float_stage == 0 && (((uintptr_t)p.records) & 15u) == 0) ? 1 : 0; // k_fit_tpb stores records 16 bytes at a time
     if (p.prefit && chainPhase != 2)
     {
       mark(c, stream);
