@@ -117,6 +117,8 @@ namespace limg_hip
     // 24-bit integer multiplies (full rate; v_mul_lo_u32 is quarter rate).  Operands here always fit: see kRecordLimit.
     __device__ __forceinline__ int mul_i24(int a, int b) { int r; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
     __device__ __forceinline__ uint32_t mul_u24(uint32_t a, uint32_t b) { uint32_t r; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+    // same with a wave-uniform factor straight from its SGPR (src0 of the VOP2 form): no v_mov to bring it into a VGPR first
+    __device__ __forceinline__ uint32_t mul_u24_uniform(uint32_t a, uint32_t uniformB) { uint32_t r; asm("v_mul_u32_u24 %0, %2, %1" : "=v"(r) : "v"(a), "s"(uniformB)); return r; }
     __device__ __forceinline__ int med3_i32(int a, int b, int c) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
     __device__ __forceinline__ int mad_i24(int a, int b, int c) { int r; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 

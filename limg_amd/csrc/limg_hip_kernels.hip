@@ -76,7 +76,7 @@ namespace limg_hip
 
     __device__ __forceinline__ void make_terms(const uint32_t f, const uint32_t s, const int n[3], const int m[3], uint32_t &tRG, int &tB)
     {
-      const int d = (int)mul_u24(f >> s, shift_mul(s)); // <= 255 * 256
+      const int d = (int)mul_u24_uniform(f >> s, shift_mul(s)); // <= 255 * 256; the shift is wave-uniform in the packed trial
       const int t0 = mad_i24(d, n[0], m[0]), t1 = mad_i24(d, n[1], m[1]), t2 = mad_i24(d, n[2], m[2]);
       tRG = __builtin_amdgcn_perm((uint32_t)t1, (uint32_t)t0, 0x06050201u); // ((t1 >> 8) & 0xFFFF) << 16 | ((t0 >> 8) & 0xFFFF)
       tB = t2 >> 8;
