@@ -275,7 +275,7 @@ namespace
       if ((r = c->park.ensure((size_t)(c->persistentWorkgroups / 5 * 6) * 2 * 8192)) != limg_hip_success) return r;
       p.park = (uint8_t *)c->park.p;
       mark(c, stream);
-      launch_encode_persistent(p, channels, p.prefit ? c->persistentWorkgroups / 5 * 6 : c->persistentWorkgroups, stream); // 6 workgroups per CU fit once the float stage is out
+      launch_encode_persistent(p, channels, p.prefit ? c->persistentWorkgroups / 5 * 6 : c->persistentWorkgroups, stream); // 6 workgroups per CU once the float stage is out (7 fit and were measured: no faster, the kernel is issue-bound)
       mark(c, stream); mark(c, stream);
       if (!p.prefit) mark(c, stream); // 4 events per encode: with the float stage as its own launch the intervals are {k_fit_tpb, k_encode_persistent, -}
       HIP_TRY(hipGetLastError());

@@ -175,7 +175,7 @@ namespace limg_hip
     {
       uint8_t *fac;    // [3][8][256]  pre-dither factor bytes of the strip (plane-row layout)
       uint32_t *dec;   // [4 waves][8 rows][64]  decoded pixels
-      uint8_t *out;    // [4 waves][3][8 rows][64]  output factor bytes
+      uint8_t *out;    // == fac: a lane's output byte replaces the pre-dither byte it has just read (same index)
       uint32_t *cst;   // [7][32]  per-block constants of the 7 block-uniform planes
       int32_t *nm;     // [32 blocks][2][3][4]  effective integer normals / additive constants of the decode
       uint32_t *shift; // [32]  shift words
@@ -183,17 +183,17 @@ namespace limg_hip
       const int16_t *rec; // record of block sb at rec + sb * recStride
       int recStride;
     };
-    constexpr int kPhaseFBytes = 6144 + 8192 + 6144 + 896 + 3072 + 128 + 128;
+    constexpr int kPhaseFBytes = 6144 + 8192 + 896 + 3072 + 128 + 128; // the output factor bytes replace the pre-dither ones in place
 
     __device__ __forceinline__ StripLds carve_phase_f(uint8_t *base, const int16_t *rec, int recStride)
     {
       StripLds L;
       L.fac = base;
       L.dec = reinterpret_cast<uint32_t *>(base + 6144);
-      L.out = base + 6144 + 8192;
-      L.cst = reinterpret_cast<uint32_t *>(base + 6144 + 8192 + 6144);
-      L.nm = reinterpret_cast<int32_t *>(base + 6144 + 8192 + 6144 + 896);
-      L.shift = reinterpret_cast<uint32_t *>(base + 6144 + 8192 + 6144 + 896 + 3072);
+      L.out = base;
+      L.cst = reinterpret_cast<uint32_t *>(base + 6144 + 8192);
+      L.nm = reinterpret_cast<int32_t *>(base + 6144 + 8192 + 896);
+      L.shift = reinterpret_cast<uint32_t *>(base + 6144 + 8192 + 896 + 3072);
       L.first = L.shift + 32;
       L.rec = rec; L.recStride = recStride;
       return L;
@@ -551,10 +551,10 @@ namespace limg_hip
     {
       if (!PREFIT) return LdsLayout{ kLdsV, kLdsBlk, kLdsCalls, kLdsV, kLdsTotal }; // (no trial-constant table in this layout)
       const int v = kLdsStrip + 8 * kRowDw * 4, blk = v + 6144, calls = blk + kStripBlocks * 192, tc = calls + 32, e = tc + kStripBlocks * kTrialConstDw * 4;
-      const int f = kLdsStrip + 6144 + 8192 + 6144 + 896 + 3072 + 128 + 128 + kStripBlocks * 48 + 16; // kPhaseFBytes + the F step's record copy
+      const int f = kLdsStrip + kPhaseFBytes + kStripBlocks * 48 + 16; // the F step's overlay incl. its record copy
       return LdsLayout{ v, blk, calls, tc, e > f ? e : f };
     }
-    static_assert(lds_layout<true>().total <= 163840 / 6, "6 workgroups per CU with the float stage in its own kernel");
+    static_assert(lds_layout<true>().total <= 163840 / 7, "7 workgroups per CU with the float stage in its own kernel");
 
 
     // PERSIST == false: split path, the strip's call count goes to p.stripCalls for k_strip_scan.

@@ -48,9 +48,10 @@ def main():
         pcg = bool(rng.random() < 0.2)
         pool = int([0, 0, 0, 1, 2, 3][int(rng.integers(0, 6))])
         split = bool(rng.random() < 0.3)
-        recipe = dict(w=w, h=h, gen=gen, seed=seed, alpha=alpha, ef=ef, fast=fast, pcg=pcg, pool=pool, split=split)
+        legacy = bool(rng.random() < 0.25)  # float stage with lane == pixel inside the E step instead of k_fit_tpb
+        recipe = dict(w=w, h=h, gen=gen, seed=seed, alpha=alpha, ef=ef, fast=fast, pcg=pcg, pool=pool, split=split, legacy=legacy)
         kw = dict(error_factor=ef, fast=fast)
-        g.set_options(force_split=split, dither_pcg=pcg)
+        g.set_options(force_split=split, dither_pcg=pcg, legacy_float_stage=legacy)
         mode = ["fixed", "stream", "blocked"][int(rng.integers(0, 3))]
         if mode == "fixed":
             want = orc.encode3d(img, alpha, pool_threads=pool, dither_mode=int(pcg), **kw)
