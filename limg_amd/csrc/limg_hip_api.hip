@@ -228,6 +228,14 @@ namespace
     // 16-byte vector access straight on caller pointers only where the address is 16-byte aligned for every row: sliced or offset
     // device pointers take the dword paths
     p.vecIn = (sizeX % 4 == 0) && (((uintptr_t)dIn) & 15u) == 0;
+    p.vecPlanes = 0;
+    if (dInfo && fullPlanes && sizeX % 4 == 0)
+    {
+      uintptr_t bits = 0;
+      const void *const *pp = reinterpret_cast<const void *const *>(dInfo);
+      for (int i = 1; i < 8; i++) bits |= (uintptr_t)pp[i]; // pShiftABCX .. pColCMax
+      p.vecPlanes = (bits & 15u) == 0;
+    }
     p.vecFactors = dInfo && (sizeX % 16 == 0) && ((((uintptr_t)dInfo->pFactorsA) | ((uintptr_t)dInfo->pFactorsB) | ((uintptr_t)dInfo->pFactorsC)) & 15u) == 0;
     const int channels = hasAlpha ? 4 : 3;
     const bool ragged = (sizeX % kBlock) != 0 || (sizeY % kBlock) != 0;

@@ -53,6 +53,7 @@ namespace limg_hip
     int32_t prefit;     // host dispatch only: p.records already hold the fit (k_fit_tpb ran first)
     int32_t floatFast;  // host dispatch only: FAST float stage (limg_hip_options.float_mode = 1)
     int32_t vecIn;      // rows of pIn may be read 16 bytes per lane (sizeX % 4 == 0 and pIn 16-byte aligned); otherwise dword loads
+    int32_t vecPlanes;  // the seven block-uniform uint32 planes may be stored 16 bytes per lane (sizeX % 4 == 0 and all seven 16-byte aligned)
     int32_t vecFactors; // the three factor planes may be accessed 16 bytes per lane (sizeX % 16 == 0 and all three 16-byte aligned)
   };
 

@@ -253,13 +253,34 @@ namespace limg_hip
       }
     }
 
-    // the 7 block-uniform planes: 256 contiguous bytes (8 blocks x 8 px) per store instruction, straight from registers
+    // the 7 block-uniform planes, straight from registers: 16 bytes per lane = four rows of 256 contiguous bytes (8 blocks x 8 px) per store instruction where
+    // the rows allow it (p.vecPlanes: width a multiple of 4, 16-byte aligned planes), 4 bytes per lane = one row per instruction otherwise
     __device__ __forceinline__ void phase_f_store_const(const EncodeParams &p, const StripLds &L, uint32_t x0, uint32_t y0, uint32_t ry, int lane, int wave)
     {
       const uint32_t wx0 = x0 + wave * 64;
       if (wx0 >= p.sizeX) return;
       const uint32_t ww = min(p.sizeX - wx0, 64u);
       uint32_t *planes[7] = { p.info.pShiftABCX, p.info.pColAMin, p.info.pColAMax, p.info.pColBMin, p.info.pColBMax, p.info.pColCMin, p.info.pColCMax };
+      if (p.vecPlanes)
+      {
+        const uint32_t col = ((uint32_t)lane & 15u) * 4u, rsub = (uint32_t)lane >> 4; // 16 lanes per row, 4 rows per instruction
+        uint32_t cst[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) cst[k] = L.cst[k * kStripBlocks + wave * kBlocksPerWave + (col >> 3)];
+        if (col < ww)
+#pragma unroll
+          for (uint32_t half = 0; half < 2; half++)
+          {
+            const uint32_t row = half * 4 + rsub;
+            if (row < ry)
+            {
+              const size_t g = (size_t)(y0 + row) * p.sizeX + wx0 + col;
+#pragma unroll
+              for (int k = 0; k < 7; k++) *reinterpret_cast<uint4 *>(planes[k] + g) = make_uint4(cst[k], cst[k], cst[k], cst[k]);
+            }
+          }
+        return;
+      }
       uint32_t cst[7];
 #pragma unroll
       for (int k = 0; k < 7; k++) cst[k] = L.cst[k * kStripBlocks + wave * kBlocksPerWave + (lane >> 3)];
