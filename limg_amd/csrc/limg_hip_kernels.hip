@@ -82,23 +82,26 @@ namespace limg_hip
       tB = t2 >> 8;
     }
 
-    template <bool FULL>
-    __device__ __forceinline__ bool trial_packed(TrialState &t, const uint32_t sA, const uint32_t sB, const uint32_t sC, const bool active,
-                                                 const uint32_t maxPixel32, const uint32_t blockLimit, uint32_t &blockError)
+    // the three factors' cached terms, each rebuilt on demand (shift 8: f >> 8 == 0 => term == minA, as upstream; for B and C upstream zeroes min too,
+    // src/limg_bit_crush_simd.h:593-609)
+    __device__ __forceinline__ void rebuild_A(TrialState &t, const uint32_t sA) { make_terms(t.fA, sA, t.nA, t.mA, t.tA_RG, t.tA_B); t.cA = sA; }
+    __device__ __forceinline__ void rebuild_B(TrialState &t, const uint32_t sB)
     {
-      if (sA != t.cA) { make_terms(t.fA, sA, t.nA, t.mA, t.tA_RG, t.tA_B); t.cA = sA; } // shift 8: f >> 8 == 0 => term == minA, as upstream
-      if (sB != t.cB)
-      {
-        if (sB > 7) { t.tB_RG = (uint32_t)kTermBias; t.tB_B = 0; } // upstream zeroes minB / minC too (src/limg_bit_crush_simd.h:593-609)
-        else make_terms(t.fB, sB, t.nB, t.mB, t.tB_RG, t.tB_B);
-        t.cB = sB;
-      }
-      if (sC != t.cC)
-      {
-        if (sC > 7) { t.tC_RG = (uint32_t)kTermBias; t.tC_B = 0; }
-        else make_terms(t.fC, sC, t.nC, t.mC, t.tC_RG, t.tC_B);
-        t.cC = sC;
-      }
+      if (sB > 7) { t.tB_RG = (uint32_t)kTermBias; t.tB_B = 0; }
+      else make_terms(t.fB, sB, t.nB, t.mB, t.tB_RG, t.tB_B);
+      t.cB = sB;
+    }
+    __device__ __forceinline__ void rebuild_C(TrialState &t, const uint32_t sC)
+    {
+      if (sC > 7) { t.tC_RG = (uint32_t)kTermBias; t.tC_B = 0; }
+      else make_terms(t.fC, sC, t.nC, t.mC, t.tC_RG, t.tC_B);
+      t.cC = sC;
+    }
+
+    // the trial proper on the cached terms: clamp, differences, weighted squared error, pixel check, block sum
+    template <bool FULL>
+    __device__ __forceinline__ bool trial_core(const TrialState &t, const bool active, const uint32_t maxPixel32, const uint32_t blockLimit, uint32_t &blockError)
+    {
       const uint32_t estRG = t.tA_RG + t.tB_RG + t.tC_RG; // low half: R estimate + 3 * bias; no carry / borrow crosses the halves
       const int estB = t.tA_B + t.tB_B + t.tC_B;
       short2_t e = __builtin_bit_cast(short2_t, t.pxRGb) - __builtin_bit_cast(short2_t, estRG);
@@ -118,8 +121,21 @@ namespace limg_hip
       return be < blockLimit; // be * 16 < maxBlock * n, see phase E
     }
 
+    // a9 for callers that name the shift triple (accurate search): the terms of a factor are rebuilt when its shift differs from the cached one
+    template <bool FULL>
+    __device__ __forceinline__ bool trial_packed(TrialState &t, const uint32_t sA, const uint32_t sB, const uint32_t sC, const bool active,
+                                                 const uint32_t maxPixel32, const uint32_t blockLimit, uint32_t &blockError)
+    {
+      if (sA != t.cA) rebuild_A(t, sA);
+      if (sB != t.cB) rebuild_B(t, sB);
+      if (sC != t.cC) rebuild_C(t, sC);
+      return trial_core<FULL>(t, active, maxPixel32, blockLimit, blockError);
+    }
+
     // a10 + a11 as a table-driven automaton: one trial loop, the next two candidate states are fetched (scalar loads) while
-    // the current trial computes, and the outcome selects between them.
+    // the current trial computes, and the outcome selects between them.  The scalar side of the loop is kept minimal -- the scalar unit (one per CU) is a
+    // co-bottleneck of this kernel: 8 extra scalar instructions per trial cost 10 % (measured) -- so the table carries, per edge, WHICH factors the next triple
+    // changes (no compares against cached shifts), byte offsets (no shifts), and its base address stays in SGPRs.
     // scalar 8-byte load issued now, consumed after `sload_wait` (the compiler would otherwise sink the load to its use and
     // expose the scalar-cache latency on every trial)
     __device__ __forceinline__ uint64_t sload2(const uint2 *base, uint32_t byteOffset)
@@ -134,14 +150,20 @@ namespace limg_hip
     __device__ __forceinline__ void search_fast_automaton(TrialState &t, const bool active, const uint32_t maxPixel32, const uint32_t blockLimit, uint32_t shift[3])
     {
       const uint2 *tab = d_search_tab;
+      asm volatile("" : "+s"(tab)); // opaque: otherwise the address is rematerialised (s_getpc + 2 adds) in every iteration
       uint32_t ex = (uint32_t)sgpr((int)tab[0].x), ey = (uint32_t)sgpr((int)tab[0].y);
+      uint32_t chg = 7u; // nothing cached yet
       while (!(ex >> 31))
       {
-        uint64_t ep = sload2(tab, (ey & 0xFFFFu) << 3), ef = sload2(tab, (ey >> 16) << 3);
+        uint64_t ep = sload2(tab, ey & 0xFFFFu), ef = sload2(tab, ey >> 16);
+        if (chg & 1u) rebuild_A(t, ex & 15u);
+        if (chg & 2u) rebuild_B(t, (ex >> 4) & 15u);
+        if (chg & 4u) rebuild_C(t, (ex >> 8) & 15u);
         uint32_t be;
-        const bool ok = trial_packed<FULL>(t, ex & 15u, (ex >> 4) & 15u, (ex >> 8) & 15u, active, maxPixel32, blockLimit, be);
+        const bool ok = trial_core<FULL>(t, active, maxPixel32, blockLimit, be);
         sload_wait(ep, ef);
         const uint64_t e = ok ? ep : ef;
+        chg = ex >> (ok ? 12u : 15u); // bits 0..2; what lies above is never looked at
         ex = (uint32_t)e; ey = (uint32_t)(e >> 32);
       }
       shift[0] = ex & 15u; shift[1] = (ex >> 4) & 15u; shift[2] = (ex >> 8) & 15u;

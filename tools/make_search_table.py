@@ -120,6 +120,16 @@ def build():
 
 
 def encode(trans):
+    """entry = (word0, word1):
+       word0 = a | b << 4 | c << 8 | changed_on_pass << 12 | changed_on_fail << 15 | final << 31
+       word1 = byte offset of the next entry on pass | byte offset on fail << 16          (entries are 8 bytes)
+    changed_on_* = which of the three shifts (bit 0 = A, 1 = B, 2 = C) differ between this entry's triple and the successor's: the kernel keeps the terms of the
+    last evaluated triple and rebuilds exactly those factors -- no compares against cached shifts in its scalar instruction stream.  0 for a final successor."""
+    def changed(t, nxt):
+        if nxt[0] == "final":
+            return 0
+        u = nxt[0]
+        return sum(1 << k for k in range(3) if t[k] != u[k])
     words = []
     for t in trans:
         if t[0] == "final":
@@ -127,19 +137,31 @@ def encode(trans):
             words.append((a | (b << 4) | (c << 8) | (1 << 31), 0))
         else:
             (a, b, c), p, f = t
-            assert p < 65536 and f < 65536
-            words.append((a | (b << 4) | (c << 8), p | (f << 16)))
+            assert p * 8 < 65536 and f * 8 < 65536
+            words.append((a | (b << 4) | (c << 8) | (changed((a, b, c), trans[p]) << 12) | (changed((a, b, c), trans[f]) << 15), (p * 8) | ((f * 8) << 16)))
     return words
 
 
 def walk(words, outcome):
-    """Run the automaton with `outcome(a, b, c) -> bool`; returns (shift, trials)."""
+    """Run the automaton the way the kernel does (terms cached per factor, rebuilt by the change masks) with `outcome(a, b, c) -> bool`; returns (shift, trials).
+    Asserts that the masks always leave the cached triple equal to the entry's triple."""
     s = 0
     n = 0
+    cached = [None, None, None]
+    chg = 7
     while not (words[s][0] >> 31):
         w0, w1 = words[s]
+        t = (w0 & 15, (w0 >> 4) & 15, (w0 >> 8) & 15)
+        for k in range(3):
+            if chg & (1 << k):
+                cached[k] = t[k]
+        assert tuple(cached) == t, (s, cached, t)
         n += 1
-        s = (w1 & 0xFFFF) if outcome(w0 & 15, (w0 >> 4) & 15, (w0 >> 8) & 15) else (w1 >> 16)
+        ok = outcome(*t)
+        chg = (w0 >> (12 if ok else 15)) & 7
+        off = (w1 & 0xFFFF) if ok else (w1 >> 16)
+        assert off % 8 == 0
+        s = off // 8
     w0 = words[s][0]
     return (w0 & 15, (w0 >> 4) & 15, (w0 >> 8) & 15), n
 
@@ -150,8 +172,8 @@ def main():
     body = ",\n".join("  " + ", ".join("{0x%08xu, 0x%08xu}" % w for w in words[i:i + 4]) for i in range(0, len(words), 4))
     text = """// GENERATED by tools/make_search_table.py -- do not edit.
 // Decision automaton of the reference's default shift search (src/limg_bit_crush.h:331-392, :502-614): %d states.
-// entry = { a | b << 4 | c << 8 | final << 31,  next_on_pass | next_on_fail << 16 }; state 0 is the start;
-// a final entry carries the resulting shift triple.
+// entry = { a | b << 4 | c << 8 | changed_on_pass << 12 | changed_on_fail << 15 | final << 31,  byte offset of the next entry on pass | on fail << 16 };
+// changed_on_* = which shifts (bit 0 A, 1 B, 2 C) the successor's triple changes; state 0 is the start; a final entry carries the resulting shift triple.
 #ifndef LIMG_SEARCH_TABLE_H
 #define LIMG_SEARCH_TABLE_H
 #define LIMG_SEARCH_STATES %d
