@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liblimg_hip.so")
+LIB_PATH = os.environ.get("LIMG_HIP_LIB") or os.path.join(HERE, "liblimg_hip.so")  # LIMG_HIP_LIB: A/B runs against another build of the same ABI
 
 P32 = ("pDecoded", "pShiftABCX", "pColAMin", "pColAMax", "pColBMin", "pColBMax", "pColCMin", "pColCMax")
 P8 = ("pFactorsA", "pFactorsB", "pFactorsC")

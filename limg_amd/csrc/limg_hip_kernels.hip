@@ -151,7 +151,7 @@ namespace limg_hip
     {
       const uint2 *tab = d_search_tab;
       asm volatile("" : "+s"(tab)); // opaque: otherwise the address is rematerialised (s_getpc + 2 adds) in every iteration
-      uint32_t ex = (uint32_t)sgpr((int)tab[0].x), ey = (uint32_t)sgpr((int)tab[0].y);
+      uint32_t ex = LIMG_SEARCH_ROOT_X, ey = LIMG_SEARCH_ROOT_Y; // entry 0 as immediates (the opaque base above would make reading it a memory round trip per block)
       uint32_t chg = 7u; // nothing cached yet
       while (!(ex >> 31))
       {

@@ -177,11 +177,13 @@ def main():
 #ifndef LIMG_SEARCH_TABLE_H
 #define LIMG_SEARCH_TABLE_H
 #define LIMG_SEARCH_STATES %d
+#define LIMG_SEARCH_ROOT_X 0x%08xu /* entry 0, as immediates: the kernel starts every block's search without a load */
+#define LIMG_SEARCH_ROOT_Y 0x%08xu
 #define LIMG_SEARCH_TABLE_INIT { \\
 %s \\
 }
 #endif
-""" % (len(words), len(words), body.replace("\n", " \\\n"))
+""" % (len(words), len(words), words[0][0], words[0][1], body.replace("\n", " \\\n"))
     path = os.path.join(ROOT, "limg_amd", "csrc", "limg_search_table.h")
     open(path, "w").write(text)
     print("wrote", path, len(words), "states")
