@@ -40,7 +40,7 @@ namespace limg_hip
     constexpr int kVDw = 260;   // per-block stride of the parked contributions: 64 px * 4 ch + 4 pad => the (block, channel) walkers hit 32 distinct banks
 
     // decision automaton of the default shift search (tools/make_search_table.py); read with scalar loads
-    __constant__ uint2 d_search_tab[LIMG_SEARCH_STATES] = LIMG_SEARCH_TABLE_INIT;
+    __constant__ uint4 d_search_tab[LIMG_SEARCH_STATES] = LIMG_SEARCH_TABLE_INIT;
 
     // ---- a9, packed form ------------------------------------------------------------------------------------------------
     // Same integers as `trial` above, arranged for gfx950's packed 16-bit VALU:
@@ -74,9 +74,9 @@ namespace limg_hip
       uint32_t cA, cB, cC;
     };
 
-    __device__ __forceinline__ void make_terms(const uint32_t f, const uint32_t s, const int n[3], const int m[3], uint32_t &tRG, int &tB)
+    __device__ __forceinline__ void make_terms(const uint32_t f, const uint32_t s, const uint32_t mul, const int n[3], const int m[3], uint32_t &tRG, int &tB)
     {
-      const int d = (int)mul_u24_uniform(f >> s, shift_mul(s)); // <= 255 * 256; the shift is wave-uniform in the packed trial
+      const int d = (int)mul_u24_uniform(f >> s, mul); // mul == shift_mul(s); <= 255 * 256; shift and multiplier are wave-uniform in the packed trial
       const int t0 = mad_i24(d, n[0], m[0]), t1 = mad_i24(d, n[1], m[1]), t2 = mad_i24(d, n[2], m[2]);
       tRG = __builtin_amdgcn_perm((uint32_t)t1, (uint32_t)t0, 0x06050201u); // ((t1 >> 8) & 0xFFFF) << 16 | ((t0 >> 8) & 0xFFFF)
       tB = t2 >> 8;
@@ -84,17 +84,17 @@ namespace limg_hip
 
     // the three factors' cached terms, each rebuilt on demand (shift 8: f >> 8 == 0 => term == minA, as upstream; for B and C upstream zeroes min too,
     // src/limg_bit_crush_simd.h:593-609)
-    __device__ __forceinline__ void rebuild_A(TrialState &t, const uint32_t sA) { make_terms(t.fA, sA, t.nA, t.mA, t.tA_RG, t.tA_B); t.cA = sA; }
-    __device__ __forceinline__ void rebuild_B(TrialState &t, const uint32_t sB)
+    __device__ __forceinline__ void rebuild_A(TrialState &t, const uint32_t sA, const uint32_t mul) { make_terms(t.fA, sA, mul, t.nA, t.mA, t.tA_RG, t.tA_B); t.cA = sA; }
+    __device__ __forceinline__ void rebuild_B(TrialState &t, const uint32_t sB, const uint32_t mul)
     {
       if (sB > 7) { t.tB_RG = (uint32_t)kTermBias; t.tB_B = 0; }
-      else make_terms(t.fB, sB, t.nB, t.mB, t.tB_RG, t.tB_B);
+      else make_terms(t.fB, sB, mul, t.nB, t.mB, t.tB_RG, t.tB_B);
       t.cB = sB;
     }
-    __device__ __forceinline__ void rebuild_C(TrialState &t, const uint32_t sC)
+    __device__ __forceinline__ void rebuild_C(TrialState &t, const uint32_t sC, const uint32_t mul)
     {
       if (sC > 7) { t.tC_RG = (uint32_t)kTermBias; t.tC_B = 0; }
-      else make_terms(t.fC, sC, t.nC, t.mC, t.tC_RG, t.tC_B);
+      else make_terms(t.fC, sC, mul, t.nC, t.mC, t.tC_RG, t.tC_B);
       t.cC = sC;
     }
 
@@ -126,9 +126,9 @@ namespace limg_hip
     __device__ __forceinline__ bool trial_packed(TrialState &t, const uint32_t sA, const uint32_t sB, const uint32_t sC, const bool active,
                                                  const uint32_t maxPixel32, const uint32_t blockLimit, uint32_t &blockError)
     {
-      if (sA != t.cA) rebuild_A(t, sA);
-      if (sB != t.cB) rebuild_B(t, sB);
-      if (sC != t.cC) rebuild_C(t, sC);
+      if (sA != t.cA) rebuild_A(t, sA, shift_mul(sA));
+      if (sB != t.cB) rebuild_B(t, sB, shift_mul(sB));
+      if (sC != t.cC) rebuild_C(t, sC, shift_mul(sC));
       return trial_core<FULL>(t, active, maxPixel32, blockLimit, blockError);
     }
 
@@ -138,33 +138,34 @@ namespace limg_hip
     // changes (no compares against cached shifts), byte offsets (no shifts), and its base address stays in SGPRs.
     // scalar 8-byte load issued now, consumed after `sload_wait` (the compiler would otherwise sink the load to its use and
     // expose the scalar-cache latency on every trial)
-    __device__ __forceinline__ uint64_t sload2(const uint2 *base, uint32_t byteOffset)
+    typedef unsigned int uint4s_t __attribute__((ext_vector_type(4)));
+    __device__ __forceinline__ uint4s_t sload4(const uint4 *base, uint32_t byteOffset)
     {
-      uint64_t v;
-      asm volatile("s_load_dwordx2 %0, %1, %2" : "=&s"(v) : "s"(base), "s"(byteOffset) : "memory");
+      uint4s_t v;
+      asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(v) : "s"(base), "s"(byteOffset) : "memory");
       return v;
     }
-    __device__ __forceinline__ void sload_wait(uint64_t &a, uint64_t &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)::"memory"); }
+    __device__ __forceinline__ void sload_wait(uint4s_t &a, uint4s_t &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)::"memory"); }
 
     template <bool FULL>
     __device__ __forceinline__ void search_fast_automaton(TrialState &t, const bool active, const uint32_t maxPixel32, const uint32_t blockLimit, uint32_t shift[3])
     {
-      const uint2 *tab = d_search_tab;
+      const uint4 *tab = d_search_tab;
       asm volatile("" : "+s"(tab)); // opaque: otherwise the address is rematerialised (s_getpc + 2 adds) in every iteration
-      uint32_t ex = LIMG_SEARCH_ROOT_X, ey = LIMG_SEARCH_ROOT_Y; // entry 0 as immediates (the opaque base above would make reading it a memory round trip per block)
+      // entry 0 as immediates (the opaque base above would make reading it a memory round trip per block)
+      uint32_t ex = LIMG_SEARCH_ROOT_X, ey = LIMG_SEARCH_ROOT_Y, ez = LIMG_SEARCH_ROOT_Z;
       uint32_t chg = 7u; // nothing cached yet
       while (!(ex >> 31))
       {
-        uint64_t ep = sload2(tab, ey & 0xFFFFu), ef = sload2(tab, ey >> 16);
-        if (chg & 1u) rebuild_A(t, ex & 15u);
-        if (chg & 2u) rebuild_B(t, (ex >> 4) & 15u);
-        if (chg & 4u) rebuild_C(t, (ex >> 8) & 15u);
+        uint4s_t ep = sload4(tab, ey & 0xFFFFu), ef = sload4(tab, ey >> 16);
+        if (chg & 1u) rebuild_A(t, ex & 15u, ez & 511u);
+        if (chg & 2u) rebuild_B(t, (ex >> 4) & 15u, (ez >> 9) & 511u);
+        if (chg & 4u) rebuild_C(t, (ex >> 8) & 15u, ez >> 18);
         uint32_t be;
         const bool ok = trial_core<FULL>(t, active, maxPixel32, blockLimit, be);
         sload_wait(ep, ef);
-        const uint64_t e = ok ? ep : ef;
         chg = ex >> (ok ? 12u : 15u); // bits 0..2; what lies above is never looked at
-        ex = (uint32_t)e; ey = (uint32_t)(e >> 32);
+        ex = ok ? ep.x : ef.x; ey = ok ? ep.y : ef.y; ez = ok ? ep.z : ef.z;
       }
       shift[0] = ex & 15u; shift[1] = (ex >> 4) & 15u; shift[2] = (ex >> 8) & 15u;
     }

@@ -122,9 +122,16 @@ def build():
 def encode(trans):
     """entry = (word0, word1):
        word0 = a | b << 4 | c << 8 | changed_on_pass << 12 | changed_on_fail << 15 | final << 31
-       word1 = byte offset of the next entry on pass | byte offset on fail << 16          (entries are 8 bytes)
+       word1 = byte offset of the next entry on pass | byte offset on fail << 16          (entries are 16 bytes)
+       word2 = mul(a) | mul(b) << 9 | mul(c) << 18, mul(s) = (1 << s) + decode_bias(s): the re-expansion multiplier of each shift, so that the kernel's scalar
+               stream extracts it with one bit-field instruction instead of computing it (5 instructions)
     changed_on_* = which of the three shifts (bit 0 = A, 1 = B, 2 = C) differ between this entry's triple and the successor's: the kernel keeps the terms of the
     last evaluated triple and rebuilds exactly those factors -- no compares against cached shifts in its scalar instruction stream.  0 for a final successor."""
+    MUL = [1, 2, 4, 8, 17, 36, 85, 255, 256]  # (1 << s) + decode_bias(s), src/limg_bit_crush_simd.h:611-619
+
+    def muls(t):
+        return MUL[t[0]] | (MUL[t[1]] << 9) | (MUL[t[2]] << 18)
+
     def changed(t, nxt):
         if nxt[0] == "final":
             return 0
@@ -134,11 +141,11 @@ def encode(trans):
     for t in trans:
         if t[0] == "final":
             a, b, c = t[1]
-            words.append((a | (b << 4) | (c << 8) | (1 << 31), 0))
+            words.append((a | (b << 4) | (c << 8) | (1 << 31), 0, 0))
         else:
             (a, b, c), p, f = t
-            assert p * 8 < 65536 and f * 8 < 65536
-            words.append((a | (b << 4) | (c << 8) | (changed((a, b, c), trans[p]) << 12) | (changed((a, b, c), trans[f]) << 15), (p * 8) | ((f * 8) << 16)))
+            assert p * 16 < 65536 and f * 16 < 65536
+            words.append((a | (b << 4) | (c << 8) | (changed((a, b, c), trans[p]) << 12) | (changed((a, b, c), trans[f]) << 15), (p * 16) | ((f * 16) << 16), muls((a, b, c))))
     return words
 
 
@@ -150,8 +157,9 @@ def walk(words, outcome):
     cached = [None, None, None]
     chg = 7
     while not (words[s][0] >> 31):
-        w0, w1 = words[s]
+        w0, w1, w2 = words[s]
         t = (w0 & 15, (w0 >> 4) & 15, (w0 >> 8) & 15)
+        assert [(w2 >> (9 * k)) & 511 for k in range(3)] == [[1, 2, 4, 8, 17, 36, 85, 255, 256][x] for x in t]
         for k in range(3):
             if chg & (1 << k):
                 cached[k] = t[k]
@@ -160,8 +168,8 @@ def walk(words, outcome):
         ok = outcome(*t)
         chg = (w0 >> (12 if ok else 15)) & 7
         off = (w1 & 0xFFFF) if ok else (w1 >> 16)
-        assert off % 8 == 0
-        s = off // 8
+        assert off % 16 == 0
+        s = off // 16
     w0 = words[s][0]
     return (w0 & 15, (w0 >> 4) & 15, (w0 >> 8) & 15), n
 
@@ -169,21 +177,23 @@ def walk(words, outcome):
 def main():
     trans = build()
     words = encode(trans)
-    body = ",\n".join("  " + ", ".join("{0x%08xu, 0x%08xu}" % w for w in words[i:i + 4]) for i in range(0, len(words), 4))
+    body = ",\n".join("  " + ", ".join("{0x%08xu, 0x%08xu, 0x%08xu, 0u}" % w for w in words[i:i + 4]) for i in range(0, len(words), 4))
     text = """// GENERATED by tools/make_search_table.py -- do not edit.
 // Decision automaton of the reference's default shift search (src/limg_bit_crush.h:331-392, :502-614): %d states.
-// entry = { a | b << 4 | c << 8 | changed_on_pass << 12 | changed_on_fail << 15 | final << 31,  byte offset of the next entry on pass | on fail << 16 };
+// entry (16 bytes) = { a | b << 4 | c << 8 | changed_on_pass << 12 | changed_on_fail << 15 | final << 31,  byte offset of the next entry on pass | on fail << 16,
+//                     mul(a) | mul(b) << 9 | mul(c) << 18,  0 };
 // changed_on_* = which shifts (bit 0 A, 1 B, 2 C) the successor's triple changes; state 0 is the start; a final entry carries the resulting shift triple.
 #ifndef LIMG_SEARCH_TABLE_H
 #define LIMG_SEARCH_TABLE_H
 #define LIMG_SEARCH_STATES %d
 #define LIMG_SEARCH_ROOT_X 0x%08xu /* entry 0, as immediates: the kernel starts every block's search without a load */
 #define LIMG_SEARCH_ROOT_Y 0x%08xu
+#define LIMG_SEARCH_ROOT_Z 0x%08xu
 #define LIMG_SEARCH_TABLE_INIT { \\
 %s \\
 }
 #endif
-""" % (len(words), len(words), words[0][0], words[0][1], body.replace("\n", " \\\n"))
+""" % (len(words), len(words), words[0][0], words[0][1], words[0][2], body.replace("\n", " \\\n"))
     path = os.path.join(ROOT, "limg_amd", "csrc", "limg_search_table.h")
     open(path, "w").write(text)
     print("wrote", path, len(words), "states")
