@@ -577,9 +577,9 @@ namespace limg_hip
         const float fb = dp4<CH>((pv - est) - off[1], nrm[1]) * invN[1];
         est = est + nrm[1] * fb;
         const float fc = dp4<CH>((pv - est) - off[2], nrm[2]) * invN[2];
-        sf[i] = (uint8_t)med3_i32(cvt_rne(255.0f * fa), 0, 255);
-        sf[(size_t)cap + i] = (uint8_t)med3_i32(cvt_rne(255.0f * fb), 0, 255);
-        sf[2 * (size_t)cap + i] = (uint8_t)med3_i32(cvt_rne(255.0f * fc), 0, 255);
+        sf[i] = (uint8_t)cvt_u8_rne_sat(255.0f * fa);
+        sf[(size_t)cap + i] = (uint8_t)cvt_u8_rne_sat(255.0f * fb);
+        sf[2 * (size_t)cap + i] = (uint8_t)cvt_u8_rne_sat(255.0f * fc);
       }
       scratch_fence();
 

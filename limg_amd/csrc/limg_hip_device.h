@@ -62,6 +62,9 @@ namespace limg_hip
     }
 
     __device__ __forceinline__ int cvt_rne(float x) { return (int)__builtin_rintf(x); }
+    // clamp(round-to-nearest-even(x), 0, 255), NaN -> 0, in one instruction: what CVTPS2DQ + the saturating packs of a8 (src/limg_factorization.h:98-197) give.
+    // Checked against nearbyintf + clamp on 2 M inputs incl. every tie and the specials (tools/cvt_pk_u8_check.hip).
+    __device__ __forceinline__ uint32_t cvt_u8_rne_sat(float x) { uint32_t r; asm("v_cvt_pk_u8_f32 %0, %1, 0, 0" : "=v"(r) : "v"(x)); return r; }
 
     __device__ __forceinline__ void store_v(float *V, int lane, const float v[4])
     {

@@ -1003,15 +1003,15 @@ namespace limg_hip
           const V4 pv = px_to_v4(px);
           const V4 nA = ld4(be->nrm[0]), mnA = ld4(be->off[0]);
           const float fa = dp4<CH, FAST>(pv - mnA, nA) * be->invN[0];
-          int q = cvt_rne(255.0f * fa); fA = (uint32_t)med3_i32(q, 0, 255);
+          fA = cvt_u8_rne_sat(255.0f * fa);
           const V4 nB = ld4(be->nrm[1]), ofB = ld4(be->off[1]);
           V4 est = mnA + nA * fa;
           const float fb = dp4<CH, FAST>((pv - est) - ofB, nB) * be->invN[1];
-          q = cvt_rne(255.0f * fb); fB = (uint32_t)med3_i32(q, 0, 255);
+          fB = cvt_u8_rne_sat(255.0f * fb);
           const V4 nC = ld4(be->nrm[2]), ofC = ld4(be->off[2]);
           est = est + nB * fb;
           const float fc = dp4<CH, FAST>((pv - est) - ofC, nC) * be->invN[2];
-          q = cvt_rne(255.0f * fc); fC = (uint32_t)med3_i32(q, 0, 255);
+          fC = cvt_u8_rne_sat(255.0f * fc);
         }
 
         uint32_t shift[3] = { 0, 0, 0 };
