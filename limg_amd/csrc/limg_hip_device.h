@@ -377,16 +377,24 @@ namespace limg_hip
     // neither of which can reach the comparison's outcome; the NaN-producing degenerate cases never get here (kZero* flags).
     // RSQRTPS = the captured Intel table: index = [exponent lsb : top 10 mantissa bits], exponent = 126 - floor((e - 127) / 2).
     // FAST: the hardware's v_rsq_f32 (1 ulp) instead of the 12-bit x86 table -- unit vectors 2^-12 closer to unit length than the reference's.
-    template <int CH, bool FAST = false>
+    // ZERO_BY_LEN2: decide "all lanes zero" from d . d != 0 instead of OR-ing the four bit patterns (three instructions fewer).  Equivalent for everything the
+    // fit can feed it: a non-zero difference of a byte pixel and a float average / estimate is far above 1e-19, so its square does not underflow.  Used by
+    // k_fit_tpb (which has the registers for it); the lane == pixel path keeps the bit test (there it cost a spill).
+    template <int CH, bool FAST = false, bool ZERO_BY_LEN2 = false>
     __device__ __forceinline__ V4 unit4(const unsigned short *tab, const V4 &d, bool active)
     {
       const float2_t biasA = { FLT_EPSILON * 3, FLT_EPSILON * 1 }, biasB = { FLT_EPSILON * 2, 0.0f };
       const float2_t mbA = d.a - biasA, mbB = d.b - biasB, xbA = d.a + biasA, xbB = d.b + biasB;
       const float mn = vmin3(mbA.x, mbA.y, vmin(mbB.x, mbB.y));
       const float mx = vmax3(xbA.x, xbA.y, vmax(xbB.x, xbB.y));
-      const uint32_t anybits = (__float_as_uint(d.a.x) | __float_as_uint(d.a.y) | __float_as_uint(d.b.x) | __float_as_uint(d.b.y)) << 1;
-      const bool use = (anybits != 0u) && active;
       const float len2 = dp4<CH, FAST>(d, d);
+      bool use;
+      if (ZERO_BY_LEN2) use = (len2 != 0.0f) && active;
+      else
+      {
+        const uint32_t anybits = (__float_as_uint(d.a.x) | __float_as_uint(d.a.y) | __float_as_uint(d.b.x) | __float_as_uint(d.b.y)) << 1;
+        use = (anybits != 0u) && active;
+      }
       float inv;
       if (FAST) inv = __builtin_amdgcn_rsqf(len2);
       else

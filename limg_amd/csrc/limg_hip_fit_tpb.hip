@@ -105,7 +105,7 @@ namespace limg_hip
           {
             V4 d = px_to_v4(q[i]) - avg;
             mask_alpha<CH>(d);
-            acc = acc + unit4<CH, FAST>(tab, d, true);
+            acc = acc + unit4<CH, FAST, true>(tab, d, true);
           }
         }
         finish_dir(acc, dirA, invA, zeroA);
@@ -129,7 +129,7 @@ namespace limg_hip
             mn = vmin(mn, fA); mx = vmax(mx, fA);
             V4 e = pf - (avg + dirA * fA);
             mask_alpha<CH>(e);
-            acc = acc + unit4<CH, FAST>(tab, e, true);
+            acc = acc + unit4<CH, FAST, true>(tab, e, true);
           }
         }
         mm[0] = mn; mm[1] = mx;
@@ -158,7 +158,7 @@ namespace limg_hip
               mnB = vmin(mnB, fB); mxB = vmax(mxB, fB);
               const V4 estB = estA + dirB * fB;
               if (r == 0 && i == 0) est0 = estB;
-              acc = acc + unit4<CH, FAST>(tab, pf - estB, true);
+              acc = acc + unit4<CH, FAST, true>(tab, pf - estB, true);
             }
           }
           mm[2] = mnB; mm[3] = mxB;
