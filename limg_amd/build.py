@@ -21,14 +21,16 @@ def _newer(target, deps):
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force=False, verbose=False, extra_flags=()):
+def build(force=False, verbose=False, extra_flags=(), out_dir=None):
+    """out_dir: build objects and the library THERE from the sources (nothing reused, nothing in-tree touched) -- the from-scratch check of tests/test_build_from_source.py."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "limg_hip.h"), os.path.abspath(__file__)]
-    if not force and _newer(OUT, deps):
+    out = OUT if out_dir is None else os.path.join(out_dir, "liblimg_hip.so")
+    if out_dir is None and not force and _newer(OUT, deps):
         return OUT
     objs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o")
+        obj = os.path.join(CSRC if out_dir is None else out_dir, src.rsplit(".", 1)[0] + ".o")
         cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if src.endswith(".cpp"):
             # host-only translation units; the merge's similarity predicate is float code that must round like the kernels: no contraction
@@ -37,11 +39,11 @@ def build(force=False, verbose=False, extra_flags=()):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 CLI_SRC = os.path.join(HERE, "..", "tools", "limg_hip_cli.cpp")

@@ -480,3 +480,75 @@ def test_repeat_determinism_at_4096(gpu):
     gpu.check()
     del ref, cur, d_img
     torch.cuda.empty_cache()
+
+
+def test_config3_bit_crush_sweep_at_8192(gpu, oracle):
+    """BASELINE config 3 at its real size: 8192^2 photo-noise with the search bypassed by a forced shift of 8 - bits on all three factors, bits = 8 .. 2 (what
+    tools/sweep.py tabulates), plus the adaptive errorFactor sweep.  Per setting: the first 64-row band equals the oracle on every plane (its dither chain starts at
+    the seed), a middle band equals it on the chain-independent planes, and PSNR falls monotonically with the bits."""
+    import torch
+    W = 8192
+    d_img = gpu.synth_device("photo_noise", W, W, seed=1)
+    band = d_img[:64].cpu().numpy().view(np.uint32)
+    mid = d_img[W // 2: W // 2 + 16].cpu().numpy().view(np.uint32)
+    planes = gpu.alloc_planes_device(W, W)
+    last_psnr = 1e9
+    try:
+        for bits in (8, 7, 6, 5, 4, 3, 2):
+            s = 8 - bits
+            gpu.set_options(forced_shift=(s, s, s))
+            gpu.encode3d_device(d_img, True, planes)
+            torch.cuda.synchronize()
+            want = oracle.encode3d(band, True, forced_shift=(s, s, s))
+            for k in PLANES:
+                got = planes[k][:64].cpu().numpy()
+                got = got.view(np.uint32) if got.dtype == np.int32 else got
+                assert np.array_equal(got, want[k]), (bits, k)
+            want = oracle.encode3d(mid, True, forced_shift=(s, s, s))
+            for k in ("pShiftABCX", "pColAMin", "pColAMax", "pColBMin", "pColBMax", "pColCMin", "pColCMax"):
+                assert np.array_equal(planes[k][W // 2: W // 2 + 16].cpu().numpy().view(np.uint32), want[k]), (bits, k)
+            psnr, _ = gpu.compare_device(d_img, planes["pDecoded"], True)
+            assert psnr < last_psnr + 1e-9, (bits, psnr, last_psnr)
+            last_psnr = psnr
+        gpu.set_options()
+        last_psnr = 1e9
+        for ef in (0, 25, 50, 100, 200, 400):
+            gpu.encode3d_device(d_img, True, planes, error_factor=ef)
+            torch.cuda.synchronize()
+            want = oracle.encode3d(band, True, error_factor=ef)
+            for k in PLANES:
+                got = planes[k][:64].cpu().numpy()
+                got = got.view(np.uint32) if got.dtype == np.int32 else got
+                assert np.array_equal(got, want[k]), (ef, k)
+            psnr, _ = gpu.compare_device(d_img, planes["pDecoded"], True)
+            assert psnr < last_psnr + 1e-9, (ef, psnr)
+            last_psnr = psnr
+    finally:
+        gpu.set_options()
+    gpu.check()
+    del planes, d_img
+    torch.cuda.empty_cache()
+
+
+def test_accurate_mode_at_4096(gpu, oracle):
+    """`--accurate-bit-crushing` (fastBitCrushing = false, src/limg_bit_crush.h:668-830) at a BASELINE size: 4096^2 random-gradient and a 4096 x 1024 photo-noise
+    image; first band on every plane and a middle band on the chain-independent planes against the oracle's accurate search."""
+    import torch
+    for kind, W, H in (("random_gradient", 4096, 4096), ("photo_noise", 4096, 1024)):
+        d_img = gpu.synth_device(kind, W, H, seed=2)
+        planes = gpu.alloc_planes_device(W, H)
+        gpu.encode3d_device(d_img, True, planes, fast=False)
+        torch.cuda.synchronize()
+        band = d_img[:32].cpu().numpy().view(np.uint32)
+        want = oracle.encode3d(band, True, fast=False)
+        for k in PLANES:
+            got = planes[k][:32].cpu().numpy()
+            got = got.view(np.uint32) if got.dtype == np.int32 else got
+            assert np.array_equal(got, want[k]), (kind, k)
+        mid = d_img[H // 2: H // 2 + 16].cpu().numpy().view(np.uint32)
+        want = oracle.encode3d(mid, True, fast=False)
+        for k in ("pShiftABCX", "pColAMin", "pColAMax", "pColBMin", "pColBMax", "pColCMin", "pColCMax"):
+            assert np.array_equal(planes[k][H // 2: H // 2 + 16].cpu().numpy().view(np.uint32), want[k]), (kind, k)
+        del planes, d_img
+    gpu.check()
+    torch.cuda.empty_cache()
