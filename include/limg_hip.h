@@ -255,7 +255,8 @@ limg_hip_result limg_hip_encode3d_single_chain_device(limg_hip_context *pCtx, co
                                                       const limg_hip_encode3d_info *pInfo, uint32_t errorFactor, int fastBitCrushing, size_t blocksBefore, void *stream);
 /* The two halves of the above without the exchange, for callers that move the counts themselves (and for single-GPU tests of the chain arithmetic):
  * phase 1 = E step + scan, writes this strip's dither-call total to *pCallsDevice; phase 2 = F step, its first dither call is *pChainBaseDevice.
- * Phase 2 must follow phase 1 of the same strip on the same context with nothing in between (the context holds the strip's intermediate results). */
+ * Phase 2 must follow phase 1 of the same strip on the same context with nothing in between (the context holds the strip's intermediate results);
+ * a phase 2 without that is refused with limg_hip_error_InvalidParameter. */
 limg_hip_result limg_hip_encode3d_chain_device(limg_hip_context *pCtx, const uint32_t *pIn, size_t sizeX, size_t stripRows, int hasAlpha, const limg_hip_encode3d_info *pInfo,
                                                uint32_t errorFactor, int fastBitCrushing, int phase, uint64_t *pCallsDevice, const uint64_t *pChainBaseDevice,
                                                size_t blocksBefore, void *stream);

@@ -96,6 +96,9 @@ struct limg_hip_context
   // multi-GPU (RCCL over xGMI): one communicator per context, created by limg_hip_comm_init
   ncclComm_t comm = nullptr;
   int commRank = 0, commWorld = 1;
+  // limg_hip_encode3d_chain_device: phase 2 is only valid right after phase 1 of the same strip (the context holds the intermediate results)
+  const void *chainIn = nullptr;
+  size_t chainX = 0, chainY = 0;
   DevBuf commWords; // [0] this rank's value, [1] its chain base, [8 ...] the all-gathered values
   DevBuf streamFac, streamTiles, streamStatus, streamBuf; // stream packer: 3 factor planes, per-tile payload words; decode status word; host-entry staging
   // optional per-kernel timing (bench): 4 events per encode, recorded on the caller's stream, read back in one go
@@ -175,6 +178,7 @@ namespace
   {
     // chainPhase: 0 = whole encode; 1 = E step + scan only (writes *dChainCalls); 2 = F step only (reads *dChainBase).  1 and 2 always take the split path.
     if (!c || !dIn) return limg_hip_error_ArgumentNull;
+    if (chainPhase == 0) c->chainIn = nullptr; // the context's per-block scratch is about to be reused
     if (sizeX == 0 || sizeY == 0 || sizeX > 0x7FFFFFF8ull || sizeY > 0x7FFFFFF8ull) return limg_hip_error_InvalidParameter;
     bool fullPlanes = true;
     if (dInfo)
@@ -517,9 +521,13 @@ extern "C"
                                                  size_t blocksBefore, void *stream)
   {
     if (phase != 1 && phase != 2) return limg_hip_error_InvalidParameter;
-    if ((phase == 1 && !pCallsDevice) || (phase == 2 && !pChainBaseDevice) || !pInfo) return limg_hip_error_ArgumentNull;
-    return encode_device(c, pIn, sizeX, sizeY, hasAlpha, pInfo, nullptr, errorFactor, 0, fastBitCrushing, (hipStream_t)stream, false, false, phase,
+    if (!c || (phase == 1 && !pCallsDevice) || (phase == 2 && !pChainBaseDevice) || !pInfo) return limg_hip_error_ArgumentNull;
+    if (phase == 2 && (c->chainIn != pIn || c->chainX != sizeX || c->chainY != sizeY)) return limg_hip_error_InvalidParameter; // no phase 1 of this strip pending
+    c->chainIn = nullptr;
+    const limg_hip_result r = encode_device(c, pIn, sizeX, sizeY, hasAlpha, pInfo, nullptr, errorFactor, 0, fastBitCrushing, (hipStream_t)stream, false, false, phase,
                          (unsigned long long *)pCallsDevice, (const unsigned long long *)pChainBaseDevice, blocksBefore);
+    if (r == limg_hip_success && phase == 1) { c->chainIn = pIn; c->chainX = sizeX; c->chainY = sizeY; }
+    return r;
   }
 
   limg_hip_result limg_hip_encode3d(limg_hip_context *c, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, limg_hip_encode3d_info *pInfo, uint32_t errorFactor,
@@ -1185,14 +1193,17 @@ extern "C"
     if (isRoot && offs[world] > capacity) return limg_hip_error_OutOfBounds; // every rank sees the same sizes: the peers would send into nothing
     // 2. exactly the used bytes, point to point: each peer -> root transfer rides one xGMI link
     NCCL_TRY(rccl().GroupStart());
+    ncclResult_t posted = ncclSuccess; // a failed post must not leave the group open: close it first, report afterwards
     if (isRoot)
     {
-      for (int r = 0; r < world; r++)
-        if (r != root && sizes[r]) NCCL_TRY(rccl().Recv(pGathered + offs[r], sizes[r], ncclUint8, r, c->comm, s));
+      for (int r = 0; r < world && posted == ncclSuccess; r++)
+        if (r != root && sizes[r]) posted = rccl().Recv(pGathered + offs[r], sizes[r], ncclUint8, r, c->comm, s);
     }
     else if (streamBytes)
-      NCCL_TRY(rccl().Send(pStream, streamBytes, ncclUint8, root, c->comm, s));
-    NCCL_TRY(rccl().GroupEnd());
+      posted = rccl().Send(pStream, streamBytes, ncclUint8, root, c->comm, s);
+    const ncclResult_t closed = rccl().GroupEnd();
+    NCCL_TRY(posted);
+    NCCL_TRY(closed);
     if (isRoot)
     {
       if (streamBytes) HIP_TRY(hipMemcpyAsync(pGathered + offs[root], pStream, streamBytes, hipMemcpyDeviceToDevice, s));

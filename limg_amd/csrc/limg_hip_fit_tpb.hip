@@ -22,23 +22,28 @@ namespace limg_hip
   {
     constexpr int kTpbStride = 68;
 
+    constexpr int kTpbWaves = 2; // waves per workgroup: they share one copy of the RSQRTPS table (2 x 17 KiB + 4 KiB => 4 workgroups = 8 waves per CU)
+
     template <int CH, bool FAST>
-    __global__ __launch_bounds__(64) void k_fit_tpb(const EncodeParams p)
+    __global__ __launch_bounds__(64 * kTpbWaves) void k_fit_tpb(const EncodeParams p)
     {
-      __shared__ __attribute__((aligned(16))) uint32_t s_px[64 * kTpbStride];
+      __shared__ __attribute__((aligned(16))) uint32_t s_pxAll[kTpbWaves][64 * kTpbStride];
       // the RSQRTPS table in LDS: a per-lane gather of 64 unrelated 2-byte entries costs the texture path ~64 address cycles per wave instruction from global
-      // memory, but only a few LDS cycles (random banks); 4 KiB per wave => 7 waves per CU instead of 9, a good trade (measured)
+      // memory, but only a few LDS cycles (random banks)
       __shared__ __attribute__((aligned(16))) unsigned short s_tab[FAST ? 8 : 2048];
-      const int lane = (int)threadIdx.x;
+      const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
       if (!FAST)
       {
         const uint4 *src = reinterpret_cast<const uint4 *>(d_rsqrt_x86_tab);
-#pragma unroll
-        for (int i = 0; i < 4; i++) reinterpret_cast<uint4 *>(s_tab)[i * 64 + lane] = src[i * 64 + lane];
+        for (int i = (int)threadIdx.x; i < 256; i += 64 * kTpbWaves) reinterpret_cast<uint4 *>(s_tab)[i] = src[i];
+        __syncthreads();
       }
       const unsigned short *tab = s_tab;
+      uint32_t *s_px = s_pxAll[wave];
       const uint32_t unitsX = (p.blocksX + 63u) / 64u;
-      const uint32_t unit = blockIdx.x % unitsX, by = blockIdx.x / unitsX;
+      const uint32_t unitId = blockIdx.x * kTpbWaves + wave;
+      if (unitId >= unitsX * p.blocksY) return; // whole wave; after the only barrier
+      const uint32_t unit = unitId % unitsX, by = unitId / unitsX;
       const uint32_t bx0 = unit * 64u, x0 = bx0 * kBlock, y0 = by * kBlock;
       const uint32_t nBlocks = min(p.blocksX - bx0, 64u), widthPx = nBlocks * kBlock;
 
@@ -251,7 +256,8 @@ namespace limg_hip
 
   void launch_fit_tpb(const EncodeParams &p, int channels, hipStream_t s)
   {
-    const dim3 grid(((p.blocksX + 63u) / 64u) * p.blocksY), block(64);
+    const uint32_t units = ((p.blocksX + 63u) / 64u) * p.blocksY;
+    const dim3 grid((units + kTpbWaves - 1) / kTpbWaves), block(64 * kTpbWaves);
     if (p.floatFast)
     {
       if (channels == 4) hipLaunchKernelGGL((k_fit_tpb<4, true>), grid, block, 0, s, p);

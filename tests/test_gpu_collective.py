@@ -68,6 +68,16 @@ def test_chain_entry_refuses_what_it_cannot_chain(oracle):
             g.encode3d_chain_device(img, True, planes, 1, calls=calls)
         with pytest.raises(limg_amd.LimgHipError):
             g.encode3d_single_chain_device(torch.zeros((64, 64), dtype=torch.int32, device="cuda"), True, g.alloc_planes_device(64, 64), 0)  # no communicator yet
+        # phase 2 without a pending phase 1 of the same strip: refused (the context holds the strip's intermediate results between the two)
+        strip = torch.zeros((64, 64), dtype=torch.int32, device="cuda")
+        planes = g.alloc_planes_device(64, 64)
+        base = torch.zeros(1, dtype=torch.int64, device="cuda")
+        with pytest.raises(limg_amd.LimgHipError):
+            g.encode3d_chain_device(strip, True, planes, 2, base=base)
+        g.encode3d_chain_device(strip, True, planes, 1, calls=calls)
+        g.encode3d_device(strip, True, planes)  # any other encode reuses the scratch ...
+        with pytest.raises(limg_amd.LimgHipError):
+            g.encode3d_chain_device(strip, True, planes, 2, base=base)  # ... so the pending phase 1 is gone
     finally:
         g.close()
 
