@@ -12,7 +12,7 @@
 // The per-pixel helpers (unit4, dp4: DPPS order, captured RSQRTPS table, no contraction) are the very functions of limg_hip_device.h, so the records are
 // bit-identical to the lane == pixel path's -- the parity tests run both.  Only whole 8x8 blocks: images with partial edge blocks keep the other path.
 //
-// LDS: the 64 blocks' pixels, block-major with a stride of 68 dwords (16-byte aligned rows; 68 = 4 mod 64 makes every 16-lane group of a ds_read_b128 hit 64
+// LDS (only when the input rows are not 16-byte aligned; see DIRECT below): the 64 blocks' pixels, block-major with a stride of 68 dwords (16-byte aligned rows; 68 = 4 mod 64 makes every 16-lane group of a ds_read_b128 hit 64
 // distinct banks).  17 KiB per wave => 9 waves per CU.  The passes re-read the pixels from LDS (2 x ds_read_b128 per row).
 #include "limg_hip_device.h"
 
@@ -22,12 +22,17 @@ namespace limg_hip
   {
     constexpr int kTpbStride = 68;
 
-    constexpr int kTpbWaves = 2; // waves per workgroup: they share one copy of the RSQRTPS table (2 x 17 KiB + 4 KiB => 4 workgroups = 8 waves per CU)
+    // DIRECT (input rows 16-byte aligned, the normal case): every lane reads its block's rows straight from global memory (two 16-byte loads per row and pass;
+    // the rows are re-read from L2 by passes 2-4) -- no LDS but the RSQRTPS table, so the registers (166 => 3 waves per SIMD = 12 per CU) set the occupancy.
+    // Otherwise the 64 blocks' pixels are staged in LDS first (dword loads), 17 KiB per wave => 8 waves per CU.
+    template <bool DIRECT> constexpr int tpb_waves() { return DIRECT ? 4 : 2; }
+    // // waves per workgroup: they share one copy of the RSQRTPS table (2 x 17 KiB + 4 KiB => 4 workgroups = 8 waves per CU)
 
-    template <int CH, bool FAST>
-    __global__ __launch_bounds__(64 * kTpbWaves) void k_fit_tpb(const EncodeParams p)
+    template <int CH, bool FAST, bool DIRECT>
+    __global__ __launch_bounds__(64 * tpb_waves<DIRECT>()) void k_fit_tpb(const EncodeParams p)
     {
-      __shared__ __attribute__((aligned(16))) uint32_t s_pxAll[kTpbWaves][64 * kTpbStride];
+      constexpr int kTpbWaves = tpb_waves<DIRECT>();
+      __shared__ __attribute__((aligned(16))) uint32_t s_pxAll[kTpbWaves][DIRECT ? 4 : 64 * kTpbStride];
       // the RSQRTPS table in LDS: a per-lane gather of 64 unrelated 2-byte entries costs the texture path ~64 address cycles per wave instruction from global
       // memory, but only a few LDS cycles (random banks)
       __shared__ __attribute__((aligned(16))) unsigned short s_tab[FAST ? 8 : 2048];
@@ -48,6 +53,8 @@ namespace limg_hip
       const uint32_t nBlocks = min(p.blocksX - bx0, 64u), widthPx = nBlocks * kBlock;
 
       // ---- stage the 8 pixel rows (coalesced 16 bytes per lane) into the block-major layout ----
+      if (!DIRECT)
+      {
       if (p.vecIn)
       {
 #pragma unroll
@@ -64,16 +71,18 @@ namespace limg_hip
           for (uint32_t col = (uint32_t)lane; col < widthPx; col += 64u)
             s_px[(col >> 3) * kTpbStride + row * 8 + (col & 7u)] = p.in[(size_t)(y0 + row) * p.sizeX + x0 + col];
       }
+      }
       wave_lds_fence();
       if ((uint32_t)lane >= nBlocks) return;
-      const uint32_t *my = s_px + lane * kTpbStride;
+      const uint32_t *my = DIRECT ? p.in + (size_t)y0 * p.sizeX + x0 + lane * 8 : s_px + lane * kTpbStride;
+      const uint32_t pitch = DIRECT ? p.sizeX : 8u;
 
       // ---- a4: channel sums (src/limg.cpp:466-497); two channels per 32-bit accumulator, 64 * 255 < 2^16 ----
       uint32_t s02 = 0, s13 = 0;
 #pragma unroll
       for (int r = 0; r < 8; r++)
       {
-        const uint4 u = *reinterpret_cast<const uint4 *>(my + r * 8), w = *reinterpret_cast<const uint4 *>(my + r * 8 + 4);
+        const uint4 u = *reinterpret_cast<const uint4 *>(my + r * pitch), w = *reinterpret_cast<const uint4 *>(my + r * pitch + 4);
         const uint32_t q[8] = { u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w };
 #pragma unroll
         for (int i = 0; i < 8; i++) { s02 += q[i] & 0x00FF00FFu; s13 += (q[i] >> 8) & 0x00FF00FFu; }
@@ -103,7 +112,7 @@ namespace limg_hip
 #pragma unroll 1
         for (int r = 0; r < 8; r++)
         {
-          const uint4 u = *reinterpret_cast<const uint4 *>(my + r * 8), w = *reinterpret_cast<const uint4 *>(my + r * 8 + 4);
+          const uint4 u = *reinterpret_cast<const uint4 *>(my + r * pitch), w = *reinterpret_cast<const uint4 *>(my + r * pitch + 4);
           const uint32_t q[8] = { u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w };
 #pragma unroll
           for (int i = 0; i < 8; i++)
@@ -124,7 +133,7 @@ namespace limg_hip
 #pragma unroll 1
         for (int r = 0; r < 8; r++)
         {
-          const uint4 u = *reinterpret_cast<const uint4 *>(my + r * 8), w = *reinterpret_cast<const uint4 *>(my + r * 8 + 4);
+          const uint4 u = *reinterpret_cast<const uint4 *>(my + r * pitch), w = *reinterpret_cast<const uint4 *>(my + r * pitch + 4);
           const uint32_t q[8] = { u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w };
 #pragma unroll
           for (int i = 0; i < 8; i++)
@@ -151,7 +160,7 @@ namespace limg_hip
 #pragma unroll 1
           for (int r = 0; r < 8; r++)
           {
-            const uint4 u = *reinterpret_cast<const uint4 *>(my + r * 8), w = *reinterpret_cast<const uint4 *>(my + r * 8 + 4);
+            const uint4 u = *reinterpret_cast<const uint4 *>(my + r * pitch), w = *reinterpret_cast<const uint4 *>(my + r * pitch + 4);
             const uint32_t q[8] = { u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w };
 #pragma unroll
             for (int i = 0; i < 8; i++)
@@ -175,7 +184,7 @@ namespace limg_hip
 #pragma unroll 1
             for (int r = 0; r < 8; r++)
             {
-              const uint4 u = *reinterpret_cast<const uint4 *>(my + r * 8), w = *reinterpret_cast<const uint4 *>(my + r * 8 + 4);
+              const uint4 u = *reinterpret_cast<const uint4 *>(my + r * pitch), w = *reinterpret_cast<const uint4 *>(my + r * pitch + 4);
               const uint32_t q[8] = { u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w };
 #pragma unroll
               for (int i = 0; i < 8; i++)
@@ -199,7 +208,7 @@ namespace limg_hip
 #pragma unroll 1
           for (int r = 0; r < 8; r++)
           {
-            const uint4 u = *reinterpret_cast<const uint4 *>(my + r * 8), w = *reinterpret_cast<const uint4 *>(my + r * 8 + 4);
+            const uint4 u = *reinterpret_cast<const uint4 *>(my + r * pitch), w = *reinterpret_cast<const uint4 *>(my + r * pitch + 4);
             const uint32_t q[8] = { u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w };
 #pragma unroll
             for (int i = 0; i < 8; i++)
@@ -257,13 +266,19 @@ namespace limg_hip
   void launch_fit_tpb(const EncodeParams &p, int channels, hipStream_t s)
   {
     const uint32_t units = ((p.blocksX + 63u) / 64u) * p.blocksY;
-    const dim3 grid((units + kTpbWaves - 1) / kTpbWaves), block(64 * kTpbWaves);
-    if (p.floatFast)
+    const int v = (channels == 4 ? 4 : 0) | (p.floatFast ? 2 : 0) | (p.vecIn ? 1 : 0);
+#define LIMG_TPB_LAUNCH(CH, FAST, DIRECT) hipLaunchKernelGGL((k_fit_tpb<CH, FAST, DIRECT>), dim3((units + tpb_waves<DIRECT>() - 1) / tpb_waves<DIRECT>()), dim3(64 * tpb_waves<DIRECT>()), 0, s, p)
+    switch (v)
     {
-      if (channels == 4) hipLaunchKernelGGL((k_fit_tpb<4, true>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((k_fit_tpb<3, true>), grid, block, 0, s, p);
+    case 0: LIMG_TPB_LAUNCH(3, false, false); break;
+    case 1: LIMG_TPB_LAUNCH(3, false, true); break;
+    case 2: LIMG_TPB_LAUNCH(3, true, false); break;
+    case 3: LIMG_TPB_LAUNCH(3, true, true); break;
+    case 4: LIMG_TPB_LAUNCH(4, false, false); break;
+    case 5: LIMG_TPB_LAUNCH(4, false, true); break;
+    case 6: LIMG_TPB_LAUNCH(4, true, false); break;
+    default: LIMG_TPB_LAUNCH(4, true, true); break;
     }
-    else if (channels == 4) hipLaunchKernelGGL((k_fit_tpb<4, false>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((k_fit_tpb<3, false>), grid, block, 0, s, p);
+#undef LIMG_TPB_LAUNCH
   }
 }
