@@ -63,7 +63,7 @@ typedef struct limg_hip_options
   int32_t force_split_kernels; /* non-0: use the three-launch path (fit+search, scan, dither+store) even where the persistent kernel applies */
   int32_t dither_pcg;          /* non-0: the reference's PCG dither (src/limg.cpp:799-822, what it runs on hosts without AES-NI) instead of the AES one */
   int32_t test_record_limit;   /* test hook, 0 = default: blocks with a record value of magnitude >= this take the generic 32-bit trial
-                                  (default 8001: a fit of byte pixels never gets there); 1 sends every block through it */
+                                  (default 2701 -- up to 2700 the packed 16-bit trial is exact by construction; a fit of byte pixels stays below 2041); 1 sends every block through it */
   int32_t float_mode;          /* 0 (default) = EXACT: the float stage op for op as the reference's strict SSE build (DPPS order, x86 RSQRTPS table, correctly
                                   rounded divisions): every plane bit-identical to the reference.  1 = FAST: hardware v_rsq_f32 / v_rcp_f32 and fused multiply-adds;
                                   contract: the integer stage stays bit-exact given the same records, extrema within +-2 LSB on >= 99.9 % of blocks, perceptual PSNR

@@ -211,7 +211,7 @@ namespace
                         c->opt.forced_shift[2] >= 0 && c->opt.forced_shift[2] <= 8;
     for (int i = 0; i < 3; i++) p.forced[i] = forced ? c->opt.forced_shift[i] : -1;
     p.floatFast = (c->opt.float_mode == 1 && !fitOnly) ? 1 : 0;
-    p.recordLimit = c->opt.test_record_limit > 0 ? c->opt.test_record_limit - 1 : 8000;
+    p.recordLimit = c->opt.test_record_limit > 0 ? c->opt.test_record_limit - 1 : 2700; // see kTermBias in limg_hip_kernels.hip: 3 * 2700 + 1 < 0x2000
     const Partition pt = partition(sizeY, poolThreads);
     p.chainCount = pt.chainCount; p.chainRows = pt.chainRows;
 

@@ -25,7 +25,7 @@ namespace limg_hip
     uint64_t maxBlock;       // maxBlockBitCrushError
     int32_t crushBits, fast; // reference: src/limg.cpp:2192-2197
     int32_t forced[3];       // -1 or forced shift
-    int32_t recordLimit;     // |record value| above which a block takes the generic 32-bit trial (8000; tests lower it to exercise that path)
+    int32_t recordLimit;     // |record value| above which a block takes the generic 32-bit trial (2700: the bound the packed trial's 16-bit terms are proven for; tests lower it to exercise the generic path)
     // chain partition (reference: src/limg.cpp:2114-2134), in block rows
     uint32_t chainCount, chainRows; // chain c (< chainCount-1) owns block rows [c*chainRows, (c+1)*chainRows); the last owns the rest
     // per-block scratch / compact outputs

@@ -52,8 +52,10 @@ namespace limg_hip
     //  * the weighted squared error is one v_dot2_u32_u16.
     // The R term of every factor carries a +0x2000 bias (folded into the additive constant, so it costs nothing) which keeps
     // the low halves positive: the three packed terms can then be summed with one plain 32-bit add3 without a borrow reaching
-    // the G half.  Valid while every record value is small (|v| <= p.recordLimit = 8000, far above what a fit of byte pixels can produce:
-    // |A| <= 765, |B| <= 1020, |C| <= 2040); phase E falls back to the generic 32-bit form otherwise.
+    // the G half.  Valid while every term stays inside (-0x2000, 0x2000): a term is (d * n + (min << 8) + 128) >> 8 with d <= 255 and n = max - min, so
+    // |term| <= |min| + |n| + 1 <= 3 L + 1 when every record value is at most L in magnitude: L = p.recordLimit = 2700 (3 * 2700 + 1 = 8101 < 8192).  Then the
+    // biased R halves are positive, three of them sum to < 65536 (no carry into G), the three G terms sum to an int16, and px - sum fits an int16 for the packed
+    // subtract / clamp.  A fit of byte pixels cannot get near it (|A| <= 765, |B| <= 1020, |C| <= 2040); phase E falls back to the generic 32-bit form otherwise.
     typedef short short2_t __attribute__((ext_vector_type(2)));
     typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
     constexpr int kTermBias = 0x2000;

@@ -147,12 +147,14 @@ def test_pcg_dither(gpu, oracle, w, h):
     _assert_planes(got, oracle.encode3d(img, True, dither_mode=DITHER_PCG), (w, h))
 
 
+@pytest.mark.parametrize("limit", [1, 120])
 @pytest.mark.parametrize("alpha,fast", [(True, True), (False, True), (True, False)])
-def test_generic_trial_path(gpu, oracle, alpha, fast):
-    """The packed 16-bit trial is only valid for small record values; larger ones (never produced by a fit of byte pixels)
-    take a generic 32-bit trial.  The test hook sends every block through that path."""
+def test_generic_trial_path(gpu, oracle, alpha, fast, limit):
+    """The packed 16-bit trial is exact by construction for record values up to 2700 in magnitude (3 * 2700 + 1 < 0x2000, limg_hip_kernels.hip); larger ones
+    (never produced by a fit of byte pixels, which stays below 2041) take a generic 32-bit trial.  The test hook lowers the limit: 1 sends every block through
+    the generic path, 120 mixes the two paths inside every work strip (the dynamic block queue hands both kinds to every wave)."""
     img = oracle.photo_noise(256, 32, 37)
-    gpu.set_options(force_split=(gpu.mode == "split"), test_record_limit=1)
+    gpu.set_options(force_split=(gpu.mode == "split"), test_record_limit=limit)
     try:
         got = gpu.encode3d(img, alpha, fast=fast)
     finally:
