@@ -100,9 +100,9 @@ namespace limg_hip
       t.cC = sC;
     }
 
-    // the trial proper on the cached terms: clamp, differences, weighted squared error, pixel check, block sum
+    // the trial proper on the cached terms: clamp, differences, weighted squared error per pixel
     template <bool FULL>
-    __device__ __forceinline__ bool trial_core(const TrialState &t, const bool active, const uint32_t maxPixel32, const uint32_t blockLimit, uint32_t &blockError)
+    __device__ __forceinline__ uint32_t trial_pixel_error(const TrialState &t, const bool active)
     {
       const uint32_t estRG = t.tA_RG + t.tB_RG + t.tC_RG; // low half: R estimate + 3 * bias; no carry / borrow crosses the halves
       const int estB = t.tA_B + t.tB_B + t.tC_B;
@@ -117,6 +117,14 @@ namespace limg_hip
       const uint32_t wRG = low_red ? 0x00040002u : 0x00040003u;
       uint32_t err = __builtin_amdgcn_udot2(sq, __builtin_bit_cast(ushort2_t, wRG), mul_u24(sqB, low_red ? 3u : 2u), false);
       if (!FULL) err = active ? err : 0u;
+      return err;
+    }
+
+    // pixel check, then block sum
+    template <bool FULL>
+    __device__ __forceinline__ bool trial_core(const TrialState &t, const bool active, const uint32_t maxPixel32, const uint32_t blockLimit, uint32_t &blockError)
+    {
+      const uint32_t err = trial_pixel_error<FULL>(t, active);
       if (__builtin_amdgcn_ballot_w64(err > maxPixel32) != 0ull) return false;
       const uint32_t be = wave_sum(err);
       blockError = be;
@@ -147,7 +155,7 @@ namespace limg_hip
       asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(v) : "s"(base), "s"(byteOffset) : "memory");
       return v;
     }
-    __device__ __forceinline__ void sload_wait(uint4s_t &a, uint4s_t &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)::"memory"); }
+    __device__ __forceinline__ void sload_wait(uint4s_t &a, uint4s_t &b, const uint32_t after) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b) : "v"(after) : "memory"); } // `after` only orders it (as an output it would make a and b divergent)
 
     template <bool FULL>
     __device__ __forceinline__ void search_fast_automaton(TrialState &t, const bool active, const uint32_t maxPixel32, const uint32_t blockLimit, uint32_t shift[3])
@@ -163,11 +171,21 @@ namespace limg_hip
         if (chg & 1u) rebuild_A(t, ex & 15u, ez & 511u);
         if (chg & 2u) rebuild_B(t, (ex >> 4) & 15u, (ez >> 9) & 511u);
         if (chg & 4u) rebuild_C(t, (ex >> 8) & 15u, ez >> 18);
-        uint32_t be;
-        const bool ok = trial_core<FULL>(t, active, maxPixel32, blockLimit, be);
-        sload_wait(ep, ef);
-        chg = ex >> (ok ? 12u : 15u); // bits 0..2; what lies above is never looked at
-        ex = ok ? ep.x : ef.x; ey = ok ? ep.y : ef.y; ez = ok ? ep.z : ef.z;
+        const uint32_t err = trial_pixel_error<FULL>(t, active);
+        sload_wait(ep, ef, err); // not before the trial's arithmetic has been issued
+        // two tails on purpose: a pixel failure (the common way to fail) needs no outcome flag, no select and no block sum -- scalar instructions are what
+        // this loop is short of
+        if (__builtin_amdgcn_ballot_w64(err > maxPixel32) != 0ull)
+        {
+          chg = ex >> 15u; // bits 0..2; what lies above is never looked at
+          ex = ef.x; ey = ef.y; ez = ef.z;
+        }
+        else
+        {
+          const bool ok = wave_sum(err) < blockLimit; // be * 16 < maxBlock * n, see phase E
+          chg = ex >> (ok ? 12u : 15u);
+          ex = ok ? ep.x : ef.x; ey = ok ? ep.y : ef.y; ez = ok ? ep.z : ef.z;
+        }
       }
       shift[0] = ex & 15u; shift[1] = (ex >> 4) & 15u; shift[2] = (ex >> 8) & 15u;
     }
