@@ -142,20 +142,19 @@ namespace limg_hip
       return trial_core<FULL>(t, active, maxPixel32, blockLimit, blockError);
     }
 
-    // a10 + a11 as a table-driven automaton: one trial loop, the next two candidate states are fetched (scalar loads) while
-    // the current trial computes, and the outcome selects between them.  The scalar side of the loop is kept minimal -- the scalar unit (one per CU) is a
-    // co-bottleneck of this kernel: 8 extra scalar instructions per trial cost 10 % (measured) -- so the table carries, per edge, WHICH factors the next triple
-    // changes (no compares against cached shifts), byte offsets (no shifts), and its base address stays in SGPRs.
-    // scalar 8-byte load issued now, consumed after `sload_wait` (the compiler would otherwise sink the load to its use and
-    // expose the scalar-cache latency on every trial)
+    // a10 + a11 as a table-driven automaton: one trial loop; the outcome of a trial picks the byte offset of the next state's 16-byte entry, which one scalar load
+    // fetches.  The scalar side of the loop is kept minimal -- the scalar unit (one per CU) is a co-bottleneck of this kernel: 8 extra scalar instructions per
+    // trial cost 10 % (measured) -- so an entry says WHICH factors its triple changes against its predecessor's (the automaton is a tree: no compares against
+    // cached shifts), holds byte offsets (no shifts) and the re-expansion multipliers, and the table's base address stays in SGPRs.  The load is NOT issued
+    // ahead for both outcomes: the other waves of the SIMD cover its latency, and the two address computations, the second load and the selects between two
+    // prefetched entries were scalar instructions too (measured equal, with less code).
     typedef unsigned int uint4s_t __attribute__((ext_vector_type(4)));
     __device__ __forceinline__ uint4s_t sload4(const uint4 *base, uint32_t byteOffset)
     {
       uint4s_t v;
-      asm volatile("s_load_dwordx4 %0, %1, %2" : "=&s"(v) : "s"(base), "s"(byteOffset) : "memory");
+      asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(base), "s"(byteOffset) : "memory");
       return v;
     }
-    __device__ __forceinline__ void sload_wait(uint4s_t &a, uint4s_t &b, const uint32_t after) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b) : "v"(after) : "memory"); } // `after` only orders it (as an output it would make a and b divergent)
 
     template <bool FULL>
     __device__ __forceinline__ void search_fast_automaton(TrialState &t, const bool active, const uint32_t maxPixel32, const uint32_t blockLimit, uint32_t shift[3])
@@ -163,29 +162,19 @@ namespace limg_hip
       const uint4 *tab = d_search_tab;
       asm volatile("" : "+s"(tab)); // opaque: otherwise the address is rematerialised (s_getpc + 2 adds) in every iteration
       // entry 0 as immediates (the opaque base above would make reading it a memory round trip per block)
-      uint32_t ex = LIMG_SEARCH_ROOT_X, ey = LIMG_SEARCH_ROOT_Y, ez = LIMG_SEARCH_ROOT_Z;
-      uint32_t chg = 7u; // nothing cached yet
+      uint32_t ex = LIMG_SEARCH_ROOT_X, ey = LIMG_SEARCH_ROOT_Y, ez = LIMG_SEARCH_ROOT_Z, ew = LIMG_SEARCH_ROOT_W;
       while (!(ex >> 31))
       {
-        uint4s_t ep = sload4(tab, ey & 0xFFFFu), ef = sload4(tab, ey >> 16);
-        if (chg & 1u) rebuild_A(t, ex & 15u, ez & 511u);
-        if (chg & 2u) rebuild_B(t, (ex >> 4) & 15u, (ez >> 9) & 511u);
-        if (chg & 4u) rebuild_C(t, (ex >> 8) & 15u, ez >> 18);
+        if (ex & 0x1000u) rebuild_A(t, ex & 15u, ew & 511u);
+        if (ex & 0x2000u) rebuild_B(t, (ex >> 4) & 15u, (ew >> 9) & 511u);
+        if (ex & 0x4000u) rebuild_C(t, (ex >> 8) & 15u, ew >> 18);
         const uint32_t err = trial_pixel_error<FULL>(t, active);
-        sload_wait(ep, ef, err); // not before the trial's arithmetic has been issued
-        // two tails on purpose: a pixel failure (the common way to fail) needs no outcome flag, no select and no block sum -- scalar instructions are what
-        // this loop is short of
-        if (__builtin_amdgcn_ballot_w64(err > maxPixel32) != 0ull)
-        {
-          chg = ex >> 15u; // bits 0..2; what lies above is never looked at
-          ex = ef.x; ey = ef.y; ez = ef.z;
-        }
-        else
-        {
-          const bool ok = wave_sum(err) < blockLimit; // be * 16 < maxBlock * n, see phase E
-          chg = ex >> (ok ? 12u : 15u);
-          ex = ok ? ep.x : ef.x; ey = ok ? ep.y : ef.y; ez = ok ? ep.z : ef.z;
-        }
+        // two tails on purpose: a pixel failure (the common way to fail) needs no outcome flag, no select and no block sum
+        uint32_t off;
+        if (__builtin_amdgcn_ballot_w64(err > maxPixel32) != 0ull) off = ez;
+        else off = (wave_sum(err) < blockLimit) ? ey : ez; // be * 16 < maxBlock * n, see phase E
+        const uint4s_t e = sload4(tab, off);
+        ex = e.x; ey = e.y; ez = e.z; ew = e.w;
       }
       shift[0] = ex & 15u; shift[1] = (ex >> 4) & 15u; shift[2] = (ex >> 8) & 15u;
     }

@@ -134,7 +134,7 @@ def test_search_automaton_replays_reference_searches():
     words = mst.encode(mst.build())
     hdr = open(os.path.join(ROOT, "limg_amd", "csrc", "limg_search_table.h")).read()
     assert "LIMG_SEARCH_STATES %d" % len(words) in hdr
-    assert all("{0x%08xu, 0x%08xu, 0x%08xu, 0u}" % w in hdr for w in words[:50] + words[-50:])
+    assert all(mst.ENTRY_FMT % w in hdr for w in words[:50] + words[-50:])
     z = gu.blocks()
     for bi in range(int(z["count"])):
         for ch in (4, 3):

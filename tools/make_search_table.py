@@ -120,32 +120,37 @@ def build():
 
 
 def encode(trans):
-    """entry = (word0, word1):
-       word0 = a | b << 4 | c << 8 | changed_on_pass << 12 | changed_on_fail << 15 | final << 31
-       word1 = byte offset of the next entry on pass | byte offset on fail << 16          (entries are 16 bytes)
-       word2 = mul(a) | mul(b) << 9 | mul(c) << 18, mul(s) = (1 << s) + decode_bias(s): the re-expansion multiplier of each shift, so that the kernel's scalar
+    """entry = (word0, word1, word2, word3), 16 bytes:
+       word0 = a | b << 4 | c << 8 | changed << 12 | final << 31
+       word1 = byte offset of the next entry on pass
+       word2 = byte offset of the next entry on fail
+       word3 = mul(a) | mul(b) << 9 | mul(c) << 18, mul(s) = (1 << s) + decode_bias(s): the re-expansion multiplier of each shift, so that the kernel's scalar
                stream extracts it with one bit-field instruction instead of computing it (5 instructions)
-    changed_on_* = which of the three shifts (bit 0 = A, 1 = B, 2 = C) differ between this entry's triple and the successor's: the kernel keeps the terms of the
-    last evaluated triple and rebuilds exactly those factors -- no compares against cached shifts in its scalar instruction stream.  0 for a final successor."""
+    changed = which of the three shifts (bit 0 = A, 1 = B, 2 = C) differ between this entry's triple and its predecessor's (7 for the start state, 0 for a
+    final one): the kernel keeps the terms of the last evaluated triple and rebuilds exactly those factors -- no compares against cached shifts in its scalar
+    instruction stream.  The automaton is a tree, so every state has exactly one predecessor and the mask is a property of the state (asserted)."""
     MUL = [1, 2, 4, 8, 17, 36, 85, 255, 256]  # (1 << s) + decode_bias(s), src/limg_bit_crush_simd.h:611-619
 
     def muls(t):
         return MUL[t[0]] | (MUL[t[1]] << 9) | (MUL[t[2]] << 18)
 
-    def changed(t, nxt):
-        if nxt[0] == "final":
-            return 0
-        u = nxt[0]
-        return sum(1 << k for k in range(3) if t[k] != u[k])
-    words = []
+    changed = {0: 7}
     for t in trans:
         if t[0] == "final":
+            continue
+        tri, p, f = t
+        for nxt in (p, f):
+            m = 0 if trans[nxt][0] == "final" else sum(1 << k for k in range(3) if tri[k] != trans[nxt][0][k])
+            assert changed.setdefault(nxt, m) == m, nxt
+    words = []
+    for i, t in enumerate(trans):
+        if t[0] == "final":
             a, b, c = t[1]
-            words.append((a | (b << 4) | (c << 8) | (1 << 31), 0, 0))
+            words.append((a | (b << 4) | (c << 8) | (1 << 31), 0, 0, 0))
         else:
             (a, b, c), p, f = t
             assert p * 16 < 65536 and f * 16 < 65536
-            words.append((a | (b << 4) | (c << 8) | (changed((a, b, c), trans[p]) << 12) | (changed((a, b, c), trans[f]) << 15), (p * 16) | ((f * 16) << 16), muls((a, b, c))))
+            words.append((a | (b << 4) | (c << 8) | (changed[i] << 12), p * 16, f * 16, muls((a, b, c))))
     return words
 
 
@@ -155,45 +160,47 @@ def walk(words, outcome):
     s = 0
     n = 0
     cached = [None, None, None]
-    chg = 7
     while not (words[s][0] >> 31):
-        w0, w1, w2 = words[s]
+        w0, w1, w2, w3 = words[s]
         t = (w0 & 15, (w0 >> 4) & 15, (w0 >> 8) & 15)
-        assert [(w2 >> (9 * k)) & 511 for k in range(3)] == [[1, 2, 4, 8, 17, 36, 85, 255, 256][x] for x in t]
+        assert [(w3 >> (9 * k)) & 511 for k in range(3)] == [[1, 2, 4, 8, 17, 36, 85, 255, 256][x] for x in t]
         for k in range(3):
-            if chg & (1 << k):
+            if (w0 >> 12) & (1 << k):
                 cached[k] = t[k]
         assert tuple(cached) == t, (s, cached, t)
         n += 1
-        ok = outcome(*t)
-        chg = (w0 >> (12 if ok else 15)) & 7
-        off = (w1 & 0xFFFF) if ok else (w1 >> 16)
+        off = w1 if outcome(*t) else w2
         assert off % 16 == 0
         s = off // 16
     w0 = words[s][0]
     return (w0 & 15, (w0 >> 4) & 15, (w0 >> 8) & 15), n
 
 
+ENTRY_FMT = "{0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu}"
+
+
 def main():
     trans = build()
     words = encode(trans)
-    body = ",\n".join("  " + ", ".join("{0x%08xu, 0x%08xu, 0x%08xu, 0u}" % w for w in words[i:i + 4]) for i in range(0, len(words), 4))
+    body = ",\n".join("  " + ", ".join(ENTRY_FMT % w for w in words[i:i + 4]) for i in range(0, len(words), 4))
     text = """// GENERATED by tools/make_search_table.py -- do not edit.
 // Decision automaton of the reference's default shift search (src/limg_bit_crush.h:331-392, :502-614): %d states.
-// entry (16 bytes) = { a | b << 4 | c << 8 | changed_on_pass << 12 | changed_on_fail << 15 | final << 31,  byte offset of the next entry on pass | on fail << 16,
-//                     mul(a) | mul(b) << 9 | mul(c) << 18,  0 };
-// changed_on_* = which shifts (bit 0 A, 1 B, 2 C) the successor's triple changes; state 0 is the start; a final entry carries the resulting shift triple.
+// entry (16 bytes) = { a | b << 4 | c << 8 | changed << 12 | final << 31,  byte offset of the next entry on pass,  byte offset of the next entry on fail,
+//                     mul(a) | mul(b) << 9 | mul(c) << 18 };
+// changed = which shifts (bit 0 A, 1 B, 2 C) this entry's triple changes against its (only) predecessor's; state 0 is the start; a final entry carries the
+// resulting shift triple.
 #ifndef LIMG_SEARCH_TABLE_H
 #define LIMG_SEARCH_TABLE_H
 #define LIMG_SEARCH_STATES %d
 #define LIMG_SEARCH_ROOT_X 0x%08xu /* entry 0, as immediates: the kernel starts every block's search without a load */
 #define LIMG_SEARCH_ROOT_Y 0x%08xu
 #define LIMG_SEARCH_ROOT_Z 0x%08xu
+#define LIMG_SEARCH_ROOT_W 0x%08xu
 #define LIMG_SEARCH_TABLE_INIT { \\
 %s \\
 }
 #endif
-""" % (len(words), len(words), words[0][0], words[0][1], words[0][2], body.replace("\n", " \\\n"))
+""" % (len(words), len(words), words[0][0], words[0][1], words[0][2], words[0][3], body.replace("\n", " \\\n"))
     path = os.path.join(ROOT, "limg_amd", "csrc", "limg_search_table.h")
     open(path, "w").write(text)
     print("wrote", path, len(words), "states")
