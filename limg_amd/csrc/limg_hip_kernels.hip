@@ -287,7 +287,8 @@ namespace limg_hip
 
     // the 7 block-uniform planes, straight from registers: 16 bytes per lane = four rows of 256 contiguous bytes (8 blocks x 8 px) per store instruction where
     // the rows allow it (p.vecPlanes: width a multiple of 4, 16-byte aligned planes), 4 bytes per lane = one row per instruction otherwise
-    __device__ __forceinline__ void phase_f_store_const(const EncodeParams &p, const StripLds &L, uint32_t x0, uint32_t y0, uint32_t ry, int lane, int wave)
+    template <class P>
+    __device__ __forceinline__ void phase_f_store_const(const P &p, const StripLds &L, uint32_t x0, uint32_t y0, uint32_t ry, int lane, int wave)
     {
       const uint32_t wx0 = x0 + wave * 64;
       if (wx0 >= p.sizeX) return;
@@ -326,8 +327,8 @@ namespace limg_hip
     }
 
     // dither + decode of the wave's 8 blocks into the per-wave staging areas, then the per-pixel planes' stores
-    template <int CH>
-    __device__ __forceinline__ void phase_f_pixels(const EncodeParams &p, const StripLds &L, uint32_t strip, uint32_t x0, uint32_t y0, uint32_t ry, int lane, int wave, int tid)
+    template <int CH, class P>
+    __device__ __forceinline__ void phase_f_pixels(const P &p, const StripLds &L, uint32_t strip, uint32_t x0, uint32_t y0, uint32_t ry, int lane, int wave, int tid)
     {
       uint32_t *dec = L.dec + wave * 512;
       uint8_t *out = L.out; // [3 planes][8 rows][256 px]: strip-wide rows, so that the stores below write whole 128-byte lines
@@ -551,7 +552,8 @@ namespace limg_hip
     }
 
     // called by all 64 lanes of one wave; returns the number of dither calls of the chain before strip `id`
-    __device__ __forceinline__ uint32_t lookback_base(const EncodeParams &p, uint32_t id, uint32_t headId, uint32_t agg, int lane)
+    template <class P>
+    __device__ __forceinline__ uint32_t lookback_base(const P &p, uint32_t id, uint32_t headId, uint32_t agg, int lane)
     {
       if (id == headId) return 0u;
       uint32_t base = 0;
@@ -616,8 +618,8 @@ namespace limg_hip
     constexpr int kParkFac = 0, kParkRec = 6144, kParkShift = 6144 + 1536, kParkBytes = 8192;
 
     // PREFIT: the float stage already ran in k_fit_tpb (limg_hip_fit_tpb.hip, one lane per block); this step loads the records and goes on with phase E.
-    template <int CH, bool PERSIST, bool FAST, bool PREFIT>
-    __device__ __forceinline__ void fit_search_strip(const EncodeParams &p, const uint32_t id, uint8_t *lds, uint8_t *park, const int tid)
+    template <int CH, bool PERSIST, bool FAST, bool PREFIT, class P>
+    __device__ __forceinline__ void fit_search_strip(const P &p, const uint32_t id, uint8_t *lds, uint8_t *park, const int tid)
     {
       // the 4 KiB RSQRTPS table is read straight from global memory (it lives in the CU's vector L1): keeping a copy in LDS would
       // cost the fifth workgroup per CU
@@ -1224,8 +1226,8 @@ namespace limg_hip
     // PERSIST == true : from the look-back over the descriptors, and the strip's inclusive count is published first thing.
     static_assert(kPhaseFBytes + kStripBlocks * 48 <= kLdsTotal - kLdsStrip - 16, "the F step's LDS overlays the E step's");
 
-    template <int CH, bool PERSIST>
-    __device__ __forceinline__ void dither_store_strip(const EncodeParams &p, const uint32_t id, uint8_t *fbase, const uint8_t *park, const int tid)
+    template <int CH, bool PERSIST, class P>
+    __device__ __forceinline__ void dither_store_strip(const P &p, const uint32_t id, uint8_t *fbase, const uint8_t *park, const int tid)
     {
       int16_t *s_rec = reinterpret_cast<int16_t *>(fbase + kPhaseFBytes); // [32][24]
       const int lane = tid & 63, wave = tid >> 6;
@@ -1343,6 +1345,11 @@ namespace limg_hip
       const uint32_t S = p.stripsX * p.blocksY;
       uint8_t *park = p.park + (size_t)blockIdx.x * 2 * kParkBytes;
       uint32_t prev = 0xFFFFFFFFu, slot = 0;
+      // The two steps read the parameters straight from the kernel-argument segment, through a pointer the compiler cannot see through from one step to the
+      // next: a field is then fetched (one scalar load, scalar-cache hit) where a step uses it.  Read from `p`, all ~70 dwords are loaded once before the
+      // loop and kept alive across it -- more SGPRs than there are, so the compiler parks them in VGPR lanes and pays a quarter-rate v_readlane per use.
+      typedef const __attribute__((address_space(4))) EncodeParams KernArgs;
+      KernArgs *const kargs = (KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
       for (;;)
       {
         __syncthreads(); // the previous step's LDS use is over (and the rsqrt table is in place)
@@ -1351,13 +1358,17 @@ namespace limg_hip
         const uint32_t t = s_ticket;
         int tid_e = tid;
         asm volatile("" : "+v"(tid_e));
-        if (t < S) fit_search_strip<CH, true, FAST, PREFIT>(p, t, s_lds, park + slot * kParkBytes, tid_e);
+        KernArgs *pe = kargs;
+        asm volatile("" : "+s"(pe));
+        if (t < S) fit_search_strip<CH, true, FAST, PREFIT>(*pe, t, s_lds, park + slot * kParkBytes, tid_e);
         if (prev != 0xFFFFFFFFu)
         {
           __syncthreads();
           int tid_f = tid;
           asm volatile("" : "+v"(tid_f));
-          dither_store_strip<CH, true>(p, prev, s_lds + kLdsStrip, park + (slot ^ 1u) * kParkBytes, tid_f);
+          KernArgs *pf = kargs;
+          asm volatile("" : "+s"(pf));
+          dither_store_strip<CH, true>(*pf, prev, s_lds + kLdsStrip, park + (slot ^ 1u) * kParkBytes, tid_f);
         }
         if (t >= S) break;
         prev = t;
