@@ -67,7 +67,8 @@ namespace limg_hip
       uint32_t pxRGb; // (R + 3 * bias) | G << 16
       uint32_t loRG, hiRG;
       int pxB, pxBlo;
-      // wave-uniform record view: n* scalars, m* = (min << 8) + 128 (+ bias << 8 for R)
+      // wave-uniform record view: n* scalars, m* = (min << 8) + 128 (+ bias << 8 for R); the B channel's are negated (n = -n, m = 255 - m) and mA[2] also
+      // carries the pixel's B << 8 (per lane): see trial_pixel_error
       int nA[3], nB[3], nC[3];
       int mA[3], mB[3], mC[3];
       // cached terms and the shifts they were built for
@@ -105,11 +106,11 @@ namespace limg_hip
     __device__ __forceinline__ uint32_t trial_pixel_error(const TrialState &t, const bool active)
     {
       const uint32_t estRG = t.tA_RG + t.tB_RG + t.tC_RG; // low half: R estimate + 3 * bias; no carry / borrow crosses the halves
-      const int estB = t.tA_B + t.tB_B + t.tC_B;
+      const int dBraw = t.tA_B + t.tB_B + t.tC_B; // == pxB - (sum of the three B terms): the B terms are kept negated and factor A's carries the pixel (phase E)
       short2_t e = __builtin_bit_cast(short2_t, t.pxRGb) - __builtin_bit_cast(short2_t, estRG);
       e = __builtin_elementwise_max(e, __builtin_bit_cast(short2_t, t.loRG));
       e = __builtin_elementwise_min(e, __builtin_bit_cast(short2_t, t.hiRG));
-      int dB = med3_i32(t.pxB - estB, t.pxBlo, t.pxB); // clamp(px - S, px - 255, px)
+      int dB = med3_i32(dBraw, t.pxBlo, t.pxB); // clamp(px - S, px - 255, px)
       const ushort2_t eu = __builtin_bit_cast(ushort2_t, e);
       const ushort2_t sq = eu * eu; // d^2 <= 65025 fits 16 bits; (-d)^2 mod 2^16 == d^2
       const uint32_t sqB = (uint32_t)mul_i24(dB, dB);
@@ -969,8 +970,10 @@ namespace limg_hip
             if (PREFIT && c < 3)
             { // the packed trial's integer operands, once per block here instead of per lane in phase E: n = max - min, m = (min << 8) + 128 (+ the R bias)
               int *tc = s_trialc + (wave * kBlocksPerWave + b) * kTrialConstDw;
-              tc[f * 3 + c] = (int)nrm[r];
-              tc[9 + f * 3 + c] = ((int)off[r] << 8) + 128 + (c == 0 ? (kTermBias << 8) : 0);
+              // B channel negated: -floor(x / 256) == floor((-x + 255) / 256), so (d * -n + (255 - m)) >> 8 is minus the term -- the trial then needs no subtraction
+              const int n_ = (int)nrm[r], m_ = ((int)off[r] << 8) + 128 + (c == 0 ? (kTermBias << 8) : 0);
+              tc[f * 3 + c] = c == 2 ? -n_ : n_;
+              tc[9 + f * 3 + c] = c == 2 ? 255 - m_ : m_;
             }
           }
         }
@@ -1066,8 +1069,14 @@ namespace limg_hip
                 const int loA = blkE->rec[c], hiA = blkE->rec[4 + c], loB = blkE->rec[8 + c], hiB = blkE->rec[12 + c], loC = blkE->rec[16 + c], hiC = blkE->rec[20 + c];
                 t.nA[c] = hiA - loA; t.nB[c] = hiB - loB; t.nC[c] = hiC - loC;
                 t.mA[c] = (loA << 8) + 128 + bias; t.mB[c] = (loB << 8) + 128 + bias; t.mC[c] = (loC << 8) + 128 + bias;
+                if (c == 2)
+                { // B channel negated, as in the PREFIT table above
+                  t.nA[c] = -t.nA[c]; t.nB[c] = -t.nB[c]; t.nC[c] = -t.nC[c];
+                  t.mA[c] = 255 - t.mA[c]; t.mB[c] = 255 - t.mB[c]; t.mC[c] = 255 - t.mC[c];
+                }
               }
             }
+            t.mA[2] += t.pxB << 8; // per pixel: factor A's (negated) B term becomes pxB - term, so the three B terms sum to pxB - estimate
             t.cA = t.cB = t.cC = 0xFFu;
             t.tA_RG = t.tB_RG = t.tC_RG = 0; t.tA_B = t.tB_B = t.tC_B = 0;
             if (n == 64)
