@@ -40,7 +40,8 @@ namespace limg_hip
     constexpr int kVDw = 260;   // per-block stride of the parked contributions: 64 px * 4 ch + 4 pad => the (block, channel) walkers hit 32 distinct banks
 
     // decision automaton of the default shift search (tools/make_search_table.py); read with scalar loads
-    __constant__ uint4 d_search_tab[LIMG_SEARCH_STATES] = LIMG_SEARCH_TABLE_INIT;
+    struct __attribute__((aligned(32))) SearchEntry { uint32_t w[8]; };
+    __constant__ SearchEntry d_search_tab[LIMG_SEARCH_STATES] = LIMG_SEARCH_TABLE_INIT;
 
     // ---- a9, packed form ------------------------------------------------------------------------------------------------
     // Same integers as `trial` above, arranged for gfx950's packed 16-bit VALU:
@@ -79,7 +80,7 @@ namespace limg_hip
 
     __device__ __forceinline__ void make_terms(const uint32_t f, const uint32_t s, const uint32_t mul, const int n[3], const int m[3], uint32_t &tRG, int &tB)
     {
-      const int d = (int)mul_u24_uniform(f >> s, mul); // mul == shift_mul(s); <= 255 * 256; shift and multiplier are wave-uniform in the packed trial
+      const int d = (int)mul_u24_uniform(f >> (s & 31u), mul); // mul == shift_mul(s); <= 255 * 256; shift and multiplier are wave-uniform in the packed trial
       const int t0 = mad_i24(d, n[0], m[0]), t1 = mad_i24(d, n[1], m[1]), t2 = mad_i24(d, n[2], m[2]);
       tRG = __builtin_amdgcn_perm((uint32_t)t1, (uint32_t)t0, 0x06050201u); // ((t1 >> 8) & 0xFFFF) << 16 | ((t0 >> 8) & 0xFFFF)
       tB = t2 >> 8;
@@ -149,35 +150,35 @@ namespace limg_hip
     // cached shifts), holds byte offsets (no shifts) and the re-expansion multipliers, and the table's base address stays in SGPRs.  The load is NOT issued
     // ahead for both outcomes: the other waves of the SIMD cover its latency, and the two address computations, the second load and the selects between two
     // prefetched entries were scalar instructions too (measured equal, with less code).
-    typedef unsigned int uint4s_t __attribute__((ext_vector_type(4)));
-    __device__ __forceinline__ uint4s_t sload4(const uint4 *base, uint32_t byteOffset)
+    typedef unsigned int uint8s_t __attribute__((ext_vector_type(8)));
+    __device__ __forceinline__ uint8s_t sload8(const SearchEntry *base, uint32_t byteOffset)
     {
-      uint4s_t v;
-      asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(base), "s"(byteOffset) : "memory");
+      uint8s_t v;
+      asm volatile("s_load_dwordx8 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(base), "s"(byteOffset) : "memory");
       return v;
     }
 
     template <bool FULL>
     __device__ __forceinline__ void search_fast_automaton(TrialState &t, const bool active, const uint32_t maxPixel32, const uint32_t blockLimit, uint32_t shift[3])
     {
-      const uint4 *tab = d_search_tab;
+      const SearchEntry *tab = d_search_tab;
       asm volatile("" : "+s"(tab)); // opaque: otherwise the address is rematerialised (s_getpc + 2 adds) in every iteration
       // entry 0 as immediates (the opaque base above would make reading it a memory round trip per block)
-      uint32_t ex = LIMG_SEARCH_ROOT_X, ey = LIMG_SEARCH_ROOT_Y, ez = LIMG_SEARCH_ROOT_Z, ew = LIMG_SEARCH_ROOT_W;
-      while (!(ex >> 31))
-      {
-        if (ex & 0x1000u) rebuild_A(t, ex & 15u, ew & 511u);
-        if (ex & 0x2000u) rebuild_B(t, (ex >> 4) & 15u, (ew >> 9) & 511u);
-        if (ex & 0x4000u) rebuild_C(t, (ex >> 8) & 15u, ew >> 18);
+      constexpr uint32_t root[8] = LIMG_SEARCH_ROOT;
+      uint8s_t e = { root[0], root[1], root[2], root[3], root[4], root[5], root[6], root[7] };
+      while (!(e[0] >> 31))
+      { // every field sits in an SGPR of its own: no extraction.  (e[0] & 31 is the shift amount as v_lshrrev_b32 reads it -- the mask costs nothing)
+        if (e[0] & 0x20u) rebuild_A(t, e[0] & 31u, e[5]);
+        if (e[0] & 0x40u) rebuild_B(t, e[3], e[6]);
+        if (e[0] & 0x80u) rebuild_C(t, e[4], e[7]);
         const uint32_t err = trial_pixel_error<FULL>(t, active);
         // two tails on purpose: a pixel failure (the common way to fail) needs no outcome flag, no select and no block sum
         uint32_t off;
-        if (__builtin_amdgcn_ballot_w64(err > maxPixel32) != 0ull) off = ez;
-        else off = (wave_sum(err) < blockLimit) ? ey : ez; // be * 16 < maxBlock * n, see phase E
-        const uint4s_t e = sload4(tab, off);
-        ex = e.x; ey = e.y; ez = e.z; ew = e.w;
+        if (__builtin_amdgcn_ballot_w64(err > maxPixel32) != 0ull) off = e[2];
+        else off = (wave_sum(err) < blockLimit) ? e[1] : e[2]; // be * 16 < maxBlock * n, see phase E
+        e = sload8(tab, off);
       }
-      shift[0] = ex & 15u; shift[1] = (ex >> 4) & 15u; shift[2] = (ex >> 8) & 15u;
+      shift[0] = e[0] & 31u; shift[1] = e[3]; shift[2] = e[4];
     }
 
     // generic-path search (see phase E): real function, rarely if ever executed

@@ -119,21 +119,20 @@ def build():
     return trans
 
 
+ENTRY_BYTES = 32
+MUL = [1, 2, 4, 8, 17, 36, 85, 255, 256]  # (1 << s) + decode_bias(s), src/limg_bit_crush_simd.h:611-619
+
+
 def encode(trans):
-    """entry = (word0, word1, word2, word3), 16 bytes:
-       word0 = a | b << 4 | c << 8 | changed << 12 | final << 31
+    """entry = 8 dwords (32 bytes), every field the kernel's scalar stream needs in a register of its own -- nothing to extract:
+       word0 = a | changed << 5 | final << 31      (bits 0..4 are the shift amount of factor A as v_lshrrev_b32 reads it)
        word1 = byte offset of the next entry on pass
        word2 = byte offset of the next entry on fail
-       word3 = mul(a) | mul(b) << 9 | mul(c) << 18, mul(s) = (1 << s) + decode_bias(s): the re-expansion multiplier of each shift, so that the kernel's scalar
-               stream extracts it with one bit-field instruction instead of computing it (5 instructions)
+       word3 = b,  word4 = c
+       word5..7 = mul(a), mul(b), mul(c);  mul(s) = (1 << s) + decode_bias(s), the re-expansion multiplier of a shift
     changed = which of the three shifts (bit 0 = A, 1 = B, 2 = C) differ between this entry's triple and its predecessor's (7 for the start state, 0 for a
     final one): the kernel keeps the terms of the last evaluated triple and rebuilds exactly those factors -- no compares against cached shifts in its scalar
     instruction stream.  The automaton is a tree, so every state has exactly one predecessor and the mask is a property of the state (asserted)."""
-    MUL = [1, 2, 4, 8, 17, 36, 85, 255, 256]  # (1 << s) + decode_bias(s), src/limg_bit_crush_simd.h:611-619
-
-    def muls(t):
-        return MUL[t[0]] | (MUL[t[1]] << 9) | (MUL[t[2]] << 18)
-
     changed = {0: 7}
     for t in trans:
         if t[0] == "final":
@@ -146,11 +145,11 @@ def encode(trans):
     for i, t in enumerate(trans):
         if t[0] == "final":
             a, b, c = t[1]
-            words.append((a | (b << 4) | (c << 8) | (1 << 31), 0, 0, 0))
+            words.append((a | (1 << 31), 0, 0, b, c, 0, 0, 0))
         else:
             (a, b, c), p, f = t
-            assert p * 16 < 65536 and f * 16 < 65536
-            words.append((a | (b << 4) | (c << 8) | (changed[i] << 12), p * 16, f * 16, muls((a, b, c))))
+            assert p * ENTRY_BYTES < 65536 and f * ENTRY_BYTES < 65536
+            words.append((a | (changed[i] << 5), p * ENTRY_BYTES, f * ENTRY_BYTES, b, c, MUL[a], MUL[b], MUL[c]))
     return words
 
 
@@ -161,46 +160,42 @@ def walk(words, outcome):
     n = 0
     cached = [None, None, None]
     while not (words[s][0] >> 31):
-        w0, w1, w2, w3 = words[s]
-        t = (w0 & 15, (w0 >> 4) & 15, (w0 >> 8) & 15)
-        assert [(w3 >> (9 * k)) & 511 for k in range(3)] == [[1, 2, 4, 8, 17, 36, 85, 255, 256][x] for x in t]
+        w = words[s]
+        t = (w[0] & 31, w[3], w[4])
+        assert [w[5], w[6], w[7]] == [MUL[x] for x in t]
         for k in range(3):
-            if (w0 >> 12) & (1 << k):
+            if (w[0] >> 5) & (1 << k):
                 cached[k] = t[k]
         assert tuple(cached) == t, (s, cached, t)
         n += 1
-        off = w1 if outcome(*t) else w2
-        assert off % 16 == 0
-        s = off // 16
-    w0 = words[s][0]
-    return (w0 & 15, (w0 >> 4) & 15, (w0 >> 8) & 15), n
+        off = w[1] if outcome(*t) else w[2]
+        assert off % ENTRY_BYTES == 0
+        s = off // ENTRY_BYTES
+    w = words[s]
+    return (w[0] & 31, w[3], w[4]), n
 
 
-ENTRY_FMT = "{0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu}"
+ENTRY_FMT = "{0x%08xu, 0x%04xu, 0x%04xu, %du, %du, %du, %du, %du}"
 
 
 def main():
     trans = build()
     words = encode(trans)
-    body = ",\n".join("  " + ", ".join(ENTRY_FMT % w for w in words[i:i + 4]) for i in range(0, len(words), 4))
+    body = ",\n".join("  " + ", ".join(ENTRY_FMT % w for w in words[i:i + 2]) for i in range(0, len(words), 2))
     text = """// GENERATED by tools/make_search_table.py -- do not edit.
 // Decision automaton of the reference's default shift search (src/limg_bit_crush.h:331-392, :502-614): %d states.
-// entry (16 bytes) = { a | b << 4 | c << 8 | changed << 12 | final << 31,  byte offset of the next entry on pass,  byte offset of the next entry on fail,
-//                     mul(a) | mul(b) << 9 | mul(c) << 18 };
+// entry (8 dwords) = { a | changed << 5 | final << 31,  byte offset of the next entry on pass,  byte offset of the next entry on fail,  b,  c,  mul(a), mul(b), mul(c) };
 // changed = which shifts (bit 0 A, 1 B, 2 C) this entry's triple changes against its (only) predecessor's; state 0 is the start; a final entry carries the
 // resulting shift triple.
 #ifndef LIMG_SEARCH_TABLE_H
 #define LIMG_SEARCH_TABLE_H
 #define LIMG_SEARCH_STATES %d
-#define LIMG_SEARCH_ROOT_X 0x%08xu /* entry 0, as immediates: the kernel starts every block's search without a load */
-#define LIMG_SEARCH_ROOT_Y 0x%08xu
-#define LIMG_SEARCH_ROOT_Z 0x%08xu
-#define LIMG_SEARCH_ROOT_W 0x%08xu
+#define LIMG_SEARCH_ROOT { %s } /* entry 0, as immediates: the kernel starts every block's search without a load */
 #define LIMG_SEARCH_TABLE_INIT { \\
 %s \\
 }
 #endif
-""" % (len(words), len(words), words[0][0], words[0][1], words[0][2], words[0][3], body.replace("\n", " \\\n"))
+""" % (len(words), len(words), ", ".join("0x%xu" % v for v in words[0]), body.replace("\n", " \\\n"))
     path = os.path.join(ROOT, "limg_amd", "csrc", "limg_search_table.h")
     open(path, "w").write(text)
     print("wrote", path, len(words), "states")
