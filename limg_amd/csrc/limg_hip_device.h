@@ -352,6 +352,9 @@ namespace limg_hip
     __device__ __forceinline__ V4 operator*(const V4 &x, float s) { V4 r; r.a = x.a * s; r.b = x.b * s; return r; }
     // FAST (limg_hip_options.float_mode = 1): the same dot product with the second pair of products fused into the first (v_pk_fma_f32): one
     // instruction and two roundings fewer; not the reference's bits, covered by the FAST-mode tolerance contract (DESIGN.md "numerics").
+    // the last add of a dot product, kept out of the vectoriser's sight: paired with a neighbouring pixel's it becomes one v_pk_add_f32 plus three v_mov to
+    // line the operands up -- dearer than the two full-rate v_add_f32 it replaces
+    __device__ __forceinline__ float hadd(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
     template <int CH, bool FAST = false>
     __device__ __forceinline__ float dp4(const V4 &x, const V4 &y)
     {
@@ -366,7 +369,7 @@ namespace limg_hip
       float2_t n = x.b * y.b;
       if (CH == 3) n.y = 0.0f; // DPPS mask 0x7F
       const float2_t s2 = m + n;
-      return s2.x + s2.y;
+      return hadd(s2.x, s2.y);
     }
     template <int CH>
     __device__ __forceinline__ void mask_alpha(V4 &v) { if (CH == 3) v.b.y = 0.0f; }
@@ -389,7 +392,9 @@ namespace limg_hip
       const float mx = vmax3(xbA.x, xbA.y, vmax(xbB.x, xbB.y));
       const float len2 = dp4<CH, FAST>(d, d);
       bool use;
-      if (ZERO_BY_LEN2) use = (len2 != 0.0f) && active;
+      // (EXACT + ZERO_BY_LEN2: no zero test at all -- len2 == 0 means d == 0 here, the table's value for 0 is finite, and 0 * finite adds nothing to a sum
+      //  that starts at +0, bit for bit what selecting 0 does.  FAST: v_rsq_f32(0) is infinite, so the test stays.)
+      if (ZERO_BY_LEN2) use = FAST ? ((len2 != 0.0f) && active) : active;
       else
       {
         const uint32_t anybits = (__float_as_uint(d.a.x) | __float_as_uint(d.a.y) | __float_as_uint(d.b.x) | __float_as_uint(d.b.y)) << 1;
