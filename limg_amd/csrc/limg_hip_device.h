@@ -383,7 +383,10 @@ namespace limg_hip
     // ZERO_BY_LEN2: decide "all lanes zero" from d . d != 0 instead of OR-ing the four bit patterns (three instructions fewer).  Equivalent for everything the
     // fit can feed it: a non-zero difference of a byte pixel and a float average / estimate is far above 1e-19, so its square does not underflow.  Used by
     // k_fit_tpb (which has the registers for it); the lane == pixel path keeps the bit test (there it cost a spill).
-    template <int CH, bool FAST = false, bool ZERO_BY_LEN2 = false>
+    // TAB32 (k_fit_tpb's LDS copy): `tab` points at 2048 dwords T[j] = table[j ^ 0x400] << 11 -- entry already in mantissa position, index without the flip --
+    // and the exponent comes from one subtraction: (0x5f3fffff - (bits >> 1)) & 0xff800000 == ((380 - e) >> 1) << 23 (the constant's clear bit 22 turns an odd
+    // exponent into the borrow the floor needs; the mantissa bits below never borrow).  Five instructions instead of eight, same bits.
+    template <int CH, bool FAST = false, bool ZERO_BY_LEN2 = false, bool TAB32 = false>
     __device__ __forceinline__ V4 unit4(const unsigned short *tab, const V4 &d, bool active)
     {
       const float2_t biasA = { FLT_EPSILON * 3, FLT_EPSILON * 1 }, biasB = { FLT_EPSILON * 2, 0.0f };
@@ -406,10 +409,18 @@ namespace limg_hip
       {
         // RSQRTPS table lookup; for skipped lanes len2 == 0 => index 0x400, exponent garbage: result discarded below
         const uint32_t bits = __float_as_uint(len2);
+        if (TAB32)
+        {
+          const uint32_t tvs = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(tab) + ((bits >> 11) & 0x1FFCu));
+          inv = __uint_as_float(((0x5f3fffffu - (bits >> 1)) & 0xff800000u) | tvs);
+        }
+        else
+        {
         const uint32_t idx2 = ((bits >> 12) & 0xFFEu) ^ 0x800u; // byte offset into the u16 table
         const uint32_t tv = *reinterpret_cast<const unsigned short *>(reinterpret_cast<const unsigned char *>(tab) + idx2);
         const uint32_t ex = (380u - (bits >> 23)) >> 1; // 126 - floor((e - 127) / 2)
         inv = __uint_as_float((ex << 23) | (tv << 11));
+        }
       }
       inv = (-mn > mx) ? -inv : inv; // |min| > max  (min >= 0 can never satisfy either form)
       inv = use ? inv : 0.0f;

@@ -35,15 +35,23 @@ namespace limg_hip
       __shared__ __attribute__((aligned(16))) uint32_t s_pxAll[kTpbWaves][DIRECT ? 4 : 64 * kTpbStride];
       // the RSQRTPS table in LDS: a per-lane gather of 64 unrelated 2-byte entries costs the texture path ~64 address cycles per wave instruction from global
       // memory, but only a few LDS cycles (random banks)
-      __shared__ __attribute__((aligned(16))) unsigned short s_tab[FAST ? 8 : 2048];
+      // 8 KiB: T[j] = table[j ^ 0x400] << 11, the form unit4<..., TAB32> reads (entry in mantissa position, no index flip)
+      __shared__ __attribute__((aligned(16))) uint32_t s_tab[FAST ? 4 : 2048];
       const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
       if (!FAST)
       {
         const uint4 *src = reinterpret_cast<const uint4 *>(d_rsqrt_x86_tab);
-        for (int i = (int)threadIdx.x; i < 256; i += 64 * kTpbWaves) reinterpret_cast<uint4 *>(s_tab)[i] = src[i];
+        for (int i = (int)threadIdx.x; i < 256; i += 64 * kTpbWaves)
+        {
+          const uint4 v = src[i]; // entries 8 i .. 8 i + 7
+          const uint32_t q[4] = { v.x, v.y, v.z, v.w };
+          uint32_t *dst = s_tab + ((8 * i) ^ 0x400);
+#pragma unroll
+          for (int k = 0; k < 4; k++) { dst[2 * k] = (q[k] & 0xFFFFu) << 11; dst[2 * k + 1] = (q[k] >> 16) << 11; }
+        }
         __syncthreads();
       }
-      const unsigned short *tab = s_tab;
+      const unsigned short *tab = reinterpret_cast<const unsigned short *>(s_tab);
       uint32_t *s_px = s_pxAll[wave];
       const uint32_t unitsX = (p.blocksX + 63u) / 64u;
       const uint32_t unitId = blockIdx.x * kTpbWaves + wave;
@@ -119,7 +127,7 @@ namespace limg_hip
           {
             V4 d = px_to_v4(q[i]) - avg;
             mask_alpha<CH>(d);
-            acc = acc + unit4<CH, FAST, true>(tab, d, true);
+            acc = acc + unit4<CH, FAST, true, true>(tab, d, true);
           }
         }
         finish_dir(acc, dirA, invA, zeroA);
@@ -143,7 +151,7 @@ namespace limg_hip
             mn = vmin(mn, fA); mx = vmax(mx, fA);
             V4 e = pf - (avg + dirA * fA);
             mask_alpha<CH>(e);
-            acc = acc + unit4<CH, FAST, true>(tab, e, true);
+            acc = acc + unit4<CH, FAST, true, true>(tab, e, true);
           }
         }
         mm[0] = mn; mm[1] = mx;
@@ -172,7 +180,7 @@ namespace limg_hip
               mnB = vmin(mnB, fB); mxB = vmax(mxB, fB);
               const V4 estB = estA + dirB * fB;
               if (r == 0 && i == 0) est0 = estB;
-              acc = acc + unit4<CH, FAST, true>(tab, pf - estB, true);
+              acc = acc + unit4<CH, FAST, true, true>(tab, pf - estB, true);
             }
           }
           mm[2] = mnB; mm[3] = mxB;
