@@ -13,7 +13,7 @@
 // bit-identical to the lane == pixel path's -- the parity tests run both.  Only whole 8x8 blocks: images with partial edge blocks keep the other path.
 //
 // LDS (only when the input rows are not 16-byte aligned; see DIRECT below): the 64 blocks' pixels, block-major with a stride of 68 dwords (16-byte aligned rows; 68 = 4 mod 64 makes every 16-lane group of a ds_read_b128 hit 64
-// distinct banks).  17 KiB per wave => 9 waves per CU.  The passes re-read the pixels from LDS (2 x ds_read_b128 per row).
+// distinct banks).  17 KiB per wave.  The passes re-read the pixels from LDS (2 x ds_read_b128 per row).
 #include "limg_hip_device.h"
 
 namespace limg_hip
@@ -23,10 +23,11 @@ namespace limg_hip
     constexpr int kTpbStride = 68;
 
     // DIRECT (input rows 16-byte aligned, the normal case): every lane reads its block's rows straight from global memory (two 16-byte loads per row and pass;
-    // the rows are re-read from L2 by passes 2-4) -- no LDS but the RSQRTPS table, so the registers (166 => 3 waves per SIMD = 12 per CU) set the occupancy.
-    // Otherwise the 64 blocks' pixels are staged in LDS first (dword loads), 17 KiB per wave => 8 waves per CU.
-    template <bool DIRECT> constexpr int tpb_waves() { return DIRECT ? 4 : 2; }
-    // // waves per workgroup: they share one copy of the RSQRTPS table (2 x 17 KiB + 4 KiB => 4 workgroups = 8 waves per CU)
+    // the rows are re-read from L2 by passes 2-4) -- no LDS but the RSQRTPS table (8 KiB per workgroup of four waves), so the registers (166 => 3 waves per SIMD
+    // = 12 per CU) set the occupancy.  Otherwise the 64 blocks' pixels are staged in LDS first (dword loads), 17 KiB per wave, two waves per workgroup
+    // (2 x 17 + 8 KiB => 3 workgroups = 6 waves per CU).  Occupancy is not what the kernel lacks: forced down to 61 VGPRs (8 waves per SIMD) it runs at the same
+    // speed -- it is issue-bound on its instruction count.
+    template <bool DIRECT> constexpr int tpb_waves() { return DIRECT ? 4 : 2; } // waves per workgroup: they share one copy of the table
 
     template <int CH, bool FAST, bool DIRECT>
     __global__ __launch_bounds__(64 * tpb_waves<DIRECT>()) void k_fit_tpb(const EncodeParams p)
