@@ -49,7 +49,8 @@ def pmc_entry(key):
 def workload_key(args, W, H):
     mode = "split" if args.split else "fused"
     return "%dx%d_%s_ef%d_%s%s%s%s" % (W, H, args.workload, args.error_factor, mode, "" if args.forced_shift < 0 else "_shift%d" % args.forced_shift,
-                                       "_compact" if args.compact else "", ("_fastfloat" if args.float_mode == "fast" else "") + ("_legacyfit" if args.legacy_float_stage else ""))
+                                       "_compact" if args.compact else "", ("_fastfloat" if args.float_mode == "fast" else "") + ("_legacyfit" if args.legacy_float_stage else "")
+                                       + ("_accurate" if args.accurate else "") + ("_rgb" if args.rgb else ""))
 
 
 def cpu_model():
@@ -468,6 +469,8 @@ def main():
     ap.add_argument("--float-mode", default="exact", choices=["exact", "fast"],
                     help="exact (headline): the float stage op for op as the reference's strict SSE build; fast: native rsq / fused multiply-adds, PSNR-tolerance contract")
     ap.add_argument("--legacy-float-stage", action="store_true", help="float stage inside the E step with lane == pixel (round-1 mapping) instead of k_fit_tpb")
+    ap.add_argument("--accurate", action="store_true", help="accurate bit-crush search (fastBitCrushing = false, src/limg_bit_crush.h:668-830) instead of the default guess + stepwise search")
+    ap.add_argument("--rgb", action="store_true", help="encode as 3-channel (hasAlpha = false)")
     ap.add_argument("--forced-shift", type=int, default=-1, help="bypass the shift search with this shift on all three factors (bit-crush sweep)")
     ap.add_argument("--config", type=int, default=3, choices=[3, 4, 5],
                     help="BASELINE.json configs, 1-based: 3 = headline (default), 4 = batch of 64 x 4096^2 images over the ranks + gather, "
@@ -554,7 +557,7 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        g.encode3d_device(img, True, planes, error_factor=args.error_factor, pool_threads=0, fast=True, records=rec, shifts=sh)
+        g.encode3d_device(img, not args.rgb, planes, error_factor=args.error_factor, pool_threads=0, fast=not args.accurate, records=rec, shifts=sh)
 
     # cold cost, reported apart: the first encode of a size class builds the context's dither noise table and scratch
     t0 = time.perf_counter()
@@ -585,14 +588,14 @@ def main():
     px = W * H
     ms_per_step = elapsed * 1e3 / args.steps
     value = n_gpus * px * args.steps / elapsed / 1e6
-    psnr = float("nan") if args.compact else g.compare_device(img, planes["pDecoded"], True)[0]
+    psnr = float("nan") if args.compact else g.compare_device(img, planes["pDecoded"], not args.rgb)[0]
     bytes_per_px = (4 + 3 + 68.0 / 64) if args.compact else ALGO_BYTES_PER_PX
 
     if rank == 0:
         # `_perf` style on the GPU (SURVEY 8(d) last row; src/limg.cpp:2140-2173): the E step alone -- fit, factors, shift search -- nothing stored
         g.profile_begin()
         for _ in range(5):
-            g.encode3d_device(img, True, None, error_factor=args.error_factor, pool_threads=0, fast=True)
+            g.encode3d_device(img, not args.rgb, None, error_factor=args.error_factor, pool_threads=0, fast=not args.accurate)
         torch.cuda.synchronize()
         kperf = g.profile_end(5)
         perf_ms = float(kperf[1:, 0].mean()) if len(kperf) > 1 else None
@@ -618,8 +621,9 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("u8/i32 integer stage + f32 float stage (bit-exact vs the reference's strict SSE build)" if args.float_mode == "exact" else
                       "u8/i32 integer stage (bit-exact given the records) + f32 float stage in FAST mode (PSNR-tolerance contract)"), "data": "synthetic",
-            "config": {"workload": "synthetic %dx%d RGBA %s (seed 1+rank) per GPU, errorFactor %d, fast bit-crush, single dither chain"
-                                   % (W, H, args.workload, args.error_factor) + ("" if args.forced_shift < 0 else ", forced shift %d" % args.forced_shift)
+            "config": {"workload": "synthetic %dx%d %s %s (seed 1+rank) per GPU, errorFactor %d, %s bit-crush, single dither chain"
+                                   % (W, H, "RGB (hasAlpha = false)" if args.rgb else "RGBA", args.workload, args.error_factor, "ACCURATE" if args.accurate else "fast")
+                                   + ("" if args.forced_shift < 0 else ", forced shift %d" % args.forced_shift)
                                    + (", COMPACT outputs (8.06 B/px)" if args.compact else "") + (", FAST float stage" if args.float_mode == "fast" else ""),
                        "images_per_step": n_gpus, "parallelism": "independent image per GPU, no data-path collective", "psnr_db": None if psnr != psnr else round(psnr, 4),
                        "first_encode_ms": round(first_encode_ms, 2),
