@@ -210,14 +210,22 @@ namespace limg_hip
         {
           for (; b <= 8; b++)
           {
-            for (; c <= 8; c++)
-            {
-              if (a + b + c > max_shift && (a != shift[0] || b != shift[1] || c != shift[2]))
+            while (c <= 8)
+            { // upstream's `for (; c <= 8; c++)`; the iterations that cannot try anything (a + b + c <= max_shift) are stepped over at once -- walking them
+              // one by one made this scalar loop, not the trials, the cost of the accurate mode
+              if (a + b + c <= max_shift)
+              {
+                const uint32_t first = max_shift - a - b + 1; // > c
+                c = first > 8 ? 9 : first;
+                continue;
+              }
+              if (a != shift[0] || b != shift[1] || c != shift[2])
               {
                 if (T(a, b, c, be)) { shift[0] = a; shift[1] = b; shift[2] = c; max_shift = a + b + c; min_be = be; have = true; }
                 else
                   break;
               }
+              c++;
             }
             if (c == 0) break;
             c = 0;
@@ -233,17 +241,22 @@ namespace limg_hip
         {
           for (; b <= 8; b++)
           {
-            for (; c <= 8; c++)
-            {
-              if (a + b + c == max_shift)
+            while (c <= 8)
+            { // as above: only c == max_shift - a - b can try anything (max_shift is fixed in this phase)
+              const uint32_t sum = a + b + c;
+              if (sum != max_shift)
               {
-                if (T(a, b, c, be))
-                {
-                  if (!have || min_be > be) { shift[0] = a; shift[1] = b; shift[2] = c; min_be = be; have = true; }
-                }
-                else
-                  break;
+                const uint32_t only = max_shift - a - b; // meaningful when sum < max_shift
+                c = (sum < max_shift && only <= 8) ? only : 9;
+                continue;
               }
+              if (T(a, b, c, be))
+              {
+                if (!have || min_be > be) { shift[0] = a; shift[1] = b; shift[2] = c; min_be = be; have = true; }
+              }
+              else
+                break;
+              c++;
             }
             if (c == 0) break;
             c = 0;
