@@ -144,7 +144,7 @@ namespace limg_hip
       return trial_core<FULL>(t, active, maxPixel32, blockLimit, blockError);
     }
 
-    // a10 + a11 as a table-driven automaton: one trial loop; the outcome of a trial picks the byte offset of the next state's 16-byte entry, which one scalar load
+    // a10 + a11 as a table-driven automaton: one trial loop; the outcome of a trial picks the byte offset of the next state's 32-byte entry, which one scalar load
     // fetches.  The scalar side of the loop is kept minimal -- the scalar unit (one per CU) is a co-bottleneck of this kernel: 8 extra scalar instructions per
     // trial cost 10 % (measured) -- so an entry says WHICH factors its triple changes against its predecessor's (the automaton is a tree: no compares against
     // cached shifts), holds byte offsets (no shifts) and the re-expansion multipliers, and the table's base address stays in SGPRs.  The load is NOT issued
