@@ -205,6 +205,7 @@ namespace
     const uint64_t maxPixel = (uint64_t)0x6 * (errorFactor / 2) * 7, maxBlock = (uint64_t)0x4 * (errorFactor / 2) * 7;
     p.maxPixel32 = maxPixel > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)maxPixel;
     p.maxBlock = maxBlock;
+    { const uint64_t lim = (maxBlock * 64ull + 15ull) >> 4; p.blockLimitFull = lim > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)lim; }
     p.crushBits = errorFactor != 0;
     p.fast = fast != 0;
     const bool forced = c->opt.forced_shift[0] >= 0 && c->opt.forced_shift[0] <= 8 && c->opt.forced_shift[1] >= 0 && c->opt.forced_shift[1] <= 8 &&

@@ -1037,9 +1037,13 @@ namespace limg_hip
         else if (p.crushBits)
         {
           const uint64_t maxBlockN = p.maxBlock * (uint64_t)n;
-          // be * 16 < maxBlock * n  <=>  be < ceil(maxBlock * n / 16); clamped to 32 bits (be itself never gets near 2^32)
-          const uint64_t lim64 = (maxBlockN + 15ull) >> 4;
-          const uint32_t blockLimit = (uint32_t)sgpr((int)(lim64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)lim64));
+          // be * 16 < maxBlock * n  <=>  be < ceil(maxBlock * n / 16); clamped to 32 bits (be itself never gets near 2^32).  Full blocks: from the host.
+          uint32_t blockLimit = p.blockLimitFull;
+          if (n != 64)
+          {
+            const uint64_t lim64 = (maxBlockN + 15ull) >> 4;
+            blockLimit = (uint32_t)sgpr((int)(lim64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)lim64));
+          }
           const bool big = ((uint32_t)sgpr((int)blkE->flags) & kBig) != 0;
           if (!big)
           {
