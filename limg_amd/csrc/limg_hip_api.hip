@@ -2,6 +2,7 @@
 // Mirrors the reference's driver (src/limg.cpp:2175-2265 threshold/flag setup, :2105-2138 strip partition).
 #include "limg_hip_internal.h"
 #include "limg_hip_rccl.h"
+#include "limg_search_table_accurate.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -80,6 +81,7 @@ struct limg_hip_context
   DevBuf noiseDyn;                               // data-dependent chains (images with partial blocks)
   DevBuf park;                                   // persistent kernel: 2 x 8 KiB per workgroup
   DevBuf lookback;                               // fused path: ticket (16 B) then one 8-byte descriptor per work strip
+  DevBuf accTable;                               // accurate search: automaton expanded to 32-byte entries (built on the first accurate encode)
   DevBuf devStatus;                              // sticky look-back timeout word: never touched by the per-launch memset, cleared by limg_hip_check_device_status
   DevBuf in, planes;                             // staging for the host-pointer entry points
   DevBuf cmp;                                    // 8-byte accumulator of limg_hip_compare
@@ -112,6 +114,31 @@ struct limg_hip_context
 namespace
 {
   constexpr size_t kNoiseChunk = 1u << 16; // table growth granularity (entries)
+
+  // The accurate search's automaton (tools/make_search_table.py, src/limg_bit_crush.h:668-830) in the form the kernel's scalar loads want: 8 dwords per state,
+  // every field in a dword of its own = { a | phase2 << 5 | final << 31, byte offset on pass, byte offset on fail, b, c, mul(a), mul(b), mul(c) }.
+  limg_hip_result ensure_accurate_table(limg_hip_context *c)
+  {
+    if (c->accTable.p) return limg_hip_success;
+    static const uint32_t compact[LIMG_SEARCH_ACC_STATES][2] = LIMG_SEARCH_ACC_TABLE_INIT;
+    static const uint32_t mul[9] = { 1, 2, 4, 8, 17, 36, 85, 255, 256 }; // (1 << s) + decode_bias(s), src/limg_bit_crush_simd.h:611-619
+    std::vector<uint32_t> wide((size_t)LIMG_SEARCH_ACC_STATES * 8);
+    for (size_t i = 0; i < (size_t)LIMG_SEARCH_ACC_STATES; i++)
+    {
+      const uint32_t w0 = compact[i][0], w1 = compact[i][1];
+      uint32_t *e = &wide[i * 8];
+      if (w0 >> 31) { e[0] = 1u << 31; continue; }
+      const uint32_t a = w0 & 15u, b = (w0 >> 4) & 15u, cc = (w0 >> 8) & 15u;
+      e[0] = a | ((w0 & 0x1000u) ? 0x20u : 0u);
+      e[1] = (w1 & 0xFFFFu) * 32u; e[2] = (w1 >> 16) * 32u;
+      e[3] = b; e[4] = cc;
+      e[5] = mul[a]; e[6] = mul[b]; e[7] = mul[cc];
+    }
+    limg_hip_result r = c->accTable.ensure(wide.size() * 4);
+    if (r != limg_hip_success) return r;
+    if (hipMemcpy(c->accTable.p, wide.data(), wide.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { c->accTable.release(); return limg_hip_error_Generic; }
+    return limg_hip_success;
+  }
 
   limg_hip_result grow_noise_table(limg_hip_context *c, size_t entries, hipStream_t stream)
   {
@@ -208,6 +235,13 @@ namespace
     { const uint64_t lim = (maxBlock * 64ull + 15ull) >> 4; p.blockLimitFull = lim > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)lim; }
     p.crushBits = errorFactor != 0;
     p.fast = fast != 0;
+    p.accTable = nullptr;
+    if (!p.fast && p.crushBits)
+    {
+      limg_hip_result ra = ensure_accurate_table(c);
+      if (ra != limg_hip_success) return ra;
+      p.accTable = (const uint32_t *)c->accTable.p;
+    }
     const bool forced = c->opt.forced_shift[0] >= 0 && c->opt.forced_shift[0] <= 8 && c->opt.forced_shift[1] >= 0 && c->opt.forced_shift[1] <= 8 &&
                         c->opt.forced_shift[2] >= 0 && c->opt.forced_shift[2] <= 8;
     for (int i = 0; i < 3; i++) p.forced[i] = forced ? c->opt.forced_shift[i] : -1;
@@ -398,7 +432,7 @@ extern "C"
     limg_hip_context *c = *ppCtx;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = { &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->lookback, &c->devStatus, &c->commWords, &c->park, &c->in, &c->planes, &c->cmp,
+    DevBuf *bufs[] = { &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->lookback, &c->devStatus, &c->accTable, &c->commWords, &c->park, &c->in, &c->planes, &c->cmp,
                        &c->streamFac, &c->streamTiles, &c->streamStatus, &c->streamBuf,
                        &c->bFlags, &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bV, &c->bFac, &c->bNoise, &c->bNoiseBase };
     for (DevBuf *b : bufs) b->release();

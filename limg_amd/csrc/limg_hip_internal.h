@@ -25,6 +25,7 @@ namespace limg_hip
     uint64_t maxBlock;       // maxBlockBitCrushError
     uint32_t blockLimitFull; // min(ceil(maxBlock * 64 / 16), 2^32 - 1): what a full block's error sum is compared with (be * 16 < maxBlock * n)
     int32_t crushBits, fast; // reference: src/limg.cpp:2192-2197
+    const uint32_t *accTable; // !fast: the accurate search's automaton, 8 dwords per state (limg_search_table_accurate.h expanded by the context)
     int32_t forced[3];       // -1 or forced shift
     int32_t recordLimit;     // |record value| above which a block takes the generic 32-bit trial (2700: the bound the packed trial's 16-bit terms are proven for; tests lower it to exercise the generic path)
     // chain partition (reference: src/limg.cpp:2114-2134), in block rows

@@ -122,28 +122,6 @@ namespace limg_hip
       return err;
     }
 
-    // pixel check, then block sum
-    template <bool FULL>
-    __device__ __forceinline__ bool trial_core(const TrialState &t, const bool active, const uint32_t maxPixel32, const uint32_t blockLimit, uint32_t &blockError)
-    {
-      const uint32_t err = trial_pixel_error<FULL>(t, active);
-      if (__builtin_amdgcn_ballot_w64(err > maxPixel32) != 0ull) return false;
-      const uint32_t be = wave_sum(err);
-      blockError = be;
-      return be < blockLimit; // be * 16 < maxBlock * n, see phase E
-    }
-
-    // a9 for callers that name the shift triple (accurate search): the terms of a factor are rebuilt when its shift differs from the cached one
-    template <bool FULL>
-    __device__ __forceinline__ bool trial_packed(TrialState &t, const uint32_t sA, const uint32_t sB, const uint32_t sC, const bool active,
-                                                 const uint32_t maxPixel32, const uint32_t blockLimit, uint32_t &blockError)
-    {
-      if (sA != t.cA) rebuild_A(t, sA, shift_mul(sA));
-      if (sB != t.cB) rebuild_B(t, sB, shift_mul(sB));
-      if (sC != t.cC) rebuild_C(t, sC, shift_mul(sC));
-      return trial_core<FULL>(t, active, maxPixel32, blockLimit, blockError);
-    }
-
     // a10 + a11 as a table-driven automaton: one trial loop; the outcome of a trial picks the byte offset of the next state's 32-byte entry, which one scalar load
     // fetches.  The scalar side of the loop is kept minimal -- the scalar unit (one per CU) is a co-bottleneck of this kernel: 8 extra scalar instructions per
     // trial cost 10 % (measured) -- so an entry says WHICH factors its triple changes against its predecessor's (the automaton is a tree: no compares against
@@ -179,6 +157,40 @@ namespace limg_hip
         e = sload8(tab, off);
       }
       shift[0] = e[0] & 31u; shift[1] = e[3]; shift[2] = e[4];
+    }
+
+    // a12 as an automaton (limg_search_table_accurate.h, a DAG of ~19 k states in global memory, expanded by the context): which trials the accurate search runs
+    // depends on pass / fail outcomes only, so its three nested scalar loops -- which, not the trials, were the cost of this mode -- become one table walk.  What
+    // the block errors decide stays here: a passing phase-1 trial becomes the result; a passing phase-2 trial only if its error is below the best so far
+    // (src/limg_bit_crush.h:774-826; `have` is always set by then).  A state has several predecessors, so the factors to rebuild come from comparing with the cached
+    // shifts (t.cA..cC).
+    template <bool FULL>
+    __device__ __forceinline__ void search_accurate_automaton(TrialState &t, const bool active, const uint32_t maxPixel32, const uint32_t blockLimit, const uint32_t *table,
+                                                              uint32_t shift[3])
+    {
+      const SearchEntry *tab = reinterpret_cast<const SearchEntry *>(table);
+      uint32_t bestA = 0, bestB = 0, bestC = 0, minBe = 0xFFFFFFFFu;
+      uint8s_t e = sload8(tab, 0u);
+      while (!(e[0] >> 31))
+      {
+        const uint32_t a = e[0] & 31u;
+        if (a != t.cA) rebuild_A(t, a, e[5]);
+        if (e[3] != t.cB) rebuild_B(t, e[3], e[6]);
+        if (e[4] != t.cC) rebuild_C(t, e[4], e[7]);
+        const uint32_t err = trial_pixel_error<FULL>(t, active);
+        uint32_t off = e[2];
+        if (__builtin_amdgcn_ballot_w64(err > maxPixel32) == 0ull)
+        {
+          const uint32_t be = wave_sum(err);
+          if (be < blockLimit) // be * 16 < maxBlock * n, see phase E
+          {
+            off = e[1];
+            if (!(e[0] & 0x20u) || be < minBe) { bestA = a; bestB = e[3]; bestC = e[4]; minBe = be; }
+          }
+        }
+        e = sload8(tab, off);
+      }
+      shift[0] = bestA; shift[1] = bestB; shift[2] = bestC;
     }
 
     // generic-path search (see phase E): real function, rarely if ever executed
@@ -1087,20 +1099,12 @@ namespace limg_hip
             if (n == 64)
             {
               if (p.fast) search_fast_automaton<true>(t, true, p.maxPixel32, blockLimit, shift);
-              else
-              {
-                auto T = [&](uint32_t a, uint32_t bb, uint32_t c, uint32_t &be2) -> bool { return trial_packed<true>(t, a, bb, c, true, p.maxPixel32, blockLimit, be2); };
-                search_accurate(T, shift);
-              }
+              else search_accurate_automaton<true>(t, true, p.maxPixel32, blockLimit, p.accTable, shift);
             }
             else
             {
               if (p.fast) search_fast_automaton<false>(t, active, p.maxPixel32, blockLimit, shift);
-              else
-              {
-                auto T = [&](uint32_t a, uint32_t bb, uint32_t c, uint32_t &be2) -> bool { return trial_packed<false>(t, a, bb, c, active, p.maxPixel32, blockLimit, be2); };
-                search_accurate(T, shift);
-              }
+              else search_accurate_automaton<false>(t, active, p.maxPixel32, blockLimit, p.accTable, shift);
             }
           }
           else

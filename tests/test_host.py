@@ -144,6 +144,60 @@ def test_search_automaton_replays_reference_searches():
             assert list(shift) == z[p + "search_100_1"].tolist(), p
 
 
+def test_accurate_search_automaton_replays_reference_searches():
+    """The accurate search's automaton (tools/make_search_table.py -> limg_search_table_accurate.h, expanded by the library for the kernel) driven by the real
+    reference's trial outcomes and block errors (tests/golden/blocks.npz) ends at the real reference's accurate-search result; the committed header is what the
+    generator produces."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_search_table as mst
+    words = mst.encode_accurate(mst.build_accurate())
+    hdr = open(os.path.join(ROOT, "limg_amd", "csrc", "limg_search_table_accurate.h")).read()
+    assert "LIMG_SEARCH_ACC_STATES %d" % len(words) in hdr
+    assert all("{0x%08xu, 0x%08xu}" % w in hdr for w in words[:60] + words[len(words) // 2: len(words) // 2 + 60] + words[-60:])
+    z = gu.blocks()
+    longest = 0
+    for bi in range(int(z["count"])):
+        for ch in (4, 3):
+            p = "b%02d_%d_" % (bi, ch)
+            t = z[p + "trials"]
+            shift, n = mst.walk_accurate(words, lambda a, b, c: (bool(t[a, b, c, 0]), int(t[a, b, c, 1])))
+            assert list(shift) == z[p + "search_100_0"].tolist(), p
+            longest = max(longest, n)
+    assert longest > 40  # the walks are real searches, not early exits
+
+
+def test_accurate_search_automaton_equals_loops_on_random_outcomes():
+    """Random pass / fail outcomes and block errors: the table and a literal run of the restated loops (with the caller-side bookkeeping of the kernel) agree."""
+    import random
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_search_table as mst
+    words = mst.encode_accurate(mst.build_accurate())
+    rnd = random.Random(7)
+    for _ in range(600):
+        pr = rnd.random()
+        memo = {}
+
+        def outcome(a, b, c):
+            if (a, b, c) not in memo:
+                memo[(a, b, c)] = (rnd.random() < pr, rnd.randrange(1, 5000))
+            return memo[(a, b, c)]
+        got, _n = mst.walk_accurate(words, outcome)
+        g = mst.search_accurate()
+        shift, min_be = (0, 0, 0), None
+        try:
+            t = next(g)
+            while True:
+                ok, be = outcome(*t[:3])
+                if ok and (t[3] == 1 or be < min_be):
+                    shift, min_be = t[:3], be
+                t = g.send(ok)
+        except StopIteration:
+            pass
+        assert got == shift
+
+
 def test_search_automaton_equals_oracle_on_random_outcomes(oracle):
     """Random pass/fail oracles: the table and a literal re-run of the generator agree (exhaustive merge is sound)."""
     import random

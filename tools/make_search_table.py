@@ -119,6 +119,140 @@ def build():
     return trans
 
 
+def search_accurate():
+    """Literal restatement of the accurate search's control flow (src/limg_bit_crush.h:668-830) as a generator: yields (a, b, c, phase).  Which trials run depends on
+    pass / fail outcomes only; the block errors decide nothing but which passing triple of phase 2 becomes the result, and that bookkeeping stays with the caller:
+       phase 1 trial passes: shift = triple, min_be = be           phase 2 trial passes: if be < min_be: shift = triple, min_be = be
+    (`have` is always true in phase 2: max_shift > 0 only after a success.)"""
+    shift = [0, 0, 0]
+    max_shift = 0
+    ok = yield (4, 5, 6, 1)
+    if ok:
+        shift = [4, 5, 6]
+        max_shift = 15
+        ok = yield (5, 8, 8, 1)
+        if ok:
+            shift = [5, 8, 8]
+            max_shift = 21
+        else:
+            ok = yield (4, 6, 8, 1)
+            if ok:
+                shift = [4, 6, 8]
+                max_shift = 18
+    else:
+        ok = yield (2, 4, 5, 1)
+        if ok:
+            shift = [2, 4, 5]
+            max_shift = 11
+    a = 0
+    b = 0
+    c = 1
+    while a <= 8:
+        while b <= 8:
+            while c <= 8:
+                if a + b + c > max_shift and [a, b, c] != shift:
+                    ok = yield (a, b, c, 1)
+                    if ok:
+                        shift = [a, b, c]
+                        max_shift = a + b + c
+                    else:
+                        break
+                c += 1
+            if c == 0:
+                break
+            c = 0
+            b += 1
+        if b == 0:
+            break
+        b = 0
+        a += 1
+    if max_shift > 0:
+        a, b, c = shift[0], shift[1], shift[2] + 1
+        while a <= 8:
+            while b <= 8:
+                while c <= 8:
+                    if a + b + c == max_shift:
+                        ok = yield (a, b, c, 2)
+                        if not ok:
+                            break
+                    c += 1
+                if c == 0:
+                    break
+                c = 0
+                b += 1
+            if b == 0:
+                break
+            b = 0
+            a += 1
+
+
+def build_accurate():
+    """States of the accurate search merged by control state (a DAG: ~19 k states).  trans[i] = ((a, b, c, phase), next on pass, next on fail) or ("final",)."""
+    states = {}
+    trans = []
+
+    def explore(prefix):
+        g = search_accurate()
+        try:
+            t = next(g)
+            for d in prefix:
+                t = g.send(d)
+        except StopIteration:
+            key = ("final",)
+            if key not in states:
+                states[key] = len(trans)
+                trans.append(key)
+            return states[key]
+        loc = g.gi_frame.f_locals
+        if t[3] == 2:
+            key = (2, t, loc["max_shift"])  # phase 2 walks (a, b, c) with max_shift fixed; the accepted triple is the caller's business
+        else:
+            key = (g.gi_frame.f_lineno, t, tuple(loc["shift"]), loc["max_shift"])
+        if key in states:
+            return states[key]
+        sid = len(trans)
+        states[key] = sid
+        trans.append(None)
+        p = explore(prefix + [True])
+        f = explore(prefix + [False])
+        trans[sid] = (t, p, f)
+        return sid
+
+    assert explore([]) == 0
+    return trans
+
+
+def encode_accurate(trans):
+    """compact entry = (a | b << 4 | c << 8 | phase2 << 12 | final << 31,  next on pass | next on fail << 16) -- state indices; the library expands it at context
+    creation into the 32-byte form the kernel reads (limg_hip_api.hip)."""
+    assert len(trans) < 65536
+    words = []
+    for t in trans:
+        if t[0] == "final":
+            words.append((1 << 31, 0))
+        else:
+            (a, b, c, ph), p, f = t
+            words.append((a | (b << 4) | (c << 8) | ((1 << 12) if ph == 2 else 0), p | (f << 16)))
+    return words
+
+
+def walk_accurate(words, outcome):
+    """Run the accurate automaton with `outcome(a, b, c) -> (passed, block_error)`; returns (shift, trials)."""
+    s = 0
+    n = 0
+    shift = (0, 0, 0)
+    min_be = None
+    while not (words[s][0] >> 31):
+        w0, w1 = words[s]
+        t = (w0 & 15, (w0 >> 4) & 15, (w0 >> 8) & 15)
+        ok, be = outcome(*t)
+        n += 1
+        if ok and (not (w0 & 0x1000) or be < min_be):
+            shift, min_be = t, be
+        s = (w1 & 0xFFFF) if ok else (w1 >> 16)
+    return shift, n
+
+
 ENTRY_BYTES = 32
 MUL = [1, 2, 4, 8, 17, 36, 85, 255, 256]  # (1 << s) + decode_bias(s), src/limg_bit_crush_simd.h:611-619
 
@@ -199,6 +333,24 @@ def main():
     path = os.path.join(ROOT, "limg_amd", "csrc", "limg_search_table.h")
     open(path, "w").write(text)
     print("wrote", path, len(words), "states")
+    acc = encode_accurate(build_accurate())
+    body = ",\n".join("  " + ", ".join("{0x%08xu, 0x%08xu}" % w for w in acc[i:i + 6]) for i in range(0, len(acc), 6))
+    text = """// GENERATED by tools/make_search_table.py -- do not edit.
+// Decision automaton of the reference's ACCURATE shift search (src/limg_bit_crush.h:668-830): %d states (a DAG; state 0 is the start).
+// compact entry = { a | b << 4 | c << 8 | phase2 << 12 | final << 31,  next state on pass | next state on fail << 16 }.  Which trials run depends on pass / fail only;
+// a passing phase-1 trial becomes the result, a passing phase-2 trial only if its block error is below the best so far.  Host-side data: expanded into 32-byte entries
+// for the kernel at context creation.
+#ifndef LIMG_SEARCH_TABLE_ACCURATE_H
+#define LIMG_SEARCH_TABLE_ACCURATE_H
+#define LIMG_SEARCH_ACC_STATES %d
+#define LIMG_SEARCH_ACC_TABLE_INIT { \\
+%s \\
+}
+#endif
+""" % (len(acc), len(acc), body.replace("\n", " \\\n"))
+    path = os.path.join(ROOT, "limg_amd", "csrc", "limg_search_table_accurate.h")
+    open(path, "w").write(text)
+    print("wrote", path, len(acc), "states")
 
 
 if __name__ == "__main__":
