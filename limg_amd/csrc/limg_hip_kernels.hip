@@ -115,9 +115,12 @@ namespace limg_hip
       const ushort2_t eu = __builtin_bit_cast(ushort2_t, e);
       const ushort2_t sq = eu * eu; // d^2 <= 65025 fits 16 bits; (-d)^2 mod 2^16 == d^2
       const uint32_t sqB = (uint32_t)mul_i24(dB, dB);
+      // weights (R, G, B) = (2, 4, 3) while dR^2 < 0x4000, else (3, 4, 2)  ==  2 * (dR^2 + 2 dG^2 + dB^2) + (dB^2 or dR^2): one dot product with constant weights,
+      // one select (the red square is picked out of the packed pair by the select's operand modifier), one shift-add
       const bool low_red = sq.x < 0x4000;
-      const uint32_t wRG = low_red ? 0x00040002u : 0x00040003u;
-      uint32_t err = __builtin_amdgcn_udot2(sq, __builtin_bit_cast(ushort2_t, wRG), mul_u24(sqB, low_red ? 3u : 2u), false);
+      const uint32_t half = __builtin_amdgcn_udot2(sq, __builtin_bit_cast(ushort2_t, 0x00020001u), sqB, false);
+      const uint32_t extra = low_red ? sqB : (__builtin_bit_cast(uint32_t, sq) & 0xFFFFu);
+      uint32_t err = (half << 1) + extra;
       if (!FULL) err = active ? err : 0u;
       return err;
     }
