@@ -45,31 +45,35 @@ namespace limg_hip
 
     // ---- a9, packed form ------------------------------------------------------------------------------------------------
     // Same integers as `trial` above, arranged for gfx950's packed 16-bit VALU:
-    //  * per factor X the three RGB terms  tXc = (decX * nX[c] + (minX[c] << 8) + 128) >> 8  are kept between trials
-    //    (R,G packed in one VGPR, B in another) and only recomputed when that factor's shift changes -- the stepwise search
-    //    mostly moves one shift at a time;
-    //  * px - clamp(S, 0, 255) == clamp(px - S, px - 255, px), so the clamp and the difference are v_pk_max/min against
-    //    per-pixel bounds prepared once per block;
-    //  * the weighted squared error is one v_dot2_u32_u16.
-    // The R term of every factor carries a +0x2000 bias (folded into the additive constant, so it costs nothing) which keeps
-    // the low halves positive: the three packed terms can then be summed with one plain 32-bit add3 without a borrow reaching
-    // the G half.  Valid while every term stays inside (-0x2000, 0x2000): a term is (d * n + (min << 8) + 128) >> 8 with d <= 255 and n = max - min, so
-    // |term| <= |min| + |n| + 1 <= 3 L + 1 when every record value is at most L in magnitude: L = p.recordLimit = 2700 (3 * 2700 + 1 = 8101 < 8192).  Then the
-    // biased R halves are positive, three of them sum to < 65536 (no carry into G), the three G terms sum to an int16, and px - sum fits an int16 for the packed
-    // subtract / clamp.  A fit of byte pixels cannot get near it (|A| <= 765, |B| <= 1020, |C| <= 2040); phase E falls back to the generic 32-bit form otherwise.
+    //  * per factor X the three RGB terms  tXc = (decX * nX[c] + (minX[c] << 8) + 128) >> 8  are kept between trials (R,G packed in one VGPR, B in another) and
+    //    only recomputed when that factor's shift changes;
+    //  * they are kept NEGATED: -floor(x / 256) == floor((255 - x) / 256), so (d * -n + (255 - m)) >> 8 is minus the term at the same cost, and factor A's
+    //    additive constant also carries the pixel (<< 8, per lane).  The three cached values of a channel then sum to  px - estimate  directly: no subtraction in
+    //    the trial;
+    //  * px - clamp(S, 0, 255) == clamp(px - S, px - 255, px), so the clamp and the difference are one max and one min against per-pixel bounds prepared once per
+    //    block;
+    //  * the R and G halves of a packed term carry a bias (A 0x3000, B 0x3000, C 0x2000, folded into the additive constants) that keeps every half a positive
+    //    16-bit number -- one plain 32-bit add3 then adds the halves independently -- and the biases sum to 0x8000: the sum is the difference in OFFSET BINARY, which
+    //    unsigned v_pk_max / v_pk_min clamp correctly against bounds biased the same way, and whose square modulo 2^16 is the square of the difference itself
+    //    ((e + 0x8000)^2 = e^2 + 0x10000 e + 2^30, |e| <= 255).  So the bias is never removed;
+    //  * the weighted squared error is one v_dot2_u32_u16, one select and one shift-add.
+    // Valid while every term stays inside (-0x2000, 0x2000): a term is (d * n + (min << 8) + 128) >> 8 with d <= 255 and n = max - min, so
+    // |term| <= |min| + |n| + 1 <= 3 L + 1 when every record value is at most L in magnitude: L = p.recordLimit = 2700 (3 * 2700 + 1 = 8101 < 8192).  Then every
+    // biased half lies in (0, 0x5100) and three of them sum to less than 65536 (no carry between the halves or out of the register).  A fit of byte pixels cannot
+    // get near it (|A| <= 765, |B| <= 1020, |C| <= 2040); phase E falls back to the generic 32-bit form otherwise.
     typedef short short2_t __attribute__((ext_vector_type(2)));
     typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
-    constexpr int kTermBias = 0x2000;
+    __device__ __forceinline__ constexpr int term_bias(int factor) { return factor == 2 ? 0x2000 : 0x3000; } // sum over the factors == 0x8000
+    // additive constant of factor f, channel c, for a record minimum `lo`: negated, rounding constant reflected, RG halves biased
+    __device__ __forceinline__ int term_const(int f, int c, int lo) { return 255 - ((lo << 8) + 128) + (c < 2 ? (term_bias(f) << 8) : 0); }
 
     struct TrialState
     {
       // per pixel, fixed for the block
       uint32_t fA, fB, fC;
-      uint32_t pxRGb; // (R + 3 * bias) | G << 16
-      uint32_t loRG, hiRG;
+      uint32_t loRG, hiRG; // (R - 255 + 0x8000) | (G - 255 + 0x8000) << 16 and (R + 0x8000) | (G + 0x8000) << 16
       int pxB, pxBlo;
-      // wave-uniform record view: n* scalars, m* = (min << 8) + 128 (+ bias << 8 for R); the B channel's are negated (n = -n, m = 255 - m) and mA[2] also
-      // carries the pixel's B << 8 (per lane): see trial_pixel_error
+      // record view: n* = -(max - min) (wave-uniform), m* = term_const(...) (wave-uniform for B and C; factor A's also carry the pixel's channel << 8, per lane)
       int nA[3], nB[3], nC[3];
       int mA[3], mB[3], mC[3];
       // cached terms and the shifts they were built for
@@ -91,13 +95,13 @@ namespace limg_hip
     __device__ __forceinline__ void rebuild_A(TrialState &t, const uint32_t sA, const uint32_t mul) { make_terms(t.fA, sA, mul, t.nA, t.mA, t.tA_RG, t.tA_B); t.cA = sA; }
     __device__ __forceinline__ void rebuild_B(TrialState &t, const uint32_t sB, const uint32_t mul)
     {
-      if (sB > 7) { t.tB_RG = (uint32_t)kTermBias; t.tB_B = 0; }
+      if (sB > 7) { t.tB_RG = (uint32_t)term_bias(1) * 0x10001u; t.tB_B = 0; }
       else make_terms(t.fB, sB, mul, t.nB, t.mB, t.tB_RG, t.tB_B);
       t.cB = sB;
     }
     __device__ __forceinline__ void rebuild_C(TrialState &t, const uint32_t sC, const uint32_t mul)
     {
-      if (sC > 7) { t.tC_RG = (uint32_t)kTermBias; t.tC_B = 0; }
+      if (sC > 7) { t.tC_RG = (uint32_t)term_bias(2) * 0x10001u; t.tC_B = 0; }
       else make_terms(t.fC, sC, mul, t.nC, t.mC, t.tC_RG, t.tC_B);
       t.cC = sC;
     }
@@ -106,14 +110,13 @@ namespace limg_hip
     template <bool FULL>
     __device__ __forceinline__ uint32_t trial_pixel_error(const TrialState &t, const bool active)
     {
-      const uint32_t estRG = t.tA_RG + t.tB_RG + t.tC_RG; // low half: R estimate + 3 * bias; no carry / borrow crosses the halves
-      const int dBraw = t.tA_B + t.tB_B + t.tC_B; // == pxB - (sum of the three B terms): the B terms are kept negated and factor A's carries the pixel (phase E)
-      short2_t e = __builtin_bit_cast(short2_t, t.pxRGb) - __builtin_bit_cast(short2_t, estRG);
-      e = __builtin_elementwise_max(e, __builtin_bit_cast(short2_t, t.loRG));
-      e = __builtin_elementwise_min(e, __builtin_bit_cast(short2_t, t.hiRG));
+      const uint32_t dRG = t.tA_RG + t.tB_RG + t.tC_RG; // (R - estimate + 0x8000) | (G - estimate + 0x8000) << 16: no carry crosses the halves
+      const int dBraw = t.tA_B + t.tB_B + t.tC_B;        // B - estimate
+      ushort2_t eu = __builtin_bit_cast(ushort2_t, dRG);
+      eu = __builtin_elementwise_max(eu, __builtin_bit_cast(ushort2_t, t.loRG));
+      eu = __builtin_elementwise_min(eu, __builtin_bit_cast(ushort2_t, t.hiRG));
       int dB = med3_i32(dBraw, t.pxBlo, t.pxB); // clamp(px - S, px - 255, px)
-      const ushort2_t eu = __builtin_bit_cast(ushort2_t, e);
-      const ushort2_t sq = eu * eu; // d^2 <= 65025 fits 16 bits; (-d)^2 mod 2^16 == d^2
+      const ushort2_t sq = eu * eu; // (d + 0x8000)^2 mod 2^16 == d^2 <= 65025
       const uint32_t sqB = (uint32_t)mul_i24(dB, dB);
       // weights (R, G, B) = (2, 4, 3) while dR^2 < 0x4000, else (3, 4, 2)  ==  2 * (dR^2 + 2 dG^2 + dB^2) + (dB^2 or dR^2): one dot product with constant weights,
       // one select (the red square is picked out of the packed pair by the select's operand modifier), one shift-add
@@ -984,12 +987,10 @@ namespace limg_hip
             e->nrm[f][slot_of(c)] = nrm[r]; e->off[f][slot_of(c)] = off[r]; // slot order x0 x2 x1 x3, see V4
             if (c == 0) e->invN[f] = invn[r];
             if (PREFIT && c < 3)
-            { // the packed trial's integer operands, once per block here instead of per lane in phase E: n = max - min, m = (min << 8) + 128 (+ the R bias)
+            { // the packed trial's integer operands (negated, see "a9, packed form"), once per block here instead of per lane in phase E
               int *tc = s_trialc + (wave * kBlocksPerWave + b) * kTrialConstDw;
-              // B channel negated: -floor(x / 256) == floor((-x + 255) / 256), so (d * -n + (255 - m)) >> 8 is minus the term -- the trial then needs no subtraction
-              const int n_ = (int)nrm[r], m_ = ((int)off[r] << 8) + 128 + (c == 0 ? (kTermBias << 8) : 0);
-              tc[f * 3 + c] = c == 2 ? -n_ : n_;
-              tc[9 + f * 3 + c] = c == 2 ? 255 - m_ : m_;
+              tc[f * 3 + c] = -(int)nrm[r];
+              tc[9 + f * 3 + c] = term_const(f, c, (int)off[r]);
             }
           }
         }
@@ -1065,9 +1066,8 @@ namespace limg_hip
             TrialState t;
             t.fA = fA; t.fB = fB; t.fC = fC;
             const uint32_t R = px & 0xFF, G = (px >> 8) & 0xFF;
-            t.pxRGb = (R + 3u * kTermBias) | (G << 16);
-            t.hiRG = R | (G << 16);
-            t.loRG = ((R - 255u) & 0xFFFFu) | ((G - 255u) << 16);
+            t.hiRG = (R + 0x8000u) | ((G + 0x8000u) << 16);
+            t.loRG = (R + 0x8000u - 255u) | ((G + 0x8000u - 255u) << 16);
             t.pxB = (int)((px >> 16) & 0xFF);
             t.pxBlo = t.pxB - 255;
             if (PREFIT)
@@ -1085,18 +1085,13 @@ namespace limg_hip
 #pragma unroll
               for (int c = 0; c < 3; c++)
               {
-                const int bias = c == 0 ? (kTermBias << 8) : 0;
                 const int loA = blkE->rec[c], hiA = blkE->rec[4 + c], loB = blkE->rec[8 + c], hiB = blkE->rec[12 + c], loC = blkE->rec[16 + c], hiC = blkE->rec[20 + c];
-                t.nA[c] = hiA - loA; t.nB[c] = hiB - loB; t.nC[c] = hiC - loC;
-                t.mA[c] = (loA << 8) + 128 + bias; t.mB[c] = (loB << 8) + 128 + bias; t.mC[c] = (loC << 8) + 128 + bias;
-                if (c == 2)
-                { // B channel negated, as in the PREFIT table above
-                  t.nA[c] = -t.nA[c]; t.nB[c] = -t.nB[c]; t.nC[c] = -t.nC[c];
-                  t.mA[c] = 255 - t.mA[c]; t.mB[c] = 255 - t.mB[c]; t.mC[c] = 255 - t.mC[c];
-                }
+                t.nA[c] = loA - hiA; t.nB[c] = loB - hiB; t.nC[c] = loC - hiC;
+                t.mA[c] = term_const(0, c, loA); t.mB[c] = term_const(1, c, loB); t.mC[c] = term_const(2, c, loC);
               }
             }
-            t.mA[2] += t.pxB << 8; // per pixel: factor A's (negated) B term becomes pxB - term, so the three B terms sum to pxB - estimate
+            // per pixel: factor A's (negated) terms become  channel - term, so the three terms of a channel sum to  channel - estimate
+            t.mA[0] += (int)(R << 8); t.mA[1] += (int)(G << 8); t.mA[2] += t.pxB << 8;
             t.cA = t.cB = t.cC = 0xFFu;
             t.tA_RG = t.tB_RG = t.tC_RG = 0; t.tA_B = t.tB_B = t.tC_B = 0;
             if (n == 64)
