@@ -154,7 +154,7 @@ def test_accurate_search_automaton_replays_reference_searches():
     words = mst.encode_accurate(mst.build_accurate())
     hdr = open(os.path.join(ROOT, "limg_amd", "csrc", "limg_search_table_accurate.h")).read()
     assert "LIMG_SEARCH_ACC_STATES %d" % len(words) in hdr
-    assert all("{0x%08xu, 0x%08xu}" % w in hdr for w in words[:60] + words[len(words) // 2: len(words) // 2 + 60] + words[-60:])
+    assert all(mst.ACC_ENTRY_FMT % w in hdr for w in words[:60] + words[len(words) // 2: len(words) // 2 + 60] + words[-60:])
     z = gu.blocks()
     longest = 0
     for bi in range(int(z["count"])):

@@ -310,6 +310,7 @@ def walk(words, outcome):
 
 
 ENTRY_FMT = "{0x%08xu, 0x%04xu, 0x%04xu, %du, %du, %du, %du, %du}"
+ACC_ENTRY_FMT = "{0x%x,0x%x}"
 
 
 def main():
@@ -334,7 +335,7 @@ def main():
     open(path, "w").write(text)
     print("wrote", path, len(words), "states")
     acc = encode_accurate(build_accurate())
-    body = ",\n".join("  " + ", ".join("{0x%08xu, 0x%08xu}" % w for w in acc[i:i + 6]) for i in range(0, len(acc), 6))
+    body = ",\n".join(" " + ",".join(ACC_ENTRY_FMT % w for w in acc[i:i + 12]) for i in range(0, len(acc), 12))
     text = """// GENERATED by tools/make_search_table.py -- do not edit.
 // Decision automaton of the reference's ACCURATE shift search (src/limg_bit_crush.h:668-830): %d states (a DAG; state 0 is the start).
 // compact entry = { a | b << 4 | c << 8 | phase2 << 12 | final << 31,  next state on pass | next state on fail << 16 }.  Which trials run depends on pass / fail only;
