@@ -158,10 +158,22 @@ def run_sharded(args, g, dist, rank, world):
         g._comm_ready = True
         before = [(y0 // 8) * (W // 8) for (y0, _) in strips]
 
+    # --contexts K (config 4): the rank's images go round-robin over K contexts, each on a HIP stream of its own -- the next image's float-stage kernel fills the
+    # CUs that the previous image's persistent kernel leaves idle while its last strips drain (a 4096^2 image is only ~5 strips per workgroup)
+    ctxs, streams = [g], [torch.cuda.current_stream()]
+    if args.config == 4 and args.contexts > 1:
+        import limg_amd
+        ctxs += [limg_amd.LimgHip(torch.cuda.current_device()) for _ in range(args.contexts - 1)]
+        streams += [torch.cuda.Stream() for _ in range(args.contexts - 1)]
+        name += ", round-robin over %d contexts / HIP streams" % args.contexts
+
     def step():
         for i, (img, planes) in enumerate(units):
             if single_chain:  # ONE dither chain through the 8 strips (== the reference with pThreadPool == nullptr): an 8-byte all-gather between E and F step
                 g.encode3d_single_chain_device(img, True, planes, before[rank], error_factor=args.error_factor)
+            elif len(ctxs) > 1:
+                with torch.cuda.stream(streams[i % len(ctxs)]):
+                    ctxs[i % len(ctxs)].encode3d_device(img, True, planes, error_factor=args.error_factor, pool_threads=0, fast=True)
             else:
                 g.encode3d_device(img, True, planes, error_factor=args.error_factor, pool_threads=0, fast=True)
 
@@ -478,7 +490,8 @@ def main():
     ap.add_argument("--stream", action="store_true", help="compact LMG3 stream instead of the planes: encode + pack, then decode (SURVEY 8(f) #2)")
     ap.add_argument("--blocked", action="store_true", help="merged-block encoder limg_blocked_encode3d_test (SURVEY 8(f) #1): GPU kernels + host merge / chain walk")
     ap.add_argument("--images", type=int, default=64, help="--config 4: images in the batch")
-    ap.add_argument("--contexts", type=int, default=1, help="--blocked: also time a stream of images pipelined over this many contexts / host threads on the one GPU")
+    ap.add_argument("--contexts", type=int, default=1, help="--blocked: also time a stream of images pipelined over this many contexts / host threads on the one GPU; "
+                    "--config 4: spread the rank's images round-robin over this many contexts / HIP streams")
     ap.add_argument("--no-gather", action="store_true", help="--config 4/5: skip the reassembly of the planes on rank 0")
     ap.add_argument("--gather-stream", action="store_true", help="--config 5: reassemble through the compact LMG3 stream instead of the planes: every rank encodes its "
                                                                      "strips to streams, rank 0 gathers the bytes and decodes them into the full image")
