@@ -654,6 +654,11 @@ def main():
                                   "(HIP events on the launch stream). "
                                   "The kernel is VALU-issue-bound, not HBM-bound: see `valu`")},
         }
+        if n_gpus == 1 and not args.no_host_rate and not (args.split or args.compact or args.forced_shift >= 0):
+            try:  # what a service encoding a stream of images gets: two contexts on two HIP streams, images alternating (never `value`: the kernels overlap)
+                line["config"]["two_streams"] = two_stream_rate(g, img, planes, W, H, args)
+            except Exception as e:
+                line["config"]["two_streams"] = {"error": repr(e)}
         if n_gpus == 1 and not args.no_host_rate:
             try:
                 line["config"]["host_entry"] = host_entry_rate(g, W, H, args)
@@ -668,6 +673,34 @@ def main():
     g.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def two_stream_rate(g, img, planes, W, H, args, n_images=12):
+    """Throughput of a stream of images over two contexts, each on a HIP stream of its own: the second image's float-stage kernel runs on the CUs the first image's
+    persistent kernel leaves idle while its last strips drain (and the other way round).  Same image and options as the timed loop; its own planes for the second context."""
+    import torch
+    import limg_amd
+    g2 = limg_amd.LimgHip(torch.cuda.current_device())
+    g2.set_options(float_fast=(args.float_mode == "fast"), legacy_float_stage=args.legacy_float_stage)
+    planes2 = g2.alloc_planes_device(W, H)
+    s2 = torch.cuda.Stream()
+    pairs = [(g, planes, torch.cuda.current_stream()), (g2, planes2, s2)]
+
+    def run(n):
+        for i in range(n):
+            c, pl, st = pairs[i & 1]
+            with torch.cuda.stream(st):
+                c.encode3d_device(img, not args.rgb, pl, error_factor=args.error_factor, pool_threads=0, fast=not args.accurate)
+    run(4)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(n_images)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    g.check(); g2.check()
+    same = bool(torch.equal(planes["pDecoded"], planes2["pDecoded"]))
+    g2.close()
+    return {"contexts": 2, "images": n_images, "ms_per_image": round(dt * 1e3 / n_images, 4), "Mpixels_per_s": round(n_images * W * H / dt / 1e6, 1), "outputs_identical": same}
 
 
 def host_entry_rate(g, W, H, args):
