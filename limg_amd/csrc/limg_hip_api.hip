@@ -293,6 +293,16 @@ namespace
     p.chainBase = chainPhase == 2 ? dChainBase : nullptr;
     // The float stage as its own launch, one lane per block (limg_hip_fit_tpb.hip), wherever every block is a whole 8x8: the E step then starts from the records.
     p.prefit = (!ragged && c->opt.legacy_float_stage == 0 && (((uintptr_t)p.records) & 15u) == 0) ? 1 : 0; // k_fit_tpb stores records 16 bytes at a time
+    const bool fused = dInfo != nullptr && !ragged && !c->forceSplit && chainPhase == 0;
+    if (fused)
+    { // the persistent kernel's ticket (16 B) and one 8-byte look-back descriptor per work strip, zero at its start: k_fit_tpb clears them on its way (one launch
+      // and its gaps less per image); without that kernel, a memset
+      if ((r = c->lookback.ensure(16 + strips * 8)) != limg_hip_success) return r;
+      p.ticket = (uint32_t *)c->lookback.p;
+      p.desc = (unsigned long long *)((uint8_t *)c->lookback.p + 16);
+      p.zeroLookback = p.prefit ? 1 : 0;
+      if (!p.prefit) HIP_TRY(hipMemsetAsync(c->lookback.p, 0, 16 + strips * 8, stream));
+    }
     if (p.prefit && chainPhase != 2)
     {
       mark(c, stream);
@@ -304,20 +314,14 @@ namespace
         return limg_hip_success;
       }
     }
-    const bool fused = dInfo != nullptr && !ragged && !c->forceSplit && chainPhase == 0;
     if (fused)
     {
-      // one launch does everything: zero the look-back words, go
-      if ((r = c->lookback.ensure(16 + strips * 8)) != limg_hip_success) return r;
-      HIP_TRY(hipMemsetAsync(c->lookback.p, 0, 16 + strips * 8, stream));
-      p.ticket = (uint32_t *)c->lookback.p;
       if (!c->devStatus.p)
       {
         if ((r = c->devStatus.ensure(16)) != limg_hip_success) return r;
         HIP_TRY(hipMemsetAsync(c->devStatus.p, 0, 16, stream));
       }
       p.timeout = (uint32_t *)c->devStatus.p;
-      p.desc = (unsigned long long *)((uint8_t *)c->lookback.p + 16);
       p.compactOut = compact != nullptr;
       if ((r = c->park.ensure((size_t)(c->persistentWorkgroups / 5 * 6) * 2 * 8192)) != limg_hip_success) return r;
       p.park = (uint8_t *)c->park.p;

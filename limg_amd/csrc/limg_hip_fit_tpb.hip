@@ -60,6 +60,11 @@ namespace limg_hip
       const uint32_t unit = unitId % unitsX, by = unitId / unitsX;
       const uint32_t bx0 = unit * 64u, x0 = bx0 * kBlock, y0 = by * kBlock;
       const uint32_t nBlocks = min(p.blocksX - bx0, 64u), widthPx = nBlocks * kBlock;
+      if (p.zeroLookback)
+      { // this wave's 64 blocks are two work strips of the persistent kernel: clear their look-back descriptors (and, once, the ticket) instead of a memset launch
+        if ((uint32_t)lane < 2u && unit * 2u + (uint32_t)lane < p.stripsX) p.desc[(size_t)by * p.stripsX + unit * 2u + (uint32_t)lane] = 0ull;
+        if (unitId == 0 && lane < 4) p.ticket[lane] = 0u;
+      }
 
       // ---- stage the 8 pixel rows (coalesced 16 bytes per lane) into the block-major layout ----
       if (!DIRECT)

@@ -44,6 +44,7 @@ namespace limg_hip
     // fused single-kernel path: per-strip look-back descriptors (status << 32 | value), work ticket, error word
     unsigned long long *desc;
     uint32_t *ticket;   // [0] = next strip id
+    int32_t zeroLookback; // k_fit_tpb clears `ticket` (16 bytes) and the descriptors of the strips its waves cover (the persistent launch follows it on the stream)
     uint32_t *timeout;  // sticky: set when a look-back spin gave up; lives outside the per-launch words, cleared only by limg_hip_check_device_status
     uint8_t *park;      // persistent kernel: per workgroup two 8 KiB slots holding a strip's parked results between its E and F steps
     int32_t compactOut; // persistent kernel: also write records / shift words to the raster-order arrays
