@@ -1368,6 +1368,10 @@ namespace limg_hip
       // loop and kept alive across it -- more SGPRs than there are, so the compiler parks them in VGPR lanes and pays a quarter-rate v_readlane per use.
       typedef const __attribute__((address_space(4))) EncodeParams KernArgs;
       KernArgs *const kargs = (KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+      // All workgroups start their first E step together, so their first F steps (latency-bound, little vector work) coincide too, and it takes a few iterations
+      // of data-dependent search lengths before the E and F steps of a CU's six workgroups interleave.  Workgroups are dealt out to the 256 CUs residency slot
+      // by slot, so slot k (= blockIdx.x / 256) starts k * 3.4 us late: measured -0.5 % on the kernel, and harmless where the placement differs.
+      for (uint32_t i = 0; i < (blockIdx.x >> 8); i++) __builtin_amdgcn_s_sleep(127);
       for (;;)
       {
         __syncthreads(); // the previous step's LDS use is over (and the rsqrt table is in place)
