@@ -14,6 +14,9 @@
 // Kernels: k_encode_persistent (one launch per image: every workgroup loops over work strips, E step of a new strip then the
 // F step of the strip it fitted one iteration earlier) and the three-launch split path k_fit_search / k_strip_scan /
 // k_dither_store (images with partial edge blocks, whose chain has to be walked on the host; `_perf` mode; A/B testing).
+// For images made of whole blocks the float stage (channel sums, direction fit, extrema, record) runs before them as its own
+// kernel with one lane per block (k_fit_tpb, limg_hip_fit_tpb.hip; template parameter PREFIT here): the E step then starts from
+// the records.  The float-stage code in this file is the lane == pixel form that images with partial edge blocks keep.
 //
 // Work decomposition: one 256-thread workgroup owns a "work strip" of 32 adjacent 8x8 image blocks (256 x 8 pixels): its
 // eight 1 KiB pixel rows are read with 16-byte-per-lane loads into LDS, each of the 4 waves then owns 8 blocks and works
@@ -1347,7 +1350,7 @@ namespace limg_hip
     // Both steps are inlined into the loop.  Left alone, LLVM hoists every lane-dependent address computation of both steps
     // out of the loop (they only depend on threadIdx) and keeps them all live: 194 VGPRs.  Passing the thread id through an
     // empty asm at the top of each iteration makes it opaque per iteration, which keeps the two steps' live ranges apart.
-    // Persistent single-launch encode: 5 workgroups per CU loop over the work strips (ticket order).  Each iteration runs the
+    // Persistent single-launch encode: 6 workgroups per CU (5 with the float stage inside) loop over the work strips (ticket order).  Each iteration runs the
     // VALU-bound E step (fit + search) of a new strip and then the HBM-bound F step (dither, decode, all plane stores) of the
     // strip the SAME workgroup fitted one iteration earlier, whose parked results sit in a private, L2-resident 8 KiB slot.
     // The one-iteration lag means that by the time an F step asks for its strip's position in the dither chain, every
