@@ -1117,13 +1117,14 @@ namespace limg_hip
           {
             // out-of-range record (never produced by a fit of byte pixels; kept so that no input can break exactness):
             // generic 32-bit trial, deliberately a real call so that none of it is speculated into the common path
-            const uint32_t packed = search_generic(px, fA, fB, fC, blkE->rec, active, p.maxPixel32, maxBlockN, p.fast != 0);
+            const uint32_t packed = (uint32_t)sgpr((int)search_generic(px, fA, fB, fC, blkE->rec, active, p.maxPixel32, maxBlockN, p.fast != 0)); // uniform: keeps the shift triple (and the bookkeeping below) on the scalar unit for the common path too
             shift[0] = packed & 0xFF; shift[1] = (packed >> 8) & 0xFF; shift[2] = (packed >> 16) & 0xFF;
           }
         }
 
         // dither calls this block will make (src/limg.cpp:1951-1958)
-        const uint32_t calls = (shift[0] && shift[0] != 8 ? 1u : 0u) + (shift[1] && shift[1] != 8 ? 1u : 0u) + (shift[2] && shift[2] != 8 ? 1u : 0u);
+        // a shift of 1..7 dithers (one call), 0 and 8 do not; as scalar arithmetic -- ((s & 7) + 7) >> 3 -- because a boolean would go through a lane mask and a vector select
+        const uint32_t calls = (((shift[0] & 7u) + 7u) >> 3) + (((shift[1] & 7u) + 7u) >> 3) + (((shift[2] & 7u) + 7u) >> 3);
         waveCalls += calls;
 
         const size_t bi = (size_t)by * p.blocksX + bx;
