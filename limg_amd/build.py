@@ -12,6 +12,9 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liblimg_hip.so")
 SOURCES = ["limg_hip_kernels.hip", "limg_hip_fit_tpb.hip", "limg_hip_stream.hip", "limg_hip_blocked.hip", "limg_hip_synth.hip", "limg_hip_api.hip", "limg_hip_noise.cpp", "limg_hip_blocked_host.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+# per-source extras.  limg_hip_kernels.hip: every atomic in it is issued by one lane (block queue, ticket, look-back descriptors); LLVM's atomic optimizer would still
+# wrap each in its wave-aggregation prologue (v_mbcnt x 2, compare, s_bcnt1, broadcast, add) -- five vector instructions per 8x8 block for nothing
+SOURCE_FLAGS = {"limg_hip_kernels.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]}
 
 
 def _newer(target, deps):
@@ -31,7 +34,7 @@ def build(force=False, verbose=False, extra_flags=(), out_dir=None):
     objs = []
     for src in SOURCES:
         obj = os.path.join(CSRC if out_dir is None else out_dir, src.rsplit(".", 1)[0] + ".o")
-        cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + SOURCE_FLAGS.get(src, []) + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if src.endswith(".cpp"):
             # host-only translation units; the merge's similarity predicate is float code that must round like the kernels: no contraction
             cmd = [hipcc, "-O3", "-fPIC", "-std=c++17", "-Wall", "-ffp-contract=off", "-fno-fast-math", "-x", "c++", "-c", os.path.join(CSRC, src), "-o", obj]
