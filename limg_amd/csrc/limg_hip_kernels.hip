@@ -154,8 +154,13 @@ namespace limg_hip
       const SearchEntry *tab = d_search_tab;
       asm volatile("" : "+s"(tab)); // opaque: otherwise the address is rematerialised (s_getpc + 2 adds) in every iteration
       // entry 0 as immediates (the opaque base above would make reading it a memory round trip per block)
+      // its three factors are built here, unconditionally and with immediate operands (the loop then starts with nothing to rebuild): the cached terms need no
+      // initial value at all
       constexpr uint32_t root[8] = LIMG_SEARCH_ROOT;
-      uint8s_t e = { root[0], root[1], root[2], root[3], root[4], root[5], root[6], root[7] };
+      rebuild_A(t, root[0] & 31u, root[5]);
+      rebuild_B(t, root[3], root[6]);
+      rebuild_C(t, root[4], root[7]);
+      uint8s_t e = { root[0] & ~0xE0u, root[1], root[2], root[3], root[4], root[5], root[6], root[7] };
       while (!(e[0] >> 31))
       { // every field sits in an SGPR of its own: no extraction.  (e[0] & 31 is the shift amount as v_lshrrev_b32 reads it -- the mask costs nothing)
         if (e[0] & 0x20u) rebuild_A(t, e[0] & 31u, e[5]);
@@ -182,6 +187,12 @@ namespace limg_hip
     {
       const SearchEntry *tab = reinterpret_cast<const SearchEntry *>(table);
       uint32_t bestA = 0, bestB = 0, bestC = 0, minBe = 0xFFFFFFFFu;
+      { // the first triple is the fast search's: built unconditionally, so that the cached terms need no initial value
+        constexpr uint32_t root[8] = LIMG_SEARCH_ROOT;
+        rebuild_A(t, root[0] & 31u, root[5]);
+        rebuild_B(t, root[3], root[6]);
+        rebuild_C(t, root[4], root[7]);
+      }
       uint8s_t e = sload8(tab, 0u);
       while (!(e[0] >> 31))
       {
@@ -1098,18 +1109,18 @@ namespace limg_hip
             }
             // per pixel: factor A's (negated) terms become  channel - term, so the three terms of a channel sum to  channel - estimate
             t.mA[0] += (int)(R << 8); t.mA[1] += (int)(G << 8); t.mA[2] += t.pxB << 8;
-            t.cA = t.cB = t.cC = 0xFFu;
-            // nothing is cached yet: both searches rebuild all three factors for their first triple, so the terms start undefined (an empty asm "defines" them:
-            // six v_mov less per block than zeroing)
-            asm volatile("" : "=v"(t.tA_RG), "=v"(t.tB_RG), "=v"(t.tC_RG), "=v"(t.tA_B), "=v"(t.tB_B), "=v"(t.tC_B));
-            if (n == 64)
+            // (the flag goes through an opaque scalar: hoisted out of the block loop as a boolean it comes back as a lane mask that is negated with two vector
+            //  instructions per block)
+            int fastNow = p.fast;
+            asm volatile("" : "+s"(fastNow));
+            if (fastNow)
             {
-              if (p.fast) search_fast_automaton<true>(t, true, p.maxPixel32, blockLimit, shift);
-              else search_accurate_automaton<true>(t, true, p.maxPixel32, blockLimit, p.accTable, shift);
+              if (n == 64) search_fast_automaton<true>(t, true, p.maxPixel32, blockLimit, shift);
+              else search_fast_automaton<false>(t, active, p.maxPixel32, blockLimit, shift);
             }
             else
             {
-              if (p.fast) search_fast_automaton<false>(t, active, p.maxPixel32, blockLimit, shift);
+              if (n == 64) search_accurate_automaton<true>(t, true, p.maxPixel32, blockLimit, p.accTable, shift);
               else search_accurate_automaton<false>(t, active, p.maxPixel32, blockLimit, p.accTable, shift);
             }
           }
