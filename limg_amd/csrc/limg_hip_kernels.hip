@@ -245,14 +245,14 @@ namespace limg_hip
       uint8_t *fac;    // [3][8][256]  pre-dither factor bytes of the strip (plane-row layout)
       uint32_t *dec;   // [4 waves][8 rows][64]  decoded pixels
       uint8_t *out;    // == fac: a lane's output byte replaces the pre-dither byte it has just read (same index)
-      uint32_t *cst;   // [7][32]  per-block constants of the 7 block-uniform planes
+      uint32_t *cst;   // [7][32][4]  per-block constants of the 7 block-uniform planes, each four times over: a 16-byte store takes it from one ds_read_b128
       int32_t *nm;     // [32 blocks][2][3][4]  effective integer normals / additive constants of the decode
       uint32_t *shift; // [32]  shift words
       uint32_t *first; // [32]  first dither-call index of each block
       const int16_t *rec; // record of block sb at rec + sb * recStride
       int recStride;
     };
-    constexpr int kPhaseFBytes = 6144 + 8192 + 896 + 3072 + 128 + 128; // the output factor bytes replace the pre-dither ones in place
+    constexpr int kPhaseFBytes = 6144 + 8192 + 3584 + 3072 + 128 + 128; // the output factor bytes replace the pre-dither ones in place
 
     __device__ __forceinline__ StripLds carve_phase_f(uint8_t *base, const int16_t *rec, int recStride)
     {
@@ -261,8 +261,8 @@ namespace limg_hip
       L.dec = reinterpret_cast<uint32_t *>(base + 6144);
       L.out = base;
       L.cst = reinterpret_cast<uint32_t *>(base + 6144 + 8192);
-      L.nm = reinterpret_cast<int32_t *>(base + 6144 + 8192 + 896);
-      L.shift = reinterpret_cast<uint32_t *>(base + 6144 + 8192 + 896 + 3072);
+      L.nm = reinterpret_cast<int32_t *>(base + 6144 + 8192 + 3584);
+      L.shift = reinterpret_cast<uint32_t *>(base + 6144 + 8192 + 3584 + 3072);
       L.first = L.shift + 32;
       L.rec = rec; L.recStride = recStride;
       return L;
@@ -298,7 +298,7 @@ namespace limg_hip
           }
           if (CH == 3) v |= 0xFF000000u;
         }
-        L.cst[k * kStripBlocks + sb] = v;
+        reinterpret_cast<uint4 *>(L.cst)[k * kStripBlocks + sb] = make_uint4(v, v, v, v);
       }
 #pragma unroll
       for (int r = 0; r < 2; r++)
@@ -334,9 +334,7 @@ namespace limg_hip
       if (p.vecPlanes)
       {
         const uint32_t col = ((uint32_t)lane & 15u) * 4u, rsub = (uint32_t)lane >> 4; // 16 lanes per row, 4 rows per instruction
-        uint32_t cst[7];
-#pragma unroll
-        for (int k = 0; k < 7; k++) cst[k] = L.cst[k * kStripBlocks + wave * kBlocksPerWave + (col >> 3)];
+        const uint4 *cst = reinterpret_cast<const uint4 *>(L.cst) + wave * kBlocksPerWave + (col >> 3); // read per store: the LDS pipe has the room, registers do not
         if (col < ww)
 #pragma unroll
           for (uint32_t half = 0; half < 2; half++)
@@ -344,16 +342,17 @@ namespace limg_hip
             const uint32_t row = half * 4 + rsub;
             if (row < ry)
             {
-              const size_t g = (size_t)(y0 + row) * p.sizeX + wx0 + col;
+              size_t g = (size_t)(y0 + row) * p.sizeX + wx0 + col;
+              asm volatile("" : "+v"(g)); // one offset for the seven planes (left to itself the compiler adds its three loop-invariant parts to every plane's base separately)
 #pragma unroll
-              for (int k = 0; k < 7; k++) *reinterpret_cast<uint4 *>(planes[k] + g) = make_uint4(cst[k], cst[k], cst[k], cst[k]);
+              for (int k = 0; k < 7; k++) *reinterpret_cast<uint4 *>(planes[k] + g) = cst[k * kStripBlocks];
             }
           }
         return;
       }
       uint32_t cst[7];
 #pragma unroll
-      for (int k = 0; k < 7; k++) cst[k] = L.cst[k * kStripBlocks + wave * kBlocksPerWave + (lane >> 3)];
+      for (int k = 0; k < 7; k++) cst[k] = L.cst[(k * kStripBlocks + wave * kBlocksPerWave + (lane >> 3)) * 4];
       if ((uint32_t)lane < ww)
         for (uint32_t row = 0; row < ry; row++)
         {
