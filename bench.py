@@ -167,7 +167,14 @@ def run_sharded(args, g, dist, rank, world):
         streams += [torch.cuda.Stream() for _ in range(args.contexts - 1)]
         name += ", round-robin over %d contexts / HIP streams" % args.contexts
 
+    batched = args.config == 4 and len(ctxs) == 1 and not args.no_batch and len(units) > 1
+    if batched:
+        name += ", the rank's %d images in ONE launch pair (limg_hip_encode3d_batch_device)" % len(units)
+
     def step():
+        if batched:  # the reference's per-file loop (src/main.cpp:278-323) as one call: one k_fit_tpb grid + one persistent launch over all images
+            g.encode3d_batch_device([u[0] for u in units], True, [u[1] for u in units], error_factor=args.error_factor, pool_threads=0, fast=True)
+            return
         for i, (img, planes) in enumerate(units):
             if single_chain:  # ONE dither chain through the 8 strips (== the reference with pThreadPool == nullptr): an 8-byte all-gather between E and F step
                 g.encode3d_single_chain_device(img, True, planes, before[rank], error_factor=args.error_factor)
@@ -190,6 +197,7 @@ def run_sharded(args, g, dist, rank, world):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernels = g.profile_end(args.steps * max(len(units), 1))
+    launches_per_step = 1 if batched else len(units)
     if dist is not None:
         dist.barrier()
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
@@ -261,7 +269,8 @@ def run_sharded(args, g, dist, rank, world):
     if rank == 0:
         kavg = kernels.mean(axis=0) if len(kernels) else np.zeros(3)
         ksum = float(kavg.sum())  # k_fit_tpb + k_encode_persistent of one unit (single chain: the E/scan, exchange and F intervals)
-        px_per_launch = units[0][0].numel() if units else 0
+        px_per_launch = (units[0][0].numel() if units else 0) * (len(units) if batched else 1)
+        pmc = pmc_entry("config%d_%s%s" % (args.config, "batched" if batched else "single", "" if args.contexts == 1 else "_ctx%d" % args.contexts))
         achieved = ALGO_BYTES_PER_PX * px_per_launch / (ksum * 1e-3) / 1e9 if ksum > 0 else 0.0
         line = {
             "metric": "encode Mpixels/s, RGBA (limg_encode3d_test-equivalent: all 11 planes stored), BASELINE configs[%d]" % (args.config - 1),
@@ -273,10 +282,13 @@ def run_sharded(args, g, dist, rank, world):
                        "gather_ms": None if gather_ms is None else round(gather_ms, 3), "gathered_bytes_rank0": gathered_bytes,
                        "gather_backend": None if dist is None else dist.get_backend(), "gathered": "LMG3 streams, decoded on rank 0" if args.gather_stream else "planes"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": None, "algorithmic_bytes_per_launch": int(ALGO_BYTES_PER_PX * px_per_launch),
+                         "traffic": None if not pmc or pmc.get("fetch_kib") is None else int((2 * pmc["fetch_kib"] + pmc["write_kib"]) * 1024),
+                         "valu_busy": None if not pmc else pmc.get("valu_busy"), "pmc_source": None if not pmc else pmc.get("source"),
+                         "algorithmic_bytes_per_launch": int(ALGO_BYTES_PER_PX * px_per_launch), "launch_pairs_per_step": launches_per_step,
                          "kernels_ms": {"k_fit_tpb": round(float(kavg[0]), 4), "k_encode_persistent": round(float(kavg[1]), 4)} if not single_chain else
                                        {"E step + scan": round(float(kavg[0]), 4), "all-gather + base": round(float(kavg[1]), 4), "F step": round(float(kavg[2]), 4)},
-                         "note": "per unit = one image (config 4) / one strip (config 5) on rank 0: k_fit_tpb + k_encode_persistent; HIP events on the launch stream"},
+                         "note": "per launch pair = %s on rank 0: k_fit_tpb + k_encode_persistent; HIP events on the launch stream"
+                                 % ("the rank's whole image list" if batched else "one image (config 4) / one strip (config 5)")},
         }
         print(json.dumps(line), flush=True)
 
@@ -492,6 +504,7 @@ def main():
     ap.add_argument("--images", type=int, default=64, help="--config 4: images in the batch")
     ap.add_argument("--contexts", type=int, default=1, help="--blocked: also time a stream of images pipelined over this many contexts / host threads on the one GPU; "
                     "--config 4: spread the rank's images round-robin over this many contexts / HIP streams")
+    ap.add_argument("--no-batch", action="store_true", help="--config 4: one launch pair per image (limg_hip_encode3d_device in a loop) instead of the batched entry")
     ap.add_argument("--no-gather", action="store_true", help="--config 4/5: skip the reassembly of the planes on rank 0")
     ap.add_argument("--gather-stream", action="store_true", help="--config 5: reassemble through the compact LMG3 stream instead of the planes: every rank encodes its "
                                                                      "strips to streams, rank 0 gathers the bytes and decodes them into the full image")

@@ -70,6 +70,8 @@ typedef struct limg_hip_options
                                   within 0.10 dB of EXACT; the 8x8 path only (the merged-block encoder always runs EXACT) */
   int32_t legacy_float_stage;  /* non-0: run the float stage inside the E step with lane == pixel (round-1 mapping; what images with partial edge blocks always use)
                                   instead of the one-lane-per-block kernel k_fit_tpb.  Same bits either way; A/B switch for tests and the bench */
+  int32_t test_batch_chunk;    /* test hook, 0 = default: limg_hip_encode3d_batch_device puts at most this many images into one launch pair (default: as many as 1 GiB
+                                  of per-block scratch holds) */
 } limg_hip_options;
 
 typedef struct limg_hip_context limg_hip_context;
@@ -102,6 +104,15 @@ limg_hip_result limg_hip_encode3d_perf(limg_hip_context *pCtx, const uint32_t *p
 limg_hip_result limg_hip_encode3d_device(limg_hip_context *pCtx, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha,
                                          const limg_hip_encode3d_info *pInfo, const limg_hip_compact_out *pCompact, uint32_t errorFactor, int poolThreads,
                                          int fastBitCrushing, void *stream);
+
+/* A list of images of ONE shape, each with its own 11 planes: replaces the reference's per-file loop `for (file) limg_encode3d_test(...)` (src/main.cpp:278-323, what
+ * its `--count` benchmark and BASELINE configs 2 / 4 run).  ppIn[i] / pInfos[i] are the DEVICE pointers of image i (the arrays themselves are host memory and may be
+ * freed when the call returns).  Every image gets the planes a single limg_hip_encode3d_device call would give it (own dither chain(s), same poolThreads rule), but
+ * the whole list goes through one launch pair -- one float-stage grid over the blocks of all images, one persistent launch over the strips of all images -- so a
+ * small image's ramp-up and drain are paid once per list, not once per image.  Images with partial edge blocks, compact mode (planes NULL) and the A/B options
+ * fall back to one encode per image, same results.  Asynchronous on `stream`. */
+limg_hip_result limg_hip_encode3d_batch_device(limg_hip_context *pCtx, size_t count, const uint32_t *const *ppIn, size_t sizeX, size_t sizeY, int hasAlpha,
+                                               const limg_hip_encode3d_info *pInfos, uint32_t errorFactor, int poolThreads, int fastBitCrushing, void *stream);
 
 /* Replaces `limg_compare` (src/limg.h:48, src/limg.cpp:2455-2491): perceptual PSNR; HOST pointers. */
 double limg_hip_compare(limg_hip_context *pCtx, const uint32_t *pImageA, const uint32_t *pImageB, size_t sizeX, size_t sizeY, int hasAlpha,

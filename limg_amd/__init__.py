@@ -19,7 +19,7 @@ PLANES = P32 + P8
 # every symbol include/limg_hip.h declares (checked by tests/test_host.py without a GPU)
 ABI_SYMBOLS = (
     "limg_hip_init", "limg_hip_shutdown", "limg_hip_default_options", "limg_hip_set_options", "limg_hip_encode3d", "limg_hip_encode3d_perf",
-    "limg_hip_encode3d_device", "limg_hip_compare", "limg_hip_compare_device", "limg_hip_synth_random_gradient_device",
+    "limg_hip_encode3d_device", "limg_hip_encode3d_batch_device", "limg_hip_compare", "limg_hip_compare_device", "limg_hip_synth_random_gradient_device",
     "limg_hip_synth_photo_noise_device", "limg_hip_context_device_bytes", "limg_hip_version", "limg_hip_profile_begin", "limg_hip_profile_end",
     "limg_hip_host_noise_table", "limg_hip_host_chain_call", "limg_hip_host_partition", "limg_hip_check_device_status",
     "limg_hip_stream_bound", "limg_hip_encode_stream_device", "limg_hip_decode_stream_device", "limg_hip_encode_stream", "limg_hip_decode_stream",
@@ -59,7 +59,8 @@ class CompactOut(C.Structure):
 
 
 class Options(C.Structure):
-    _fields_ = [("forced_shift", C.c_int32 * 3), ("force_split_kernels", C.c_int32), ("dither_pcg", C.c_int32), ("test_record_limit", C.c_int32), ("float_mode", C.c_int32), ("legacy_float_stage", C.c_int32)]
+    _fields_ = [("forced_shift", C.c_int32 * 3), ("force_split_kernels", C.c_int32), ("dither_pcg", C.c_int32), ("test_record_limit", C.c_int32), ("float_mode", C.c_int32), ("legacy_float_stage", C.c_int32),
+                ("test_batch_chunk", C.c_int32)]
 
 
 def load_library(path=None):
@@ -87,6 +88,8 @@ def load_library(path=None):
     L.limg_hip_encode3d_perf.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_uint32, C.c_int, C.c_int]
     L.limg_hip_encode3d_device.restype = C.c_int
     L.limg_hip_encode3d_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+    L.limg_hip_encode3d_batch_device.restype = C.c_int
+    L.limg_hip_encode3d_batch_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
     L.limg_hip_compare.restype = C.c_double
     L.limg_hip_compare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
     L.limg_hip_compare_device.restype = C.c_double
@@ -237,7 +240,7 @@ class LimgHip:
         except Exception:
             pass
 
-    def set_options(self, forced_shift=None, force_split=False, dither_pcg=False, test_record_limit=0, float_fast=False, legacy_float_stage=False):
+    def set_options(self, forced_shift=None, force_split=False, dither_pcg=False, test_record_limit=0, float_fast=False, legacy_float_stage=False, test_batch_chunk=0):
         o = Options()
         self.lib.limg_hip_default_options(C.byref(o))
         if forced_shift is not None:
@@ -248,6 +251,7 @@ class LimgHip:
         o.test_record_limit = int(test_record_limit)
         o.float_mode = 1 if float_fast else 0
         o.legacy_float_stage = int(legacy_float_stage)
+        o.test_batch_chunk = int(test_batch_chunk)
         _check(self.lib.limg_hip_set_options(self.ctx, C.byref(o)), "limg_hip_set_options")
 
     def set_forced_shift(self, shift=None):
@@ -298,6 +302,16 @@ class LimgHip:
             comp = CompactOut(records.data_ptr() if records is not None else None, shifts.data_ptr() if shifts is not None else None)
         _check(self.lib.limg_hip_encode3d_device(self.ctx, C.c_void_p(img.data_ptr()), w, h, int(has_alpha), C.byref(info) if info else None,
                                                  C.byref(comp) if comp else None, error_factor, pool_threads, int(fast), self._stream()), "limg_hip_encode3d_device")
+
+    def encode3d_batch_device(self, imgs, has_alpha, planes_list, error_factor=100, pool_threads=0, fast=True):
+        """imgs: list of torch int32 CUDA tensors of one shape; planes_list: one alloc_planes_device dict per image.  One launch pair for the whole list."""
+        n = len(imgs)
+        h, w = imgs[0].shape
+        assert all(tuple(i.shape) == (h, w) for i in imgs) and len(planes_list) == n
+        ins = (C.c_void_p * n)(*[i.data_ptr() for i in imgs])
+        infos = (Info * n)(*[Info(*[(pl[k].data_ptr() if k in pl else None) for k in PLANES]) for pl in planes_list])
+        _check(self.lib.limg_hip_encode3d_batch_device(self.ctx, n, ins, w, h, int(has_alpha), infos, error_factor, pool_threads, int(fast), self._stream()),
+               "limg_hip_encode3d_batch_device")
 
     def compare_device(self, a, b, has_alpha):
         mse, mx = C.c_double(), C.c_double()

@@ -80,6 +80,7 @@ struct limg_hip_context
   uint64_t noiseNext = kDitherSeed;              // chain value after the last generated entry
   DevBuf noiseDyn;                               // data-dependent chains (images with partial blocks)
   DevBuf park;                                   // persistent kernel: 2 x 8 KiB per workgroup
+  DevBuf batchTable;                             // batched encode: one ImageIO per image
   DevBuf lookback;                               // fused path: ticket (16 B) then one 8-byte descriptor per work strip
   DevBuf accTable;                               // accurate search: automaton expanded to 32-byte entries (built on the first accurate encode)
   DevBuf devStatus;                              // sticky look-back timeout word: never touched by the per-launch memset, cleared by limg_hip_check_device_status
@@ -201,8 +202,11 @@ namespace
 
   limg_hip_result encode_device(limg_hip_context *c, const uint32_t *dIn, size_t sizeX, size_t sizeY, int hasAlpha, const limg_hip_encode3d_info *dInfo,
                                 const limg_hip_compact_out *compact, uint32_t errorFactor, int poolThreads, int fast, hipStream_t stream, bool streamRaw = false, bool fitOnly = false,
-                                int chainPhase = 0, unsigned long long *dChainCalls = nullptr, const unsigned long long *dChainBase = nullptr, size_t chainBlocksBefore = 0)
+                                int chainPhase = 0, unsigned long long *dChainCalls = nullptr, const unsigned long long *dChainBase = nullptr, size_t chainBlocksBefore = 0,
+                                const ImageIO *batch = nullptr, size_t batchCount = 1)
   {
+    // batch (host array of batchCount entries, batchCount > 1): the images of a batched encode -- same shape, whole 8x8 blocks, all 11 planes -- in one launch
+    // pair; dIn / dInfo are then those of image 0.  The caller (limg_hip_encode3d_batch_device) has checked all of that.
     // chainPhase: 0 = whole encode; 1 = E step + scan only (writes *dChainCalls); 2 = F step only (reads *dChainBase).  1 and 2 always take the split path.
     if (!c || !dIn) return limg_hip_error_ArgumentNull;
     if (chainPhase == 0) c->chainIn = nullptr; // the context's per-block scratch is about to be reused
@@ -223,7 +227,7 @@ namespace
 
     EncodeParams p;
     memset(&p, 0, sizeof(p));
-    p.in = dIn;
+    p.io.in = dIn;
     p.sizeX = (uint32_t)sizeX; p.sizeY = (uint32_t)sizeY;
     p.blocksX = (uint32_t)((sizeX + kBlock - 1) / kBlock);
     p.blocksY = (uint32_t)((sizeY + kBlock - 1) / kBlock);
@@ -250,7 +254,9 @@ namespace
     const Partition pt = partition(sizeY, poolThreads);
     p.chainCount = pt.chainCount; p.chainRows = pt.chainRows;
 
-    const size_t blocks = (size_t)p.blocksX * p.blocksY, strips = (size_t)p.stripsX * p.blocksY;
+    p.batchCount = (uint32_t)batchCount;
+    p.imageStrips = p.stripsX * p.blocksY;
+    const size_t blocks = (size_t)p.blocksX * p.blocksY * batchCount, strips = (size_t)p.stripsX * p.blocksY * batchCount; // of all images
     limg_hip_result r;
     if (compact && compact->pRecords) p.records = compact->pRecords;
     else { if ((r = c->records.ensure(blocks * sizeof(limg_hip_block_record))) != limg_hip_success) return r; p.records = (limg_hip_block_record *)c->records.p; }
@@ -263,7 +269,7 @@ namespace
     p.fullPlanes = fullPlanes;
     p.streamRaw = streamRaw && !fullPlanes;
     p.fitOnly = fitOnly && !dInfo;
-    if (dInfo) p.info = *dInfo;
+    if (dInfo) p.io.info = *dInfo;
     // 16-byte vector access straight on caller pointers only where the address is 16-byte aligned for every row: sliced or offset
     // device pointers take the dword paths
     p.vecIn = (sizeX % 4 == 0) && (((uintptr_t)dIn) & 15u) == 0;
@@ -278,6 +284,21 @@ namespace
     p.vecFactors = dInfo && (sizeX % 16 == 0) && ((((uintptr_t)dInfo->pFactorsA) | ((uintptr_t)dInfo->pFactorsB) | ((uintptr_t)dInfo->pFactorsC)) & 15u) == 0;
     const int channels = hasAlpha ? 4 : 3;
     const bool ragged = (sizeX % kBlock) != 0 || (sizeY % kBlock) != 0;
+    if (batchCount > 1)
+    { // the 16-byte access paths only if every image of the batch allows them; the table goes to the device behind whatever the stream still holds
+      for (size_t i = 1; i < batchCount; i++)
+      {
+        uintptr_t bits = 0;
+        const void *const *pp = reinterpret_cast<const void *const *>(&batch[i].info);
+        for (int k = 1; k < 8; k++) bits |= (uintptr_t)pp[k];
+        p.vecPlanes = p.vecPlanes && (bits & 15u) == 0;
+        p.vecIn = p.vecIn && (((uintptr_t)batch[i].in) & 15u) == 0;
+        p.vecFactors = p.vecFactors && ((((uintptr_t)batch[i].info.pFactorsA) | ((uintptr_t)batch[i].info.pFactorsB) | ((uintptr_t)batch[i].info.pFactorsC)) & 15u) == 0;
+      }
+      if ((r = c->batchTable.ensure(batchCount * sizeof(ImageIO))) != limg_hip_success) return r;
+      launch_set_batch_table((ImageIO *)c->batchTable.p, batch, batchCount, stream); // through kernel arguments: stream-ordered, and the host array may die right away
+      p.batch = (const ImageIO *)c->batchTable.p;
+    }
 
     if (dInfo && !ragged)
     {
@@ -293,7 +314,8 @@ namespace
     p.chainBase = chainPhase == 2 ? dChainBase : nullptr;
     // The float stage as its own launch, one lane per block (limg_hip_fit_tpb.hip), wherever every block is a whole 8x8: the E step then starts from the records.
     p.prefit = (!ragged && c->opt.legacy_float_stage == 0 && (((uintptr_t)p.records) & 15u) == 0) ? 1 : 0; // k_fit_tpb stores records 16 bytes at a time
-    const bool fused = dInfo != nullptr && !ragged && !c->forceSplit && chainPhase == 0;
+    const bool fused = dInfo != nullptr && !ragged && (!c->forceSplit || batchCount > 1) && chainPhase == 0;
+    if (batchCount > 1 && (!fused || !p.prefit || !fullPlanes)) return limg_hip_error_InvalidParameter; // the caller falls back to one encode per image
     if (fused)
     { // the persistent kernel's ticket (16 B) and one 8-byte look-back descriptor per work strip, zero at its start: k_fit_tpb clears them on its way (one launch
       // and its gaps less per image); without that kernel, a memset
@@ -436,7 +458,7 @@ extern "C"
     limg_hip_context *c = *ppCtx;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = { &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->lookback, &c->devStatus, &c->accTable, &c->commWords, &c->park, &c->in, &c->planes, &c->cmp,
+    DevBuf *bufs[] = { &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->lookback, &c->devStatus, &c->accTable, &c->commWords, &c->park, &c->batchTable, &c->in, &c->planes, &c->cmp,
                        &c->streamFac, &c->streamTiles, &c->streamStatus, &c->streamBuf,
                        &c->bFlags, &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bV, &c->bFac, &c->bNoise, &c->bNoiseBase };
     for (DevBuf *b : bufs) b->release();
@@ -553,6 +575,55 @@ extern "C"
                                            const limg_hip_compact_out *pCompact, uint32_t errorFactor, int poolThreads, int fastBitCrushing, void *stream)
   {
     return encode_device(c, pIn, sizeX, sizeY, hasAlpha, pInfo, pCompact, errorFactor, poolThreads, fastBitCrushing, (hipStream_t)stream);
+  }
+
+  // The reference encodes a list of images by calling limg_encode3d_test(_perf) once per image (src/main.cpp:278-323).  Here the images of one shape go through ONE
+  // launch pair: one k_fit_tpb grid over the blocks of all images and one persistent launch whose tickets run through the strips of image 0, image 1, ...;
+  // every image starts its own dither chain(s), so each image's planes are those of a single encode.  A small image alone cannot fill the chip for long
+  // (a 4096^2 image is ~5 strips per workgroup: ramp-up and drain are a third of its encode); a batch amortises both.
+  limg_hip_result limg_hip_encode3d_batch_device(limg_hip_context *c, size_t count, const uint32_t *const *ppIn, size_t sizeX, size_t sizeY, int hasAlpha,
+                                                 const limg_hip_encode3d_info *pInfos, uint32_t errorFactor, int poolThreads, int fastBitCrushing, void *stream)
+  {
+    if (!c || !ppIn || !pInfos) return limg_hip_error_ArgumentNull;
+    if (count == 0) return limg_hip_success;
+    if (sizeX == 0 || sizeY == 0 || sizeX > 0x7FFFFFF8ull || sizeY > 0x7FFFFFF8ull) return limg_hip_error_InvalidParameter;
+    bool full = true;
+    for (size_t i = 0; i < count; i++)
+    {
+      if (!ppIn[i]) return limg_hip_error_ArgumentNull;
+      const void *const *pp = reinterpret_cast<const void *const *>(&pInfos[i]);
+      for (int k = 8; k < 11; k++)
+        if (!pp[k]) return limg_hip_error_ArgumentNull;
+      int n32 = 0;
+      for (int k = 0; k < 8; k++) n32 += pp[k] != nullptr;
+      if (n32 != 0 && n32 != 8) return limg_hip_error_ArgumentNull;
+      full = full && n32 == 8;
+    }
+    const bool ragged = (sizeX % kBlock) != 0 || (sizeY % kBlock) != 0;
+    const size_t blocks = ((sizeX + kBlock - 1) / kBlock) * ((sizeY + kBlock - 1) / kBlock), strips = ((sizeX + kBlock * kStripBlocks - 1) / (kBlock * kStripBlocks)) * ((sizeY + kBlock - 1) / kBlock);
+    // per-block scratch of a launch pair is bounded (1 GiB of records): longer lists go in several launch pairs
+    size_t chunk = (size_t)(1ull << 30) / (blocks * sizeof(limg_hip_block_record));
+    if (chunk * strips > 0x7FFFFFFFull) chunk = 0x7FFFFFFFull / strips; // strip ids are 32 bits
+    if (chunk < 1) chunk = 1;
+    if (c->opt.test_batch_chunk > 0) chunk = (size_t)c->opt.test_batch_chunk;
+    const bool oneByOne = count == 1 || ragged || !full || c->opt.legacy_float_stage != 0 || c->forceSplit;
+    std::vector<ImageIO> table;
+    for (size_t i0 = 0; i0 < count;)
+    {
+      const size_t n = oneByOne ? 1 : (count - i0 < chunk ? count - i0 : chunk);
+      limg_hip_result r;
+      if (n == 1) r = encode_device(c, ppIn[i0], sizeX, sizeY, hasAlpha, &pInfos[i0], nullptr, errorFactor, poolThreads, fastBitCrushing, (hipStream_t)stream);
+      else
+      {
+        table.resize(n);
+        for (size_t i = 0; i < n; i++) { table[i].in = ppIn[i0 + i]; table[i].info = pInfos[i0 + i]; }
+        r = encode_device(c, ppIn[i0], sizeX, sizeY, hasAlpha, &pInfos[i0], nullptr, errorFactor, poolThreads, fastBitCrushing, (hipStream_t)stream, false, false, 0, nullptr, nullptr, 0,
+                          table.data(), n);
+      }
+      if (r != limg_hip_success) return r;
+      i0 += n;
+    }
+    return limg_hip_success;
   }
 
   limg_hip_result limg_hip_encode3d_chain_device(limg_hip_context *c, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, const limg_hip_encode3d_info *pInfo,

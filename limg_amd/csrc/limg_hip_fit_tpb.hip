@@ -56,13 +56,15 @@ namespace limg_hip
       uint32_t *s_px = s_pxAll[wave];
       const uint32_t unitsX = (p.blocksX + 63u) / 64u;
       const uint32_t unitId = blockIdx.x * kTpbWaves + wave;
-      if (unitId >= unitsX * p.blocksY) return; // whole wave; after the only barrier
-      const uint32_t unit = unitId % unitsX, by = unitId / unitsX;
+      if (unitId >= unitsX * p.blocksY * p.batchCount) return; // whole wave; after the only barrier
+      const uint32_t unit = unitId % unitsX, byS = unitId / unitsX; // byS: block row counted through all images of a batch (= row in the per-block scratch)
+      const uint32_t img = p.batchCount > 1 ? byS / p.blocksY : 0u, by = byS - img * p.blocksY;
+      const uint32_t *const pin = p.batchCount > 1 ? p.batch[img].in : p.io.in;
       const uint32_t bx0 = unit * 64u, x0 = bx0 * kBlock, y0 = by * kBlock;
       const uint32_t nBlocks = min(p.blocksX - bx0, 64u), widthPx = nBlocks * kBlock;
       if (p.zeroLookback)
       { // this wave's 64 blocks are two work strips of the persistent kernel: clear their look-back descriptors (and, once, the ticket) instead of a memset launch
-        if ((uint32_t)lane < 2u && unit * 2u + (uint32_t)lane < p.stripsX) p.desc[(size_t)by * p.stripsX + unit * 2u + (uint32_t)lane] = 0ull;
+        if ((uint32_t)lane < 2u && unit * 2u + (uint32_t)lane < p.stripsX) p.desc[(size_t)byS * p.stripsX + unit * 2u + (uint32_t)lane] = 0ull;
         if (unitId == 0 && lane < 4) p.ticket[lane] = 0u;
       }
 
@@ -75,7 +77,7 @@ namespace limg_hip
         for (int row = 0; row < 8; row++)
           for (uint32_t col = (uint32_t)lane * 4u; col < widthPx; col += 256u)
           {
-            const uint4 v = *reinterpret_cast<const uint4 *>(p.in + (size_t)(y0 + row) * p.sizeX + x0 + col);
+            const uint4 v = *reinterpret_cast<const uint4 *>(pin + (size_t)(y0 + row) * p.sizeX + x0 + col);
             *reinterpret_cast<uint4 *>(&s_px[(col >> 3) * kTpbStride + row * 8 + (col & 7u)]) = v;
           }
       }
@@ -83,12 +85,12 @@ namespace limg_hip
       {
         for (int row = 0; row < 8; row++)
           for (uint32_t col = (uint32_t)lane; col < widthPx; col += 64u)
-            s_px[(col >> 3) * kTpbStride + row * 8 + (col & 7u)] = p.in[(size_t)(y0 + row) * p.sizeX + x0 + col];
+            s_px[(col >> 3) * kTpbStride + row * 8 + (col & 7u)] = pin[(size_t)(y0 + row) * p.sizeX + x0 + col];
       }
       }
       wave_lds_fence();
       if ((uint32_t)lane >= nBlocks) return;
-      const uint32_t *my = DIRECT ? p.in + (size_t)y0 * p.sizeX + x0 + lane * 8 : s_px + lane * kTpbStride;
+      const uint32_t *my = DIRECT ? pin + (size_t)y0 * p.sizeX + x0 + lane * 8 : s_px + lane * kTpbStride;
       const uint32_t pitch = DIRECT ? p.sizeX : 8u;
 
       // ---- a4: channel sums (src/limg.cpp:466-497); two channels per 32-bit accumulator, 64 * 255 < 2^16 ----
@@ -271,15 +273,40 @@ namespace limg_hip
       }
 #pragma unroll
       for (int i = 0; i < 12; i++) words[4 + i] = (uint32_t)(uint16_t)rec[2 * i] | ((uint32_t)(uint16_t)rec[2 * i + 1] << 16);
-      uint4 *dst = reinterpret_cast<uint4 *>(p.records + (size_t)by * p.blocksX + bx0 + lane);
+      uint4 *dst = reinterpret_cast<uint4 *>(p.records + (size_t)byS * p.blocksX + bx0 + lane);
 #pragma unroll
       for (int i = 0; i < 4; i++) dst[i] = make_uint4(words[4 * i], words[4 * i + 1], words[4 * i + 2], words[4 * i + 3]);
     }
   }
 
+  namespace
+  {
+    // the image table of a batched encode travels to the device inside kernel arguments (copied at launch: no host buffer has to outlive the call, no blocking copy)
+    struct TableChunk { ImageIO e[32]; uint32_t n; };
+    static_assert(sizeof(TableChunk) <= 3584, "kernel-argument segment");
+    __global__ void k_set_batch_table(ImageIO *dst, const TableChunk chunk)
+    {
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(chunk.e);
+      uint32_t *out = reinterpret_cast<uint32_t *>(dst);
+      for (uint32_t i = threadIdx.x; i < chunk.n * (uint32_t)(sizeof(ImageIO) / 4); i += blockDim.x) out[i] = src[i];
+    }
+  }
+
+  void launch_set_batch_table(ImageIO *dTable, const ImageIO *hTable, size_t count, hipStream_t s)
+  {
+    for (size_t i0 = 0; i0 < count; i0 += 32)
+    {
+      TableChunk ch;
+      ch.n = (uint32_t)(count - i0 < 32 ? count - i0 : 32);
+      for (uint32_t i = 0; i < ch.n; i++) ch.e[i] = hTable[i0 + i];
+      for (uint32_t i = ch.n; i < 32; i++) ch.e[i] = ImageIO{};
+      hipLaunchKernelGGL(k_set_batch_table, dim3(1), dim3(256), 0, s, dTable + i0, ch);
+    }
+  }
+
   void launch_fit_tpb(const EncodeParams &p, int channels, hipStream_t s)
   {
-    const uint32_t units = ((p.blocksX + 63u) / 64u) * p.blocksY;
+    const uint32_t units = ((p.blocksX + 63u) / 64u) * p.blocksY * p.batchCount;
     const int v = (channels == 4 ? 4 : 0) | (p.floatFast ? 2 : 0) | (p.vecIn ? 1 : 0);
 #define LIMG_TPB_LAUNCH(CH, FAST, DIRECT) hipLaunchKernelGGL((k_fit_tpb<CH, FAST, DIRECT>), dim3((units + tpb_waves<DIRECT>() - 1) / tpb_waves<DIRECT>()), dim3(64 * tpb_waves<DIRECT>()), 0, s, p)
     switch (v)

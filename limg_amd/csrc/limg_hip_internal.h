@@ -16,10 +16,23 @@ namespace limg_hip
   constexpr int kStripBlocks = 32; // image blocks per workgroup ("work strip": 256 x 8 px)
   constexpr uint64_t kDitherSeed = 0xCA7F00D15BADF00DULL; // reference: src/limg.cpp:1893
 
+  // The caller's pointers of one image: input pixels and the 11 output planes.  A batched encode (limg_hip_encode3d_batch_device) holds one of these per image
+  // in a device table; the kernels read them with scalar loads where they use them.
+  struct ImageIO
+  {
+    const uint32_t *in;
+    limg_hip_encode3d_info info;
+  };
+
   // Everything one encode needs on the device.  Passed by value to the kernels.
   struct EncodeParams
   {
-    const uint32_t *in;
+    ImageIO io;              // image 0 (the only one of a single-image encode)
+    // batched encode: `batchCount` images of the same shape in ONE launch pair; image i = batch[i]; work strip ids, look-back descriptors and the per-block
+    // scratch (records, shift words) run image after image (image i owns strips [i * imageStrips, (i + 1) * imageStrips) and block rows [i * blocksY, ...));
+    // every image starts its own dither chain(s) (the reference's batch loop calls the encoder once per image: src/main.cpp:278-323)
+    const ImageIO *batch;
+    uint32_t batchCount, imageStrips;
     uint32_t sizeX, sizeY, blocksX, blocksY, stripsX;
     uint32_t maxPixel32;     // min(maxPixelBitCrushError, 2^32 - 1)
     uint64_t maxBlock;       // maxBlockBitCrushError
@@ -35,8 +48,7 @@ namespace limg_hip
     uint32_t *shifts;      // per block: sA | sB<<8 | sC<<16 | calls<<24
     uint32_t *stripCalls;  // per work strip: number of dither calls (blocksY * stripsX, raster order)
     uint32_t *stripBase;   // per work strip: index of its first dither call inside its chain (exclusive scan)
-    // pre-dither factor bytes live in the caller's factor planes between the two kernels
-    limg_hip_encode3d_info info;
+    // (split path: the pre-dither factor bytes live in the caller's factor planes between the two kernels)
     int32_t storePlanes;   // 0: _perf behaviour
     int32_t fullPlanes;    // 0: compact mode -- only the three factor planes (+ records / shift words) are written
     // dither noise: byte p of call k = low byte of the 16-bit lane the reference ANDs with ditherSize for pixel p
@@ -80,6 +92,7 @@ namespace limg_hip
     uint32_t *status; // bit 0: header mismatch, bit 1: inconsistent payload offsets
   };
 
+  void launch_set_batch_table(ImageIO *dTable, const ImageIO *hTable, size_t count, hipStream_t s);
   void launch_fit_tpb(const EncodeParams &p, int channels, hipStream_t s);
   void launch_fit_search(const EncodeParams &p, int channels, hipStream_t s);
   void launch_encode_persistent(const EncodeParams &p, int channels, int workgroups, hipStream_t s);

@@ -324,13 +324,13 @@ namespace limg_hip
 
     // the 7 block-uniform planes, straight from registers: 16 bytes per lane = four rows of 256 contiguous bytes (8 blocks x 8 px) per store instruction where
     // the rows allow it (p.vecPlanes: width a multiple of 4, 16-byte aligned planes), 4 bytes per lane = one row per instruction otherwise
-    template <class P>
-    __device__ __forceinline__ void phase_f_store_const(const P &p, const StripLds &L, uint32_t x0, uint32_t y0, uint32_t ry, int lane, int wave)
+    template <class P, class IO>
+    __device__ __forceinline__ void phase_f_store_const(const P &p, const IO &io, const StripLds &L, uint32_t x0, uint32_t y0, uint32_t ry, int lane, int wave)
     {
       const uint32_t wx0 = x0 + wave * 64;
       if (wx0 >= p.sizeX) return;
       const uint32_t ww = min(p.sizeX - wx0, 64u);
-      uint32_t *planes[7] = { p.info.pShiftABCX, p.info.pColAMin, p.info.pColAMax, p.info.pColBMin, p.info.pColBMax, p.info.pColCMin, p.info.pColCMax };
+      uint32_t *planes[7] = { io.info.pShiftABCX, io.info.pColAMin, io.info.pColAMax, io.info.pColBMin, io.info.pColBMax, io.info.pColCMin, io.info.pColCMax };
       if (p.vecPlanes)
       {
         const uint32_t col = ((uint32_t)lane & 15u) * 4u, rsub = (uint32_t)lane >> 4; // 16 lanes per row, 4 rows per instruction
@@ -363,8 +363,8 @@ namespace limg_hip
     }
 
     // dither + decode of the wave's 8 blocks into the per-wave staging areas, then the per-pixel planes' stores
-    template <int CH, class P>
-    __device__ __forceinline__ void phase_f_pixels(const P &p, const StripLds &L, uint32_t strip, uint32_t x0, uint32_t y0, uint32_t ry, int lane, int wave, int tid)
+    template <int CH, class P, class IO>
+    __device__ __forceinline__ void phase_f_pixels(const P &p, const IO &io, const StripLds &L, uint32_t strip, uint32_t x0, uint32_t y0, uint32_t ry, int lane, int wave, int tid)
     {
       uint32_t *dec = L.dec + wave * 512;
       uint8_t *out = L.out; // [3 planes][8 rows][256 px]: strip-wide rows, so that the stores below write whole 128-byte lines
@@ -465,12 +465,12 @@ namespace limg_hip
       {
         const uint32_t ww = min(p.sizeX - wx0, 64u);
         if ((uint32_t)lane < ww)
-          for (uint32_t row = 0; row < ry; row++) p.info.pDecoded[(size_t)(y0 + row) * p.sizeX + wx0 + lane] = dec[row * 64 + lane];
+          for (uint32_t row = 0; row < ry; row++) io.info.pDecoded[(size_t)(y0 + row) * p.sizeX + wx0 + lane] = dec[row * 64 + lane];
       }
       __syncthreads(); // the three factor planes are stored strip-wide: 16 bytes per lane, whole rows of 256 bytes
       {
         const uint32_t stripW = min(p.sizeX - x0, (uint32_t)(kStripBlocks * kBlock));
-        uint8_t *planes8[3] = { p.info.pFactorsA, p.info.pFactorsB, p.info.pFactorsC };
+        uint8_t *planes8[3] = { io.info.pFactorsA, io.info.pFactorsB, io.info.pFactorsC };
         if (p.vecFactors)
         {
           for (int i = tid; i < 384; i += kThreads)
@@ -654,8 +654,11 @@ namespace limg_hip
     constexpr int kParkFac = 0, kParkRec = 6144, kParkShift = 6144 + 1536, kParkBytes = 8192;
 
     // PREFIT: the float stage already ran in k_fit_tpb (limg_hip_fit_tpb.hip, one lane per block); this step loads the records and goes on with phase E.
-    template <int CH, bool PERSIST, bool FAST, bool PREFIT, class P>
-    __device__ __forceinline__ void fit_search_strip(const P &p, const uint32_t id, uint8_t *lds, uint8_t *park, const int tid)
+    // id: the strip's number in ticket / look-back order (all images of a batch); local: its number inside its image (geometry); rowBase: the image's first
+    // block row in the per-block scratch arrays; head0: the id of the image's first strip
+    template <int CH, bool PERSIST, bool FAST, bool PREFIT, class P, class IO>
+    __device__ __forceinline__ void fit_search_strip(const P &p, const IO &io, const uint32_t id, const uint32_t local, const uint32_t rowBase, const uint32_t head0, uint8_t *lds,
+                                                     uint8_t *park, const int tid)
     {
       // the 4 KiB RSQRTPS table is read straight from global memory (it lives in the CU's vector L1): keeping a copy in LDS would
       // cost the fifth workgroup per CU
@@ -668,7 +671,8 @@ namespace limg_hip
       int *s_trialc = reinterpret_cast<int *>(lds + LL.trialc);
 
       const int lane = tid & 63, wave = tid >> 6;
-      const uint32_t strip = id % p.stripsX, by = id / p.stripsX;
+      const uint32_t strip = local % p.stripsX, by = local / p.stripsX;
+      const uint32_t byS = rowBase + by; // block row in the per-block scratch arrays (records, shift words)
       const uint32_t x0 = strip * (kStripBlocks * kBlock), y0 = by * kBlock;
       const uint32_t stripW = min(p.sizeX - x0, (uint32_t)(kStripBlocks * kBlock)); // pixels
       const uint32_t ry = min(p.sizeY - y0, (uint32_t)kBlock);
@@ -682,7 +686,7 @@ namespace limg_hip
           const uint32_t row = pass * 4 + (tid >> 6), col = (tid & 63) * 4; // 4 px per lane
           if (row < ry && col < stripW)
           {
-            const uint4 v = *reinterpret_cast<const uint4 *>(p.in + (size_t)(y0 + row) * p.sizeX + x0 + col);
+            const uint4 v = *reinterpret_cast<const uint4 *>(io.in + (size_t)(y0 + row) * p.sizeX + x0 + col);
             *reinterpret_cast<uint4 *>(&s_strip[row * kRowDw + col]) = v;
           }
         }
@@ -692,7 +696,7 @@ namespace limg_hip
         for (uint32_t i = tid; i < 8 * 256; i += kThreads)
         {
           const uint32_t row = i >> 8, col = i & 255;
-          if (row < ry && col < stripW) s_strip[row * kRowDw + col] = p.in[(size_t)(y0 + row) * p.sizeX + x0 + col];
+          if (row < ry && col < stripW) s_strip[row * kRowDw + col] = io.in[(size_t)(y0 + row) * p.sizeX + x0 + col];
         }
       }
       __syncthreads();
@@ -719,7 +723,7 @@ namespace limg_hip
           const int b = r * 4 + (lane >> 4), w = lane & 15;
           const uint32_t sb = wave * kBlocksPerWave + b, bx = strip * kStripBlocks + sb;
           uint32_t val = 0;
-          if (bx < p.blocksX) val = reinterpret_cast<const uint32_t *>(p.records + (size_t)by * p.blocksX + bx)[w];
+          if (bx < p.blocksX) val = reinterpret_cast<const uint32_t *>(p.records + (size_t)byS * p.blocksX + bx)[w];
           if (w >= 4)
           {
             reinterpret_cast<uint32_t *>(blk[b].rec)[w - 4] = val;
@@ -783,7 +787,7 @@ namespace limg_hip
             const uint32_t pbx = bxx > 0 ? bxx - 1 : p.blocksX - 1, pby = bxx > 0 ? by : by - 1;
             const uint32_t prx = min(p.sizeX - pbx * kBlock, (uint32_t)kBlock);
             const uint32_t row = (uint32_t)lane / prx, col = (uint32_t)lane - row * prx; // gather index -> position inside the previous block
-            pxs = p.in[(size_t)(pby * kBlock + row) * p.sizeX + pbx * kBlock + col];
+            pxs = io.in[(size_t)(pby * kBlock + row) * p.sizeX + pbx * kBlock + col];
           }
         }
         const uint32_t s02 = wave_sum(pxs & 0x00FF00FFu), s13 = wave_sum((pxs >> 8) & 0x00FF00FFu);
@@ -966,7 +970,7 @@ namespace limg_hip
           const int b = r * 4 + (lane >> 4), w = lane & 15;
           const uint32_t sb = wave * kBlocksPerWave + b, bx = strip * kStripBlocks + sb;
           const uint32_t val = w < 4 ? __float_as_uint(blk[b].avg[slot_of(w)]) : reinterpret_cast<const uint32_t *>(blk[b].rec)[w - 4];
-          if (bx < p.blocksX && (!PERSIST || p.compactOut)) reinterpret_cast<uint32_t *>(p.records + (size_t)by * p.blocksX + bx)[w] = val;
+          if (bx < p.blocksX && (!PERSIST || p.compactOut)) reinterpret_cast<uint32_t *>(p.records + (size_t)byS * p.blocksX + bx)[w] = val;
           if (PERSIST && w >= 4) reinterpret_cast<uint32_t *>(park + kParkRec)[sb * 12 + (w - 4)] = val;
         }
       }
@@ -1137,7 +1141,7 @@ namespace limg_hip
         const uint32_t calls = (((shift[0] & 7u) + 7u) >> 3) + (((shift[1] & 7u) + 7u) >> 3) + (((shift[2] & 7u) + 7u) >> 3);
         waveCalls += calls;
 
-        const size_t bi = (size_t)by * p.blocksX + bx;
+        const size_t bi = (size_t)byS * p.blocksX + bx;
         const uint32_t word = shift[0] | (shift[1] << 8) | (shift[2] << 16) | (calls << 24);
         if (lane == 0)
         {
@@ -1158,12 +1162,12 @@ namespace limg_hip
         const uint32_t agg = s_calls[0] + s_calls[1] + s_calls[2] + s_calls[3];
         if (PERSIST)
         { // publish the count; if the predecessor's inclusive count is already there, publish ours as inclusive right away
-          uint32_t headId = 0;
+          uint32_t headId = head0;
           if (p.chainCount > 1 && p.chainRows != 0)
           {
             uint32_t c = by / p.chainRows;
             c = c < p.chainCount - 1 ? c : p.chainCount - 1;
-            headId = c * p.chainRows * p.stripsX;
+            headId = head0 + c * p.chainRows * p.stripsX;
           }
           if (id == headId) desc_store(p.desc + id, kDescInclusive, agg);
           else
@@ -1184,7 +1188,7 @@ namespace limg_hip
       // ---- pre-dither factor bytes -> the caller's factor planes (rewritten in place by k_dither_store) -------------
       if (p.storePlanes)
       {
-        uint8_t *planes[3] = { p.info.pFactorsA, p.info.pFactorsB, p.info.pFactorsC };
+        uint8_t *planes[3] = { io.info.pFactorsA, io.info.pFactorsB, io.info.pFactorsC };
         if (p.vecFactors)
         {
           for (int i = tid; i < 384; i += kThreads)
@@ -1261,17 +1265,19 @@ namespace limg_hip
     // PERSIST == true : from the look-back over the descriptors, and the strip's inclusive count is published first thing.
     static_assert(kPhaseFBytes + kStripBlocks * 48 <= kLdsTotal - kLdsStrip - 16, "the F step's LDS overlays the E step's");
 
-    template <int CH, bool PERSIST, class P>
-    __device__ __forceinline__ void dither_store_strip(const P &p, const uint32_t id, uint8_t *fbase, const uint8_t *park, const int tid)
+    template <int CH, bool PERSIST, class P, class IO>
+    __device__ __forceinline__ void dither_store_strip(const P &p, const IO &io, const uint32_t id, const uint32_t local, const uint32_t rowBase, const uint32_t head0, uint8_t *fbase,
+                                                       const uint8_t *park, const int tid)
     {
       int16_t *s_rec = reinterpret_cast<int16_t *>(fbase + kPhaseFBytes); // [32][24]
       const int lane = tid & 63, wave = tid >> 6;
-      const uint32_t strip = id % p.stripsX, by = id / p.stripsX;
+      const uint32_t strip = local % p.stripsX, by = local / p.stripsX;
+      const uint32_t byS = rowBase + by;
       const uint32_t x0 = strip * (kStripBlocks * kBlock), y0 = by * kBlock;
       const uint32_t stripW = min(p.sizeX - x0, (uint32_t)(kStripBlocks * kBlock));
       const uint32_t ry = min(p.sizeY - y0, (uint32_t)kBlock);
       const uint32_t nBlocks = min(p.blocksX - strip * kStripBlocks, (uint32_t)kStripBlocks);
-      const uint8_t *planesIn[3] = { p.info.pFactorsA, p.info.pFactorsB, p.info.pFactorsC };
+      const uint8_t *planesIn[3] = { io.info.pFactorsA, io.info.pFactorsB, io.info.pFactorsC };
       const StripLds L = carve_phase_f(fbase, s_rec, 24);
 
       if (PERSIST)
@@ -1304,26 +1310,26 @@ namespace limg_hip
         {
           const int sb = i / 12, w = i - sb * 12;
           uint32_t v = 0;
-          if ((uint32_t)sb < nBlocks) v = reinterpret_cast<const uint32_t *>(p.records + (size_t)by * p.blocksX + strip * kStripBlocks + sb)[4 + w];
+          if ((uint32_t)sb < nBlocks) v = reinterpret_cast<const uint32_t *>(p.records + (size_t)byS * p.blocksX + strip * kStripBlocks + sb)[4 + w];
           reinterpret_cast<uint32_t *>(s_rec + sb * 24)[w] = v;
         }
-        if (tid < kStripBlocks) L.shift[tid] = (uint32_t)tid < nBlocks ? p.shifts[(size_t)by * p.blocksX + strip * kStripBlocks + tid] : 0u;
+        if (tid < kStripBlocks) L.shift[tid] = (uint32_t)tid < nBlocks ? p.shifts[(size_t)byS * p.blocksX + strip * kStripBlocks + tid] : 0u;
       }
       __syncthreads();
       phase_f_prepare<CH>(L, lane, wave);
       wave_lds_fence();
-      if (p.fullPlanes) phase_f_store_const(p, L, x0, y0, ry, lane, wave); // base-independent: 28 of the 35 output bytes per pixel
+      if (p.fullPlanes) phase_f_store_const(p, io, L, x0, y0, ry, lane, wave); // base-independent: 28 of the 35 output bytes per pixel
       if (wave == 0)
       {
         uint32_t base;
         if (PERSIST)
         {
-          uint32_t headId = 0;
+          uint32_t headId = head0;
           if (p.chainCount > 1 && p.chainRows != 0)
           {
             uint32_t c = by / p.chainRows;
             c = c < p.chainCount - 1 ? c : p.chainCount - 1;
-            headId = c * p.chainRows * p.stripsX;
+            headId = head0 + c * p.chainRows * p.stripsX;
           }
           const uint32_t w = lane < kStripBlocks ? L.shift[lane] : 0u;
           const uint32_t agg = wave_sum(w >> 24);
@@ -1343,7 +1349,7 @@ namespace limg_hip
         phase_f_first_calls(L, base, lane);
       }
       __syncthreads();
-      phase_f_pixels<CH>(p, L, strip, x0, y0, ry, lane, wave, tid);
+      phase_f_pixels<CH>(p, io, L, strip, x0, y0, ry, lane, wave, tid);
     }
 
     // ---- kernels ---------------------------------------------------------------------------------------------------------
@@ -1351,14 +1357,14 @@ namespace limg_hip
     __global__ __launch_bounds__(kThreads) void k_fit_search(const EncodeParams p)
     {
       __shared__ __attribute__((aligned(16))) uint8_t s_lds[lds_layout<PREFIT>().total];
-      fit_search_strip<CH, false, FAST, PREFIT>(p, blockIdx.x, s_lds, nullptr, (int)threadIdx.x);
+      fit_search_strip<CH, false, FAST, PREFIT>(p, p.io, blockIdx.x, blockIdx.x, 0u, 0u, s_lds, nullptr, (int)threadIdx.x);
     }
 
     template <int CH>
     __global__ __launch_bounds__(kThreads) void k_dither_store(const EncodeParams p)
     {
       __shared__ __attribute__((aligned(16))) uint8_t s_lds[kPhaseFBytes + kStripBlocks * 48];
-      dither_store_strip<CH, false>(p, blockIdx.x, s_lds, nullptr, (int)threadIdx.x);
+      dither_store_strip<CH, false>(p, p.io, blockIdx.x, blockIdx.x, 0u, 0u, s_lds, nullptr, (int)threadIdx.x);
     }
 
     // Both steps are inlined into the loop.  Left alone, LLVM hoists every lane-dependent address computation of both steps
@@ -1377,14 +1383,18 @@ namespace limg_hip
       __shared__ __attribute__((aligned(16))) uint8_t s_lds[lds_layout<PREFIT>().total];
       __shared__ uint32_t s_ticket;
       const int tid = (int)threadIdx.x;
-      const uint32_t S = p.stripsX * p.blocksY;
+      const uint32_t S = p.imageStrips * p.batchCount; // the strips of all images of a batch, image after image
       uint8_t *park = p.park + (size_t)blockIdx.x * 2 * kParkBytes;
-      uint32_t prev = 0xFFFFFFFFu, slot = 0;
+      uint32_t prev = 0xFFFFFFFFu, prevImg = 0, slot = 0;
       // The two steps read the parameters straight from the kernel-argument segment, through a pointer the compiler cannot see through from one step to the
       // next: a field is then fetched (one scalar load, scalar-cache hit) where a step uses it.  Read from `p`, all ~70 dwords are loaded once before the
       // loop and kept alive across it -- more SGPRs than there are, so the compiler parks them in VGPR lanes and pays a quarter-rate v_readlane per use.
       typedef const __attribute__((address_space(4))) EncodeParams KernArgs;
       KernArgs *const kargs = (KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+      // the caller's pointers of the image a strip belongs to: the kernel arguments themselves for a single image, an entry of the device table for a batch (same
+      // address space, same scalar loads).  The table was written by a copy that precedes this launch on the stream and is not modified while the kernel runs.
+      typedef const __attribute__((address_space(4))) ImageIO KernIO;
+      auto io_of = [](KernArgs *a, uint32_t img) -> KernIO * { return a->batchCount > 1 ? (KernIO *)a->batch + img : &a->io; };
       // All workgroups start their first E step together, so their first F steps (latency-bound, little vector work) coincide too, and it takes a few iterations
       // of data-dependent search lengths before the E and F steps of a CU's six workgroups interleave.  Workgroups are dealt out to the 256 CUs residency slot
       // by slot, so slot k (= blockIdx.x / 256) starts k * 3.4 us late: measured -0.5 % on the kernel, and harmless where the placement differs.
@@ -1395,12 +1405,18 @@ namespace limg_hip
         __syncthreads(); // the previous step's LDS use is over (and the rsqrt table is in place)
         if (tid == 0) s_ticket = atomicAdd(p.ticket, 1u);
         __syncthreads();
-        const uint32_t t = s_ticket;
+        const uint32_t t = (uint32_t)sgpr((int)s_ticket);
         int tid_e = tid;
         asm volatile("" : "+v"(tid_e));
         KernArgs *pe = kargs;
         asm volatile("" : "+s"(pe));
-        if (t < S) fit_search_strip<CH, true, FAST, PREFIT>(*pe, t, s_lds, park + slot * kParkBytes, tid_e);
+        uint32_t img = 0;
+        if (t < S)
+        {
+          if (pe->batchCount > 1) img = t / pe->imageStrips; // once per strip, on the scalar unit
+          const uint32_t head0 = img * pe->imageStrips;
+          fit_search_strip<CH, true, FAST, PREFIT>(*pe, *io_of(pe, img), t, t - head0, img * pe->blocksY, head0, s_lds, park + slot * kParkBytes, tid_e);
+        }
         if (prev != 0xFFFFFFFFu)
         {
           __syncthreads();
@@ -1411,11 +1427,12 @@ namespace limg_hip
           // The F step is latency-bound with little vector work, the E step is what keeps the vector unit busy: E-step waves get the issue priority (s_setprio),
           // F-step waves take the slots they leave.  Measured: -2.5 % on the kernel (the other way round: +0.8 %).
           __builtin_amdgcn_s_setprio(0);
-          dither_store_strip<CH, true>(*pf, prev, s_lds + kLdsStrip, park + (slot ^ 1u) * kParkBytes, tid_f);
+          const uint32_t head0 = prevImg * pf->imageStrips;
+          dither_store_strip<CH, true>(*pf, *io_of(pf, prevImg), prev, prev - head0, prevImg * pf->blocksY, head0, s_lds + kLdsStrip, park + (slot ^ 1u) * kParkBytes, tid_f);
           __builtin_amdgcn_s_setprio(LIMG_PRIO_E);
         }
         if (t >= S) break;
-        prev = t;
+        prev = t; prevImg = img;
         slot ^= 1u;
       }
     }
@@ -1447,7 +1464,7 @@ namespace limg_hip
 
   void launch_encode_persistent(const EncodeParams &p, int channels, int workgroups, hipStream_t s)
   {
-    const uint32_t strips = p.stripsX * p.blocksY;
+    const uint32_t strips = p.imageStrips * p.batchCount;
     const dim3 grid(strips < (uint32_t)workgroups ? strips : (uint32_t)workgroups), block(kThreads);
     LIMG_DISPATCH(k_encode_persistent, grid, block, s, p);
   }
