@@ -281,6 +281,8 @@ namespace
       for (int i = 1; i < 8; i++) bits |= (uintptr_t)pp[i]; // pShiftABCX .. pColCMax
       p.vecPlanes = (bits & 15u) == 0;
     }
+    p.vecFactors8 = dInfo && (sizeX % 8 == 0) && ((((uintptr_t)dInfo->pFactorsA) | ((uintptr_t)dInfo->pFactorsB) | ((uintptr_t)dInfo->pFactorsC)) & 7u) == 0;
+    p.vecDecoded = dInfo && fullPlanes && (sizeX % 4 == 0) && (((uintptr_t)dInfo->pDecoded) & 15u) == 0;
     p.vecFactors = dInfo && (sizeX % 16 == 0) && ((((uintptr_t)dInfo->pFactorsA) | ((uintptr_t)dInfo->pFactorsB) | ((uintptr_t)dInfo->pFactorsC)) & 15u) == 0;
     const int channels = hasAlpha ? 4 : 3;
     const bool ragged = (sizeX % kBlock) != 0 || (sizeY % kBlock) != 0;
@@ -293,6 +295,8 @@ namespace
         for (int k = 1; k < 8; k++) bits |= (uintptr_t)pp[k];
         p.vecPlanes = p.vecPlanes && (bits & 15u) == 0;
         p.vecIn = p.vecIn && (((uintptr_t)batch[i].in) & 15u) == 0;
+        p.vecDecoded = p.vecDecoded && (((uintptr_t)batch[i].info.pDecoded) & 15u) == 0;
+        p.vecFactors8 = p.vecFactors8 && ((((uintptr_t)batch[i].info.pFactorsA) | ((uintptr_t)batch[i].info.pFactorsB) | ((uintptr_t)batch[i].info.pFactorsC)) & 7u) == 0;
         p.vecFactors = p.vecFactors && ((((uintptr_t)batch[i].info.pFactorsA) | ((uintptr_t)batch[i].info.pFactorsB) | ((uintptr_t)batch[i].info.pFactorsC)) & 15u) == 0;
       }
       if ((r = c->batchTable.ensure(batchCount * sizeof(ImageIO))) != limg_hip_success) return r;

@@ -70,6 +70,8 @@ namespace limg_hip
     int32_t vecIn;      // rows of pIn may be read 16 bytes per lane (sizeX % 4 == 0 and pIn 16-byte aligned); otherwise dword loads
     int32_t vecPlanes;  // the seven block-uniform uint32 planes may be stored 16 bytes per lane (sizeX % 4 == 0 and all seven 16-byte aligned)
     int32_t vecFactors; // the three factor planes may be accessed 16 bytes per lane (sizeX % 16 == 0 and all three 16-byte aligned)
+    int32_t vecFactors8; // ... 8 bytes per lane (sizeX % 8 == 0 and all three 8-byte aligned)
+    int32_t vecDecoded; // pDecoded may be stored 16 bytes per lane (sizeX % 4 == 0 and 16-byte aligned)
   };
 
   // stream pack (limg_hip_stream.hip): from the compact outputs of an encode (factor planes, records, shift words)

@@ -32,6 +32,8 @@
 #include "limg_hip_device.h"
 #include "limg_search_table.h"
 
+#include <type_traits>
+
 namespace limg_hip
 {
   namespace
@@ -239,39 +241,49 @@ namespace limg_hip
     // phase F / kernel 3: dither (a13), plane stores (a15), decode (a16) for one work strip
     // =====================================================================================================================
 
+    // The strip's factor bytes in LDS (written by the E step lane == pixel, read by the F step lane == (block, row) 8 bytes at a time): [3 planes][8 rows] of
+    // 256 bytes at a row stride of 320 -- 80 dwords = 16 mod 64 banks, so the 32 lanes (4 rows x 8 blocks) that a ds_read_b64 serves at a time hit 64 distinct banks
+    // (at a stride of 256 all rows of a block share two banks).
+    constexpr int kFacRow = 320, kFacPlane = 8 * kFacRow, kFacBytes = 3 * kFacPlane;
+
     // LDS areas of phase F.  In the fused kernel they overlay the (then dead) parked-contribution area of k_fit_search.
     struct StripLds
     {
-      uint8_t *fac;    // [3][8][256]  pre-dither factor bytes of the strip (plane-row layout)
+      uint8_t *fac;    // [3][8][kFacRow]  pre-dither factor bytes of the strip (plane-row layout)
       uint32_t *dec;   // [4 waves][8 rows][64]  decoded pixels
       uint8_t *out;    // == fac: a lane's output byte replaces the pre-dither byte it has just read (same index)
       uint32_t *cst;   // [7][32][4]  per-block constants of the 7 block-uniform planes, each four times over: a 16-byte store takes it from one ds_read_b128
       int32_t *nm;     // [32 blocks][2][3][4]  effective integer normals / additive constants of the decode
       uint32_t *shift; // [32]  shift words
       uint32_t *first; // [32]  first dither-call index of each block
+      uint32_t *flags; // [32]  bit 0: some record value beyond p.recordLimit (generic 32-bit decode), bit 1: the alpha lane varies inside the block; bits 8..15: its value when it does not
       const int16_t *rec; // record of block sb at rec + sb * recStride
       int recStride;
     };
-    constexpr int kPhaseFBytes = 6144 + 8192 + 3584 + 3072 + 128 + 128; // the output factor bytes replace the pre-dither ones in place
+    constexpr int kPhaseFBytes = kFacBytes + 8192 + 3584 + 3072 + 128 + 128 + 128; // the output factor bytes replace the pre-dither ones in place
 
     __device__ __forceinline__ StripLds carve_phase_f(uint8_t *base, const int16_t *rec, int recStride)
     {
       StripLds L;
       L.fac = base;
-      L.dec = reinterpret_cast<uint32_t *>(base + 6144);
+      L.dec = reinterpret_cast<uint32_t *>(base + kFacBytes);
       L.out = base;
-      L.cst = reinterpret_cast<uint32_t *>(base + 6144 + 8192);
-      L.nm = reinterpret_cast<int32_t *>(base + 6144 + 8192 + 3584);
-      L.shift = reinterpret_cast<uint32_t *>(base + 6144 + 8192 + 3584 + 3072);
+      L.cst = reinterpret_cast<uint32_t *>(base + kFacBytes + 8192);
+      L.nm = reinterpret_cast<int32_t *>(base + kFacBytes + 8192 + 3584);
+      L.shift = reinterpret_cast<uint32_t *>(base + kFacBytes + 8192 + 3584 + 3072);
       L.first = L.shift + 32;
+      L.flags = L.shift + 64;
       L.rec = rec; L.recStride = recStride;
       return L;
     }
 
     // Per-wave preparation from records + shifts (lane-parallel over the wave's 8 blocks): the 7 block-uniform plane values
     // (src/limg.cpp:2006-2036) and the effective decode constants (src/limg_decode.h:139-196 / :40-101).
+    // The decode's additive constants of the R and G lanes carry the packed form's biases (term_bias: 0x3000, 0x3000, 0x2000 -- they sum to 0x8000): see phase_f_rows.
+    __device__ __forceinline__ constexpr int decode_bias(int factor, int c) { return c < 2 ? (term_bias(factor) << 8) : 0; }
+
     template <int CH>
-    __device__ __forceinline__ void phase_f_prepare(const StripLds &L, int lane, int wave)
+    __device__ __forceinline__ void phase_f_prepare(const StripLds &L, int lane, int wave, int recordLimit)
     {
       if (lane < 56)
       {
@@ -317,8 +329,26 @@ namespace limg_hip
           else if (CH == 3) { n = 0; m = 0xFFFF; }
           int *dst = L.nm + sb * 24;
           dst[f * 4 + c] = n;
-          dst[12 + f * 4 + c] = (int)(((uint32_t)m << 8) + 128u);
+          dst[12 + f * 4 + c] = (int)(((uint32_t)m << 8) + 128u + (uint32_t)(c < 2 ? (f == 2 ? 0x200000 : 0x300000) : 0)); // + decode_bias(f, c)
         }
+      }
+      if (lane < kBlocksPerWave)
+      { // per-block flags of the decode: records beyond the packed form's range (never from a fit of byte pixels), and whether the alpha lane is one value for the block
+        const int sb = wave * kBlocksPerWave + lane;
+        const int16_t *rec = L.rec + sb * L.recStride;
+        uint32_t big = 0;
+#pragma unroll
+        for (int i = 0; i < 24; i++) { const int v = rec[i]; big |= (v > recordLimit || v < -recordLimit) ? 1u : 0u; }
+        uint32_t fl = big;
+        if (CH == 3) fl |= 255u << 8; // src/limg_decode.h:95-97: the three 0xFFFF minima clamp to 255
+        else
+        {
+          const bool varies = rec[7] != rec[3] || rec[15] != rec[11] || rec[23] != rec[19]; // an alpha normal (max - min) is never zeroed, not even at shift 8
+          int a = rec[3] + rec[11] + rec[19]; // ((m << 8) + 128) >> 8 == m for each of the three terms
+          a = a < 0 ? 0 : (a > 255 ? 255 : a);
+          fl |= varies ? 2u : ((uint32_t)a << 8);
+        }
+        L.flags[sb] = fl;
       }
     }
 
@@ -360,6 +390,226 @@ namespace limg_hip
 #pragma unroll
           for (int k = 0; k < 7; k++) planes[k][g] = cst[k];
         }
+    }
+
+    // ---- phase F for strips of whole 8x8 blocks: lane == (block j of the wave's 8, row r), 8 pixels per lane ------------------------------------------------
+    // With lane == pixel (phase_f_pixels below, which strips with partial blocks keep) everything per block is scalar work -- shift fields, dither on / off
+    // branches, multipliers: ~50 scalar instructions a block on a scalar unit the search already loads -- every plane goes through LDS staging to reach
+    // 16-byte stores, and the decode runs unpacked.  Here a lane owns one row of one block:
+    //  * its per-block values (shifts, multipliers, dither masks, decode constants) are ordinary per-lane registers: no scalar code at all;
+    //  * its 8 pixels leave as two 16-byte stores (pDecoded) and three 8-byte stores (factor planes) straight from registers; the inputs are three 8-byte
+    //    LDS reads (pre-dither factor bytes) and up to three 8-byte loads of the noise stream;
+    //  * byte lanes are addressed by SDWA operand selects: one v_add_u32_sdwa adds byte i of the factor dword and byte i of the (pre-masked) noise dword, one
+    //    v_and_b32_sdwa with dst_sel:BYTE_i inserts the crushed byte (clamped value with the dropped bits cleared == (v >> s) << s) into the output dword;
+    //  * the decode (a16, src/limg_decode.h:137-236) takes the trial's packed form: per factor three 24-bit multiply-adds, the R and G terms packed into one
+    //    register by one v_perm_b32 (both >> 8 included), biased so that a plain v_add3_u32 sums the halves independently (0x3000 + 0x3000 + 0x2000 = 0x8000: the sum is
+    //    the estimate in offset binary, clamped by unsigned packed max / min against 0x8000 / 0x80FF, and its low byte IS the clamped estimate); the alpha lane is one
+    //    value per block unless its normals are non-zero (wave-uniform test).  Valid for record values up to p.recordLimit like the trial; beyond (never from a fit
+    //    of byte pixels) the wave takes the plain 32-bit form.
+    template <int B> __device__ __forceinline__ uint32_t add_byte_sdwa(uint32_t a, uint32_t b)
+    {
+      uint32_t r;
+      if (B == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(r) : "v"(a), "v"(b));
+      else if (B == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(r) : "v"(a), "v"(b));
+      else if (B == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2" : "=v"(r) : "v"(a), "v"(b));
+      else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3" : "=v"(r) : "v"(a), "v"(b));
+      return r;
+    }
+    // acc.byte[B] = (a & b) & 0xFF, the other bytes of acc kept
+    template <int B> __device__ __forceinline__ void and_into_byte_sdwa(uint32_t &acc, uint32_t a, uint32_t b)
+    {
+      if (B == 0) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(acc) : "v"(a), "v"(b));
+      else if (B == 1) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(acc) : "v"(a), "v"(b));
+      else if (B == 2) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(acc) : "v"(a), "v"(b));
+      else asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(acc) : "v"(a), "v"(b));
+    }
+
+    // One factor of the lane's 8 pixels: dither, crushed output bytes (stored by the caller), and the factor's terms of the decode added to the accumulators
+    // (first factor: assigned).  accRG: R and G terms packed and biased, accB: B terms, accA: alpha terms (only when the wave has a block whose alpha varies).
+    template <int K, bool ALPHA>
+    __device__ __forceinline__ void rows_factor(const uint2 fac, const uint2 nzm, const uint32_t negHalf, const uint32_t shr, const uint32_t mul, const uint32_t keep, const int4 n,
+                                                const int4 m, uint32_t accRG[8], int accB[8], int accA[8], uint32_t &outLo, uint32_t &outHi)
+    {
+      outLo = 0; outHi = 0;
+      auto pixel = [&](auto BI, auto HI)
+      {
+        constexpr int B = decltype(BI)::value, H = decltype(HI)::value, I = H * 4 + B;
+        // src/limg.cpp:824-879 per byte: v = clamp(f + (noise & ditherSize) - ditherOffset, 0, 255) >> shift; a factor that does not dither has mask 0, offset 0, shift 0
+        const uint32_t t = (uint32_t)med3_i32((int)(add_byte_sdwa<B>(H ? fac.y : fac.x, H ? nzm.y : nzm.x) + negHalf), 0, 255);
+        and_into_byte_sdwa<B>(H ? outHi : outLo, t, keep); // (v >> s) << s: what the factor plane holds (src/limg.cpp:2054-2062; shift 8 => 0)
+        const int d = (int)mul_u24(t >> shr, mul);          // a16: dec = v * mul (the raw byte at shift 8)
+        const int t0 = mad_i24(d, n.x, m.x), t1 = mad_i24(d, n.y, m.y), t2 = mad_i24(d, n.z, m.z);
+        const uint32_t rg = __builtin_amdgcn_perm((uint32_t)t1, (uint32_t)t0, 0x06050201u);
+        if (K == 0) { accRG[I] = rg; accB[I] = t2 >> 8; }
+        else { accRG[I] += rg; accB[I] += t2 >> 8; }
+        if (ALPHA)
+        {
+          const int ta = mad_i24(d, n.w, m.w) >> 8;
+          if (K == 0) accA[I] = ta; else accA[I] += ta;
+          asm volatile("" : "+v"(accA[I]));
+        }
+        // the accumulators are materialised here: otherwise the packing of this factor's terms sinks to their next use (the next factor's adds) and every pixel's three
+        // products stay live until then
+        asm volatile("" : "+v"(accRG[I]), "+v"(accB[I]));
+      };
+      // two pixels at a time (the scheduler would otherwise run all eight pixels' multiply-adds ahead of their packing: 24 temporaries)
+      pixel(std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
+      pixel(std::integral_constant<int, 1>(), std::integral_constant<int, 0>());
+      __builtin_amdgcn_sched_barrier(0);
+      pixel(std::integral_constant<int, 2>(), std::integral_constant<int, 0>());
+      pixel(std::integral_constant<int, 3>(), std::integral_constant<int, 0>());
+      __builtin_amdgcn_sched_barrier(0);
+      pixel(std::integral_constant<int, 0>(), std::integral_constant<int, 1>());
+      pixel(std::integral_constant<int, 1>(), std::integral_constant<int, 1>());
+      __builtin_amdgcn_sched_barrier(0);
+      pixel(std::integral_constant<int, 2>(), std::integral_constant<int, 1>());
+      pixel(std::integral_constant<int, 3>(), std::integral_constant<int, 1>());
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    template <int CH, class P, class IO>
+    __device__ __forceinline__ void phase_f_rows(const P &p, const IO &io, const StripLds &L, const uint32_t strip, const uint32_t x0, const uint32_t y0, const int lane, const int wave)
+    {
+      const uint32_t j = (uint32_t)lane & 7u, r = (uint32_t)lane >> 3;
+      const uint32_t sb = (uint32_t)wave * kBlocksPerWave + j, bx = strip * kStripBlocks + sb;
+      const bool valid = bx < p.blocksX;
+      const uint32_t w = L.shift[sb], fl = L.flags[sb]; // (shift word 0 for blocks past the right edge)
+      uint32_t call = L.first[sb];
+      const size_t g = (size_t)(y0 + r) * p.sizeX + x0 + sb * kBlock; // the lane's 8 pixels in every plane
+      // the noise bytes of the lane's row for every factor that dithers: requested first, used factor by factor
+      uint2 nz[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+      {
+        const uint32_t s = (w >> (8 * k)) & 0xFFu;
+        nz[k] = make_uint2(0u, 0u);
+        if (((s - 1u) < 7u) && valid) // shifts 1..7 dither (src/limg.cpp:1951-1958)
+        {
+          nz[k] = *reinterpret_cast<const uint2 *>(p.noise + (size_t)call * 64 + r * 8);
+          call++;
+        }
+      }
+      const uint8_t *facRow = L.fac + r * kFacRow + sb * kBlock;
+      const int *nm = L.nm + sb * 24;
+#ifdef LIMG_X_NOGEN
+      const bool generic = false;
+#else
+      const bool generic = __builtin_amdgcn_ballot_w64((fl & 1u) != 0u) != 0ull;   // wave-uniform
+#endif
+#ifdef LIMG_X_NOALPHA
+      const bool anyAlpha = false;
+#else
+      const bool anyAlpha = CH == 4 && __builtin_amdgcn_ballot_w64((fl & 2u) != 0u) != 0ull;
+#endif
+      const bool rawEscape = !p.fullPlanes && p.streamRaw; // compact stream: a factor at shift 8 keeps its raw byte (raw-escape of the container)
+      // per-lane constants of factor k from its shift s: the shift the dither applies (0 unless 1..7), minus half the dither range, the re-expansion multiplier
+      // (1 << s) + decode_bias(s) with decode_bias = {0,0,0,0,1,4,21,127,0} = byte s of a constant pair (selector 8: a zero sign fill), the bits the crushed byte keeps
+      auto consts = [&](int k, uint32_t &negHalf, uint32_t &shr, uint32_t &mul, uint32_t &keep, uint2 &fq, uint2 &nzm)
+      {
+        const uint32_t s = (w >> (8 * k)) & 0xFFu;
+        shr = (((s - 1u) < 7u) && valid) ? s : 0u;
+        negHalf = 0u - ((1u << shr) >> 1);
+        mul = (1u << s) + __builtin_amdgcn_perm(0x7F150401u, 0u, s);
+        keep = (0xFFu << s) & 0xFFu;
+        if (rawEscape && s == 8) keep = 0xFFu;
+        fq = *reinterpret_cast<const uint2 *>(facRow + k * kFacPlane);
+        const uint32_t m4 = __builtin_amdgcn_perm(0u, (1u << shr) - 1u, 0u); // noise & ditherSize for four pixels at a time: the mask's byte in all four lanes
+        nzm = make_uint2(nz[k].x & m4, nz[k].y & m4);
+      };
+      uint8_t *planes8[3] = { io.info.pFactorsA, io.info.pFactorsB, io.info.pFactorsC };
+      auto store_factor = [&](int k, uint32_t lo, uint32_t hi)
+      {
+        if (!valid) return;
+        if (p.vecFactors8) *reinterpret_cast<uint2 *>(planes8[k] + g) = make_uint2(lo, hi);
+        else
+        {
+#pragma unroll
+          for (int i = 0; i < 4; i++) { planes8[k][g + i] = (uint8_t)(lo >> (8 * i)); planes8[k][g + 4 + i] = (uint8_t)(hi >> (8 * i)); }
+        }
+      };
+      uint32_t px[8];
+      if (!generic)
+      {
+        uint32_t accRG[8], lo, hi, negHalf, shr, mul, keep;
+        int accB[8], accA[8];
+        uint2 fq, nzm;
+        // (scheduling barriers: left alone the compiler interleaves the three factors and keeps everything live at once -- 113 VGPRs, where 80 are allowed)
+#define LIMG_ROWS_FACTOR(K, ALPHA)                                                                                                                         \
+        consts(K, negHalf, shr, mul, keep, fq, nzm);                                                                                                      \
+        rows_factor<K, ALPHA>(fq, nzm, negHalf, shr, mul, keep, *reinterpret_cast<const int4 *>(nm + 4 * K), *reinterpret_cast<const int4 *>(nm + 12 + 4 * K), accRG, accB, accA, lo, hi); \
+        store_factor(K, lo, hi);                                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0)
+        if (anyAlpha)
+        { // some block of this wave has a varying alpha lane (its normals are live even at shift 8)
+          LIMG_ROWS_FACTOR(0, true); LIMG_ROWS_FACTOR(1, true); LIMG_ROWS_FACTOR(2, true);
+        }
+        else
+        {
+          LIMG_ROWS_FACTOR(0, false); LIMG_ROWS_FACTOR(1, false); LIMG_ROWS_FACTOR(2, false);
+        }
+#undef LIMG_ROWS_FACTOR
+        if (!p.fullPlanes) return;
+        const uint32_t alphaConst = fl & 0xFF00u;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+        {
+          ushort2_t e = __builtin_bit_cast(ushort2_t, accRG[i]); // estimate + 0x8000 in both halves
+          e = __builtin_elementwise_max(e, __builtin_bit_cast(ushort2_t, 0x80008000u));
+          e = __builtin_elementwise_min(e, __builtin_bit_cast(ushort2_t, 0x80FF80FFu));
+          uint32_t ba = (uint32_t)med3_i32(accB[i], 0, 255);
+          if (anyAlpha) ba |= (uint32_t)med3_i32(accA[i], 0, 255) << 8;
+          else ba |= alphaConst;
+          px[i] = __builtin_amdgcn_perm(ba, __builtin_bit_cast(uint32_t, e), 0x05040200u); // R = low byte of the low half, G = low byte of the high half, B, A
+        }
+      }
+      else
+      { // a record value beyond the packed form's range somewhere in this wave (never from a fit of byte pixels): any int16 record, 32-bit terms, the low 32 bits of
+        // the products like PMULLD (the form of phase_f_pixels).  A rolled loop, one pixel at a time, constants re-read from LDS: this path must not set the
+        // kernel's register count.
+        uint32_t outLo[3] = { 0, 0, 0 }, outHi[3] = { 0, 0, 0 };
+#pragma unroll 1
+        for (int i = 0; i < 8; i++)
+        {
+          const uint32_t bsh = 8u * ((uint32_t)i & 3u);
+          int d[3];
+#pragma unroll
+          for (int k = 0; k < 3; k++)
+          {
+            uint32_t negHalf, shr, mul, keep;
+            uint2 fq, nzm;
+            consts(k, negHalf, shr, mul, keep, fq, nzm);
+            const uint32_t fb = ((i < 4 ? fq.x : fq.y) >> bsh) & 0xFFu, nb = ((i < 4 ? nzm.x : nzm.y) >> bsh) & 0xFFu;
+            const uint32_t t = (uint32_t)med3_i32((int)(fb + nb + negHalf), 0, 255);
+            if (i < 4) outLo[k] |= (t & keep) << bsh; else outHi[k] |= (t & keep) << bsh;
+            d[k] = (int)mul_u24(t >> shr, mul);
+          }
+          uint32_t out = 0;
+#pragma unroll
+          for (int c = 0; c < 4; c++)
+          {
+            int est = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) est += mad_i24(d[k], nm[k * 4 + c], nm[12 + k * 4 + c] - decode_bias(k, c)) >> 8;
+            out |= (uint32_t)med3_i32(est, 0, 255) << (8 * c);
+          }
+          if (valid && p.fullPlanes) io.info.pDecoded[g + i] = out;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) store_factor(k, outLo[k], outHi[k]);
+        return;
+      }
+      if (!valid) return; // (strips of whole blocks: every row r < 8 exists)
+      uint32_t *dst = io.info.pDecoded + g;
+      if (p.vecDecoded)
+      {
+        reinterpret_cast<uint4 *>(dst)[0] = make_uint4(px[0], px[1], px[2], px[3]);
+        reinterpret_cast<uint4 *>(dst)[1] = make_uint4(px[4], px[5], px[6], px[7]);
+      }
+      else
+      {
+#pragma unroll
+        for (int i = 0; i < 8; i++) dst[i] = px[i];
+      }
     }
 
     // dither + decode of the wave's 8 blocks into the per-wave staging areas, then the per-pixel planes' stores
@@ -405,7 +655,7 @@ namespace limg_hip
         uint32_t lx, ly;
         if (rx == 8) { lx = lane & 7; ly = lane >> 3; }
         else { const uint32_t l = active ? (uint32_t)lane : 0u; ly = l / rx; lx = l - ly * rx; }
-        const uint32_t o = ly * 256 + sb * kBlock + lx;
+        const uint32_t o = ly * kFacRow + sb * kBlock + lx;
         const uint32_t w = (uint32_t)sgpr((int)L.shift[sb]);
         const uint32_t shift[3] = { w & 0xFF, (w >> 8) & 0xFF, (w >> 16) & 0xFF };
 
@@ -413,7 +663,7 @@ namespace limg_hip
 #pragma unroll
         for (int k = 0; k < 3; k++)
         {
-          uint32_t v = L.fac[k * 2048 + o];
+          uint32_t v = L.fac[k * kFacPlane + o];
           const uint32_t s = shift[k];
           if (s != 0 && s != 8)
           { // src/limg.cpp:824-879: (lane16 & ditherSize) - ditherOffset, add, clamp, shift
@@ -429,7 +679,7 @@ namespace limg_hip
           if (active)
           {
 #pragma unroll
-            for (int k = 0; k < 3; k++) out[k * 2048 + o] = (uint8_t)(f[k] << ((p.streamRaw && shift[k] == 8) ? 0u : shift[k]));
+            for (int k = 0; k < 3; k++) out[k * kFacPlane + o] = (uint8_t)(f[k] << ((p.streamRaw && shift[k] == 8) ? 0u : shift[k]));
           }
           continue;
         }
@@ -441,7 +691,8 @@ namespace limg_hip
         const int4 nA = *reinterpret_cast<const int4 *>(nm), nB = *reinterpret_cast<const int4 *>(nm + 4), nC = *reinterpret_cast<const int4 *>(nm + 8);
         const int4 mA = *reinterpret_cast<const int4 *>(nm + 12), mB = *reinterpret_cast<const int4 *>(nm + 16), mC = *reinterpret_cast<const int4 *>(nm + 20);
         const int nAa[4] = { nA.x, nA.y, nA.z, nA.w }, nBa[4] = { nB.x, nB.y, nB.z, nB.w }, nCa[4] = { nC.x, nC.y, nC.z, nC.w };
-        const int mAa[4] = { mA.x, mA.y, mA.z, mA.w }, mBa[4] = { mB.x, mB.y, mB.z, mB.w }, mCa[4] = { mC.x, mC.y, mC.z, mC.w };
+        const int mAa[4] = { mA.x - decode_bias(0, 0), mA.y - decode_bias(0, 1), mA.z, mA.w }, mBa[4] = { mB.x - decode_bias(1, 0), mB.y - decode_bias(1, 1), mB.z, mB.w },
+                  mCa[4] = { mC.x - decode_bias(2, 0), mC.y - decode_bias(2, 1), mC.z, mC.w }; // (this form is exact for any record: no bias)
 #pragma unroll
         for (int c = 0; c < 4; c++)
         {
@@ -454,7 +705,7 @@ namespace limg_hip
           const uint32_t wo = ly * 64 + b * kBlock + lx;
           dec[wo] = decoded;
 #pragma unroll
-          for (int k = 0; k < 3; k++) out[k * 2048 + o] = (uint8_t)(f[k] << shift[k]); // shift 8 => 0 (src/limg.cpp:2054-2062)
+          for (int k = 0; k < 3; k++) out[k * kFacPlane + o] = (uint8_t)(f[k] << shift[k]); // shift 8 => 0 (src/limg.cpp:2054-2062)
         }
       }
       } // noise groups
@@ -477,7 +728,7 @@ namespace limg_hip
           {
             const int pl = i >> 7, row = (i & 127) >> 4, col = (i & 15) * 16;
             if ((uint32_t)row < ry && (uint32_t)col < stripW)
-              *reinterpret_cast<uint4 *>(planes8[pl] + (size_t)(y0 + row) * p.sizeX + x0 + col) = *reinterpret_cast<const uint4 *>(out + pl * 2048 + row * 256 + col);
+              *reinterpret_cast<uint4 *>(planes8[pl] + (size_t)(y0 + row) * p.sizeX + x0 + col) = *reinterpret_cast<const uint4 *>(out + pl * kFacPlane + row * kFacRow + col);
           }
         }
         else
@@ -485,7 +736,7 @@ namespace limg_hip
           for (int i = tid; i < 3 * 2048; i += kThreads)
           {
             const int pl = i >> 11, row = (i & 2047) >> 8, col = i & 255;
-            if ((uint32_t)row < ry && (uint32_t)col < stripW) planes8[pl][(size_t)(y0 + row) * p.sizeX + x0 + col] = out[i];
+            if ((uint32_t)row < ry && (uint32_t)col < stripW) planes8[pl][(size_t)(y0 + row) * p.sizeX + x0 + col] = out[pl * kFacPlane + row * kFacRow + col];
           }
         }
       }
@@ -641,11 +892,11 @@ namespace limg_hip
     template <bool PREFIT> __device__ __host__ constexpr LdsLayout lds_layout()
     {
       if (!PREFIT) return LdsLayout{ kLdsV, kLdsBlk, kLdsCalls, kLdsV, kLdsTotal }; // (no trial-constant table in this layout)
-      const int v = kLdsStrip + 8 * kRowDw * 4, blk = v + 6144, calls = blk + kStripBlocks * 192, tc = calls + 32, e = tc + kStripBlocks * kTrialConstDw * 4;
+      const int v = kLdsStrip + 8 * kRowDw * 4, blk = v + kFacBytes, calls = blk + kStripBlocks * 192, tc = calls + 32, e = tc + kStripBlocks * kTrialConstDw * 4;
       const int f = kLdsStrip + kPhaseFBytes + kStripBlocks * 48 + 16; // the F step's overlay incl. its record copy
       return LdsLayout{ v, blk, calls, tc, e > f ? e : f };
     }
-    static_assert(lds_layout<true>().total <= 163840 / 7, "7 workgroups per CU with the float stage in its own kernel");
+    static_assert(lds_layout<true>().total <= 163840 / 6, "6 workgroups per CU with the float stage in its own kernel");
 
 
     // PERSIST == false: split path, the strip's call count goes to p.stripCalls for k_strip_scan.
@@ -1150,8 +1401,8 @@ namespace limg_hip
         }
         if (p.storePlanes && active)
         {
-          const uint32_t o = ly * 256 + sb * kBlock + lx;
-          stage[o] = (uint8_t)fA; stage[2048 + o] = (uint8_t)fB; stage[4096 + o] = (uint8_t)fC;
+          const uint32_t o = ly * kFacRow + sb * kBlock + lx;
+          stage[o] = (uint8_t)fA; stage[kFacPlane + o] = (uint8_t)fB; stage[2 * kFacPlane + o] = (uint8_t)fC;
         }
         sbNext = (uint32_t)sgpr((int)qv);
       }
@@ -1181,7 +1432,7 @@ namespace limg_hip
       }
       if (PERSIST)
       { // park the pre-dither factor bytes (private, L2-resident scratch; same workgroup reads them back)
-        for (int i = tid; i < 384; i += kThreads) reinterpret_cast<uint4 *>(park + kParkFac)[i] = reinterpret_cast<const uint4 *>(stage)[i];
+        for (int i = tid; i < 384; i += kThreads) reinterpret_cast<uint4 *>(park + kParkFac)[i] = *reinterpret_cast<const uint4 *>(stage + (i >> 4) * kFacRow + (i & 15) * 16); // 24 rows of 256 bytes
         return;
       }
 
@@ -1195,7 +1446,7 @@ namespace limg_hip
           {
             const int pl = i >> 7, row = (i & 127) >> 4, col = (i & 15) * 16;
             if ((uint32_t)row < ry && (uint32_t)col < stripW)
-              *reinterpret_cast<uint4 *>(planes[pl] + (size_t)(y0 + row) * p.sizeX + x0 + col) = *reinterpret_cast<const uint4 *>(stage + pl * 2048 + row * 256 + col);
+              *reinterpret_cast<uint4 *>(planes[pl] + (size_t)(y0 + row) * p.sizeX + x0 + col) = *reinterpret_cast<const uint4 *>(stage + pl * kFacPlane + row * kFacRow + col);
           }
         }
         else
@@ -1203,7 +1454,7 @@ namespace limg_hip
           for (int i = tid; i < 3 * 2048; i += kThreads)
           {
             const int pl = i >> 11, row = (i & 2047) >> 8, col = i & 255;
-            if ((uint32_t)row < ry && (uint32_t)col < stripW) planes[pl][(size_t)(y0 + row) * p.sizeX + x0 + col] = stage[i];
+            if ((uint32_t)row < ry && (uint32_t)col < stripW) planes[pl][(size_t)(y0 + row) * p.sizeX + x0 + col] = stage[pl * kFacPlane + row * kFacRow + col];
           }
         }
       }
@@ -1282,7 +1533,7 @@ namespace limg_hip
 
       if (PERSIST)
       {
-        for (int i = tid; i < 384; i += kThreads) reinterpret_cast<uint4 *>(L.fac)[i] = reinterpret_cast<const uint4 *>(park + kParkFac)[i];
+        for (int i = tid; i < 384; i += kThreads) *reinterpret_cast<uint4 *>(L.fac + (i >> 4) * kFacRow + (i & 15) * 16) = reinterpret_cast<const uint4 *>(park + kParkFac)[i];
         for (int i = tid; i < kStripBlocks * 12; i += kThreads) reinterpret_cast<uint32_t *>(s_rec)[i] = reinterpret_cast<const uint32_t *>(park + kParkRec)[i];
         if (tid < kStripBlocks) L.shift[tid] = (uint32_t)tid < nBlocks ? reinterpret_cast<const uint32_t *>(park + kParkShift)[tid] : 0u; // nothing is parked for blocks past the right edge
       }
@@ -1294,7 +1545,7 @@ namespace limg_hip
           {
             const int pl = i >> 7, row = (i & 127) >> 4, col = (i & 15) * 16;
             if ((uint32_t)row < ry && (uint32_t)col < stripW)
-              *reinterpret_cast<uint4 *>(L.fac + pl * 2048 + row * 256 + col) = *reinterpret_cast<const uint4 *>(planesIn[pl] + (size_t)(y0 + row) * p.sizeX + x0 + col);
+              *reinterpret_cast<uint4 *>(L.fac + pl * kFacPlane + row * kFacRow + col) = *reinterpret_cast<const uint4 *>(planesIn[pl] + (size_t)(y0 + row) * p.sizeX + x0 + col);
           }
         }
         else
@@ -1302,7 +1553,7 @@ namespace limg_hip
           for (int i = tid; i < 3 * 2048; i += kThreads)
           {
             const int pl = i >> 11, row = (i & 2047) >> 8, col = i & 255;
-            if ((uint32_t)row < ry && (uint32_t)col < stripW) L.fac[i] = planesIn[pl][(size_t)(y0 + row) * p.sizeX + x0 + col];
+            if ((uint32_t)row < ry && (uint32_t)col < stripW) L.fac[pl * kFacPlane + row * kFacRow + col] = planesIn[pl][(size_t)(y0 + row) * p.sizeX + x0 + col];
           }
         }
         // records (12 dwords of int16 per block) and shift words
@@ -1316,7 +1567,7 @@ namespace limg_hip
         if (tid < kStripBlocks) L.shift[tid] = (uint32_t)tid < nBlocks ? p.shifts[(size_t)byS * p.blocksX + strip * kStripBlocks + tid] : 0u;
       }
       __syncthreads();
-      phase_f_prepare<CH>(L, lane, wave);
+      phase_f_prepare<CH>(L, lane, wave, p.recordLimit);
       wave_lds_fence();
       if (p.fullPlanes) phase_f_store_const(p, io, L, x0, y0, ry, lane, wave); // base-independent: 28 of the 35 output bytes per pixel
       if (wave == 0)
@@ -1349,7 +1600,9 @@ namespace limg_hip
         phase_f_first_calls(L, base, lane);
       }
       __syncthreads();
-      phase_f_pixels<CH>(p, io, L, strip, x0, y0, ry, lane, wave, tid);
+      // strips of whole blocks (always in the persistent kernel; in the split path unless the image has partial edge blocks)
+      if (PERSIST || (p.sizeX % kBlock == 0 && ry == (uint32_t)kBlock)) phase_f_rows<CH>(p, io, L, strip, x0, y0, lane, wave);
+      else phase_f_pixels<CH>(p, io, L, strip, x0, y0, ry, lane, wave, tid);
     }
 
     // ---- kernels ---------------------------------------------------------------------------------------------------------
