@@ -76,7 +76,7 @@ def cpu_baseline(width, seed, budget_s=30.0):
         avail = len(os.sched_getaffinity(0))
     except Exception:
         avail = os.cpu_count() or 1
-    pool = max(1, min(avail, 16))  # the GPU box gives one GPU a CPU share of 16 cores; the reference makes 4 strips per pool thread
+    pool = max(1, min(avail, 16))  # (the scalar-oracle fallback below only)
     t_start = time.perf_counter()
 
     def best(fn, reps):
@@ -97,26 +97,34 @@ def cpu_baseline(width, seed, budget_s=30.0):
                           "the reference's SIMD path (expect ~10x below it)" % (rows, pool)}
     img = orc.photo_noise(width, width, seed)
     px = width * width
+    # pools: the box's share for one of its 8 GPUs (host threads / 8), all host threads (what the reference's own tool takes: limg_threading_max_threads(),
+    # src/main.cpp:165), and the 16 of rounds 1-2 for continuity.  The reference makes 4 row strips per pool thread (src/limg.cpp:2114-2134).
+    pools = {"pool16": max(1, min(avail, 16)), "pool_gpu_share": max(1, avail // 8), "pool_allcores": avail}
     res = {}
     for build in ("fastmath", "strict"):
         if not ref_available(fastmath=(build == "fastmath")):
             continue
         ref = Ref(fastmath=(build == "fastmath"))
-        res[build] = {
-            "test_pool": px / best(lambda: ref.encode3d(img, True, error_factor=100, pool_threads=pool), 3) / 1e6,
-            "perf_pool": px / best(lambda: ref.encode3d_perf(img, True, error_factor=100, pool_threads=pool), 3) / 1e6,
-        }
-        if time.perf_counter() - t_start < budget_s * 0.6:  # single thread: a quarter of the image is enough (linear in the rows)
+        res[build] = {}
+        for name, pool in pools.items():
+            if build == "strict" and name != "pool_gpu_share":
+                continue  # the strict-IEEE build (what the parity tests pin) at one pool size only: the two builds run at the same speed
+            res[build]["test_" + name] = px / best(lambda: ref.encode3d(img, True, error_factor=100, pool_threads=pool), 2) / 1e6
+            res[build]["perf_" + name] = px / best(lambda: ref.encode3d_perf(img, True, error_factor=100, pool_threads=pool), 2) / 1e6
+        if time.perf_counter() - t_start < budget_s * 0.7:  # single thread: a quarter of the image is enough (linear in the rows)
             q = np.ascontiguousarray(img[: width // 4])
             res[build]["test_1thread"] = q.size / best(lambda: ref.encode3d(q, True, error_factor=100, pool_threads=0), 1) / 1e6
             res[build]["perf_1thread"] = q.size / best(lambda: ref.encode3d_perf(q, True, error_factor=100, pool_threads=0), 1) / 1e6
         del ref
     head = res.get("fastmath") or res["strict"]
-    return {"value": round(head["test_pool"], 2), "unit": "Mpixels/s", "cores": pool, "kind": "reference", "cpu": cpu_model(), "host_cores_available": avail,
+    key = "test_pool_allcores" if "test_pool_allcores" in head else "test_pool_gpu_share"
+    return {"value": round(head[key], 2), "unit": "Mpixels/s", "cores": pools["pool_allcores"] if key == "test_pool_allcores" else pools["pool_gpu_share"], "kind": "reference",
+            "cpu": cpu_model(), "host_cores_available": avail, "pools": pools,
             "builds_Mpixels_per_s": {b: {k: round(v, 2) for k, v in d.items()} for b, d in res.items()},
-            "sample": "the whole %dx%d bench image (%.1f Mpx), the real reference compiled by oracle/build_ref.sh; value = its own configuration: -ffast-math build, "
-                      "thread pool of %d (4 row strips per thread), limg_encode3d_test style (all planes + decode), best of <= 3; builds_Mpixels_per_s lists "
-                      "fast-math / strict-IEEE x _test / _perf style x pool / single thread (single thread on the first quarter of the rows)" % (width, width, px / 1e6, pool)}
+            "sample": "the whole %dx%d bench image (%.1f Mpx), the real reference compiled by oracle/build_ref.sh; value = its own configuration: -ffast-math build "
+                      "(project.lua:38), a thread pool of ALL %d host threads (src/main.cpp:165; 4 row strips per thread), limg_encode3d_test style (all planes + decode), best "
+                      "of 2; builds_Mpixels_per_s lists fast-math / strict-IEEE x _test / _perf style x pool of 16 / host threads over 8 GPUs (%d) / all host threads / single "
+                      "thread (single thread on the first quarter of the rows)" % (width, width, px / 1e6, pools["pool_allcores"], pools["pool_gpu_share"])}
 
 
 def run_sharded(args, g, dist, rank, world):
@@ -611,6 +619,31 @@ def main():
     torch.cuda.synchronize()
     g.check()  # a look-back timeout inside the timed loop would void the line
 
+    # cold cost of a SECOND, smaller size class on the warm context (the noise table is a prefix stream and the scratch only grows: nothing is rebuilt), and of a
+    # fresh context whose table is built on the host the way rounds 1-2 did (limg_hip_options.host_noise_table), for comparison
+    cold = {}
+    if rank == 0 and not args.no_host_rate and W >= 4096:
+        w2 = W // 2
+        img2 = g.synth_device(args.workload, w2, w2, seed=5)
+        planes2 = g.alloc_planes_device(w2, w2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        g.encode3d_device(img2, not args.rgb, planes2, error_factor=args.error_factor, pool_threads=0, fast=not args.accurate)
+        torch.cuda.synchronize()
+        cold["second_smaller_size_class_first_encode_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+        t0 = time.perf_counter()
+        g.encode3d_device(img2, not args.rgb, planes2, error_factor=args.error_factor, pool_threads=0, fast=not args.accurate)
+        torch.cuda.synchronize()
+        cold["second_smaller_size_class_warm_encode_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+        del img2, planes2
+        gh = limg_amd.LimgHip(dev)
+        gh.set_options(host_noise_table=True)
+        t0 = time.perf_counter()
+        gh.encode3d_device(img, not args.rgb, planes, error_factor=args.error_factor, pool_threads=0, fast=not args.accurate)
+        torch.cuda.synchronize()
+        cold["first_encode_ms_with_host_built_noise_table"] = round((time.perf_counter() - t0) * 1e3, 2)
+        gh.close()
+
     px = W * H
     ms_per_step = elapsed * 1e3 / args.steps
     value = n_gpus * px * args.steps / elapsed / 1e6
@@ -652,7 +685,7 @@ def main():
                                    + ("" if args.forced_shift < 0 else ", forced shift %d" % args.forced_shift)
                                    + (", COMPACT outputs (8.06 B/px)" if args.compact else "") + (", FAST float stage" if args.float_mode == "fast" else ""),
                        "images_per_step": n_gpus, "parallelism": "independent image per GPU, no data-path collective", "psnr_db": None if psnr != psnr else round(psnr, 4),
-                       "first_encode_ms": round(first_encode_ms, 2),
+                       "first_encode_ms": round(first_encode_ms, 2), "cold": cold,
                        "perf_style_ms": None if perf_ms is None else round(perf_ms, 4),
                        "perf_style_Mpixels_per_s": None if not perf_ms else round(px / perf_ms / 1e3, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),

@@ -70,11 +70,22 @@ typedef struct limg_hip_options
                                   within 0.10 dB of EXACT; the 8x8 path only (the merged-block encoder always runs EXACT) */
   int32_t legacy_float_stage;  /* non-0: run the float stage inside the E step with lane == pixel (round-1 mapping; what images with partial edge blocks always use)
                                   instead of the one-lane-per-block kernel k_fit_tpb.  Same bits either way; A/B switch for tests and the bench */
+  int32_t collect_stats;       /* non-0: every encode (8x8 path and merged-block encoder) also leaves the reference's bit statistics for limg_hip_last_stats */
+  int32_t host_noise_table;    /* non-0: build the context's dither noise table on the host (one serial AES walk + upload, ~100 ms per new size class: what rounds 1-2 did)
+                                  instead of filling it on the GPU from the embedded chain checkpoints.  Same bytes; A/B switch for tests */
   int32_t test_batch_chunk;    /* test hook, 0 = default: limg_hip_encode3d_batch_device puts at most this many images into one launch pair (default: as many as 1 GiB
                                   of per-block scratch holds) */
 } limg_hip_options;
 
 typedef struct limg_hip_context limg_hip_context;
+
+/* Thread safety.  The reference is re-entrant (stack scratch only, src/limg.cpp:1890-1891).  Here a context owns device scratch, so:
+ *   - the blocking HOST-pointer entries (limg_hip_encode3d, _encode3d_perf, _compare, _blocked_encode3d, _encode_stream, _decode_stream) take a mutex inside the
+ *     context: any number of threads may call them on one shared context at once (this is what the C++ shim's limg_encode3d_test & co. rely on); the calls run
+ *     one after the other;
+ *   - the asynchronous *_device entries enqueue kernels that use the context's scratch after the call has returned: use one context per HIP stream / thread
+ *     for those (contexts are independent and cheap next to an image: tests/test_gpu_parity.py::test_two_contexts_on_two_threads);
+ *   - limg_hip_init / limg_hip_shutdown / limg_hip_set_options of one context must not race with calls on that context. */
 
 /* Create / destroy a context bound to HIP device `device` (-1 = current device).  No reference analogue
  * (the reference keeps no state besides CPUID flags, src/limg_simd.cpp:57-60). */
@@ -130,6 +141,13 @@ limg_hip_result limg_hip_synth_photo_noise_device(uint32_t *pOut, size_t width, 
  * (protocol safety net; the host-pointer entry points call it themselves). */
 limg_hip_result limg_hip_check_device_status(limg_hip_context *pCtx);
 
+/* The statistics the reference's limg_encode3d_test / limg_blocked_encode3d_test print themselves (src/limg.cpp:2232-2248; counters :1971-1999, :1561-1590):
+ * pCounters30[f] (f = 0..2: factor A, B, C) = bits kept, summed over the pixels ((8 - shift) per pixel); pCounters30[3 + 9 f + s] = pixels whose block crushed factor
+ * f by s bits.  "Average Block Bits" = (c[0] + c[1] + c[2]) / pixels; the histogram line of factor f = c[3 + 9 f + s] * 100 / pixels for s = 0..8 ("8 bit" .. "0 bit").
+ * Of the context's last encode made with limg_hip_options.collect_stats set (a batched encode: all its images together); waits for that encode.
+ * The library itself prints nothing (SURVEY 8(b) "Side effects"); include/limg_hip_shim.hpp's limg_print_stats and tools/limg_hip_cli.cpp print upstream's lines. */
+limg_hip_result limg_hip_last_stats(limg_hip_context *pCtx, uint64_t *pCounters30, uint64_t *pPixels);
+
 /* Per-kernel timing for the bench (HIP events recorded on the stream each profiled encode is launched on).
  * limg_hip_profile_end writes 3 floats per profiled encode: k_fit_search, k_strip_scan (or the host chain walk of ragged
  * images), k_dither_store, in milliseconds; returns the number of encodes written or -1. */
@@ -145,8 +163,15 @@ int limg_hip_profile_end(limg_hip_context *pCtx, float *pMs, int maxEncodes);
  *                              forceSoftwareAes bit 0: do not use AES-NI; bit 1: PCG dither instead of AES.
  *  limg_hip_host_partition   : src/limg.cpp:2114-2134 in block rows: chain c < count-1 owns rows [c*rows, (c+1)*rows), the last the rest. */
 limg_hip_result limg_hip_host_noise_table(uint8_t *pOut, size_t calls);
+/*  limg_hip_noise_table_device: the same stream written by the GPU (what a context does for itself on the first encode of a size class): `calls` x 64 bytes into a
+ *                              DEVICE buffer (16-byte aligned), asynchronous on `stream`; at most 16 Mi calls (the reach of the embedded checkpoints). */
+limg_hip_result limg_hip_noise_table_device(limg_hip_context *pCtx, uint8_t *pOutDevice, size_t calls, void *stream);
 uint64_t limg_hip_host_chain_call(uint64_t chainValue, size_t pixelCount, uint8_t *pNoise64, int forceSoftwareAes);
 limg_hip_result limg_hip_host_partition(size_t sizeY, int poolThreads, uint32_t *pChainCount, uint32_t *pChainBlockRows);
+/*  limg_hip_host_chain_checkpoints: walks `calls` full-block dither calls from the reference's seed (src/limg.cpp:1893) and writes the chain value that call
+ *                              i * every starts from to pOut[i] (may be NULL); returns the value after the last call.  The library's embedded checkpoint
+ *                              table (one value every 1024 calls, from which the GPU fills the noise table in parallel) is generated and checked with it. */
+uint64_t limg_hip_host_chain_checkpoints(size_t calls, size_t every, uint64_t *pOut, int pcg);
 
 /* ---- merged-block encoder ----------------------------------------------------------------------------------------------------------
  * Replaces `limg_blocked_encode3d_test` (src/limg.h:46, src/limg.cpp:2329-2453), what the reference's CLI runs on a single file

@@ -10,8 +10,10 @@
 #ifndef LIMG_HIP_SHIM_HPP
 #define LIMG_HIP_SHIM_HPP
 
+#include <inttypes.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include <functional>
 #include <thread>
@@ -69,11 +71,52 @@ struct limg_blocked_encode3d_info // src/limg.h:39-44
 
 namespace limg_hip_shim
 {
+  // The reference keeps no state, so its entry points may be called from any number of threads at once (src/limg.cpp:1890-1891: scratch on the stack).  The shim's
+  // callers get the same: ONE process-wide context, created on first use by whichever thread gets there first (a function-local static: initialisation is
+  // thread-safe since C++11) and shut down when the process exits (the holder's destructor, registered after the HIP runtime's own exit handlers and therefore
+  // run before them); the blocking host-pointer entries of the C ABI that the functions below call serialise on a mutex inside the context
+  // (include/limg_hip.h "Thread safety").  Concurrent callers are correct, one encode at a time runs on the GPU.
+  struct context_holder
+  {
+    limg_hip_context *ctx = nullptr;
+    context_holder() { if (limg_hip_init(-1, &ctx) != limg_hip_success) ctx = nullptr; }
+    ~context_holder() { limg_hip_shutdown(&ctx); }
+    context_holder(const context_holder &) = delete;
+    context_holder &operator=(const context_holder &) = delete;
+  };
   inline limg_hip_context *context()
   {
-    static limg_hip_context *ctx = nullptr;
-    if (!ctx && limg_hip_init(-1, &ctx) != limg_hip_success) ctx = nullptr;
-    return ctx;
+    static context_holder holder;
+    return holder.ctx;
+  }
+
+  // Upstream's limg_encode3d_test and limg_blocked_encode3d_test print their bit statistics themselves (src/limg.cpp:2232-2248, PRINT_TEST_OUTPUT is always defined);
+  // the library is silent.  A caller that wants upstream's console output switches it on once -- limg_hip_shim::print_stats(true) -- and the two functions below then
+  // print the same block, from the counters the GPU reduced (limg_hip_last_stats), after each encode.
+  inline bool &stats_flag() { static bool on = false; return on; }
+  inline void print_stats(const bool on)
+  {
+    stats_flag() = on;
+    limg_hip_context *c = context();
+    if (!c) return;
+    limg_hip_options o;
+    limg_hip_default_options(&o);
+    o.collect_stats = on ? 1 : 0;
+    limg_hip_set_options(c, &o);
+  }
+  inline void print_last_stats(limg_hip_context *c)
+  {
+    uint64_t a[30], pixels = 0;
+    if (limg_hip_last_stats(c, a, &pixels) != limg_hip_success || pixels == 0) return;
+    const double t = (double)pixels;
+    printf("\nAverage Block Bits: %5.3f (A: %5.3f | B: %5.3f | C: %5.3f)\n\n", (a[0] + a[1] + a[2]) / t, a[0] / t, a[1] / t, a[2] / t);
+    for (size_t i = 0; i < 9; i++) printf(" %" PRIu64 " bit   ", (uint64_t)(8 - i));
+    for (size_t f = 0; f < 3; f++)
+    {
+      puts("");
+      for (size_t j = 0; j < 9; j++) printf("%7.4f  ", a[3 + f * 9 + j] * 100.0 / t);
+    }
+    puts("\n");
   }
 }
 
@@ -83,8 +126,10 @@ inline limg_result limg_encode3d_test(const uint32_t *pIn, const size_t sizeX, c
   static_assert(sizeof(limg_encode3d_info) == sizeof(limg_hip_encode3d_info), "layout");
   limg_hip_context *c = limg_hip_shim::context();
   if (!c) return limg_error_Generic;
-  return (limg_result)limg_hip_encode3d(c, pIn, sizeX, sizeY, hasAlpha ? 1 : 0, reinterpret_cast<limg_hip_encode3d_info *>(pInfo), errorFactor,
-                                        limg_hip_shim::pool_threads(pThreadPool), fastBitCrushing ? 1 : 0);
+  const limg_result r = (limg_result)limg_hip_encode3d(c, pIn, sizeX, sizeY, hasAlpha ? 1 : 0, reinterpret_cast<limg_hip_encode3d_info *>(pInfo), errorFactor,
+                                                       limg_hip_shim::pool_threads(pThreadPool), fastBitCrushing ? 1 : 0);
+  if (r == limg_success && limg_hip_shim::stats_flag()) limg_hip_shim::print_last_stats(c);
+  return r;
 }
 
 inline limg_result limg_encode3d_test_perf(const uint32_t *pIn, const size_t sizeX, const size_t sizeY, const bool hasAlpha, const uint32_t errorFactor, limg_thread_pool *pThreadPool,
@@ -102,7 +147,10 @@ inline limg_result limg_blocked_encode3d_test(const uint32_t *pIn, const size_t 
   static_assert(sizeof(limg_blocked_encode3d_info) == sizeof(limg_hip_blocked_encode3d_info), "layout");
   limg_hip_context *c = limg_hip_shim::context();
   if (!c) return limg_error_Generic;
-  return (limg_result)limg_hip_blocked_encode3d(c, pIn, sizeX, sizeY, hasAlpha ? 1 : 0, reinterpret_cast<limg_hip_blocked_encode3d_info *>(pInfo), errorFactor, fastBitCrushing ? 1 : 0);
+  const limg_result r = (limg_result)limg_hip_blocked_encode3d(c, pIn, sizeX, sizeY, hasAlpha ? 1 : 0, reinterpret_cast<limg_hip_blocked_encode3d_info *>(pInfo), errorFactor,
+                                                               fastBitCrushing ? 1 : 0);
+  if (r == limg_success && limg_hip_shim::stats_flag()) limg_hip_shim::print_last_stats(c);
+  return r;
 }
 
 inline double limg_compare(const uint32_t *pImageA, const uint32_t *pImageB, const size_t sizeX, const size_t sizeY, const bool hasAlpha, double *pMeanSquaredError,

@@ -19,9 +19,9 @@ PLANES = P32 + P8
 # every symbol include/limg_hip.h declares (checked by tests/test_host.py without a GPU)
 ABI_SYMBOLS = (
     "limg_hip_init", "limg_hip_shutdown", "limg_hip_default_options", "limg_hip_set_options", "limg_hip_encode3d", "limg_hip_encode3d_perf",
-    "limg_hip_encode3d_device", "limg_hip_encode3d_batch_device", "limg_hip_compare", "limg_hip_compare_device", "limg_hip_synth_random_gradient_device",
+    "limg_hip_encode3d_device", "limg_hip_encode3d_batch_device", "limg_hip_last_stats", "limg_hip_compare", "limg_hip_compare_device", "limg_hip_synth_random_gradient_device",
     "limg_hip_synth_photo_noise_device", "limg_hip_context_device_bytes", "limg_hip_version", "limg_hip_profile_begin", "limg_hip_profile_end",
-    "limg_hip_host_noise_table", "limg_hip_host_chain_call", "limg_hip_host_partition", "limg_hip_check_device_status",
+    "limg_hip_host_noise_table", "limg_hip_noise_table_device", "limg_hip_host_chain_call", "limg_hip_host_chain_checkpoints", "limg_hip_host_partition", "limg_hip_check_device_status",
     "limg_hip_stream_bound", "limg_hip_encode_stream_device", "limg_hip_decode_stream_device", "limg_hip_encode_stream", "limg_hip_decode_stream",
     "limg_hip_stream_info",
     "limg_hip_blocked_encode3d", "limg_hip_blocked_encode3d_device", "limg_hip_blocked_regions", "limg_hip_blocked_timing", "limg_hip_host_blocked_matches",
@@ -60,7 +60,7 @@ class CompactOut(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("forced_shift", C.c_int32 * 3), ("force_split_kernels", C.c_int32), ("dither_pcg", C.c_int32), ("test_record_limit", C.c_int32), ("float_mode", C.c_int32), ("legacy_float_stage", C.c_int32),
-                ("test_batch_chunk", C.c_int32)]
+                ("collect_stats", C.c_int32), ("host_noise_table", C.c_int32), ("test_batch_chunk", C.c_int32)]
 
 
 def load_library(path=None):
@@ -106,8 +106,14 @@ def load_library(path=None):
     L.limg_hip_check_device_status.argtypes = [C.c_void_p]
     L.limg_hip_host_noise_table.restype = C.c_int
     L.limg_hip_host_noise_table.argtypes = [C.c_void_p, C.c_size_t]
+    L.limg_hip_last_stats.restype = C.c_int
+    L.limg_hip_last_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.limg_hip_noise_table_device.restype = C.c_int
+    L.limg_hip_noise_table_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.limg_hip_host_chain_call.restype = C.c_uint64
     L.limg_hip_host_chain_call.argtypes = [C.c_uint64, C.c_size_t, C.c_void_p, C.c_int]
+    L.limg_hip_host_chain_checkpoints.restype = C.c_uint64
+    L.limg_hip_host_chain_checkpoints.argtypes = [C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]
     L.limg_hip_host_partition.restype = C.c_int
     L.limg_hip_host_partition.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.limg_hip_context_device_bytes.restype = C.c_size_t
@@ -240,7 +246,7 @@ class LimgHip:
         except Exception:
             pass
 
-    def set_options(self, forced_shift=None, force_split=False, dither_pcg=False, test_record_limit=0, float_fast=False, legacy_float_stage=False, test_batch_chunk=0):
+    def set_options(self, forced_shift=None, force_split=False, dither_pcg=False, test_record_limit=0, float_fast=False, legacy_float_stage=False, test_batch_chunk=0, host_noise_table=False, collect_stats=False):
         o = Options()
         self.lib.limg_hip_default_options(C.byref(o))
         if forced_shift is not None:
@@ -252,6 +258,8 @@ class LimgHip:
         o.float_mode = 1 if float_fast else 0
         o.legacy_float_stage = int(legacy_float_stage)
         o.test_batch_chunk = int(test_batch_chunk)
+        o.host_noise_table = int(host_noise_table)
+        o.collect_stats = int(collect_stats)
         _check(self.lib.limg_hip_set_options(self.ctx, C.byref(o)), "limg_hip_set_options")
 
     def set_forced_shift(self, shift=None):
@@ -312,6 +320,13 @@ class LimgHip:
         infos = (Info * n)(*[Info(*[(pl[k].data_ptr() if k in pl else None) for k in PLANES]) for pl in planes_list])
         _check(self.lib.limg_hip_encode3d_batch_device(self.ctx, n, ins, w, h, int(has_alpha), infos, error_factor, pool_threads, int(fast), self._stream()),
                "limg_hip_encode3d_batch_device")
+
+    def last_stats(self):
+        """(counters[30], pixels) of the last encode made with set_options(collect_stats=True): the reference's "Average Block Bits" counters (src/limg.cpp:1971-1999)."""
+        out = np.zeros(30, dtype=np.uint64)
+        px = C.c_uint64(0)
+        _check(self.lib.limg_hip_last_stats(self.ctx, _np_ptr(out), C.byref(px)), "limg_hip_last_stats")
+        return out, px.value
 
     def compare_device(self, a, b, has_alpha):
         mse, mx = C.c_double(), C.c_double()
@@ -469,3 +484,14 @@ class LimgHip:
 
     def device_bytes(self):
         return self.lib.limg_hip_context_device_bytes(self.ctx)
+
+
+def format_stats(counters, pixels):
+    """The text limg_encode3d_test prints for these counters (src/limg.cpp:2235-2248), character for character."""
+    c = [int(v) for v in counters]
+    t = float(pixels)
+    out = "\nAverage Block Bits: %5.3f (A: %5.3f | B: %5.3f | C: %5.3f)\n\n" % ((c[0] + c[1] + c[2]) / t, c[0] / t, c[1] / t, c[2] / t)
+    out += "".join(" %d bit   " % (8 - i) for i in range(9))
+    for f in range(3):
+        out += "\n" + "".join("%7.4f  " % (c[3 + f * 9 + j] * 100.0 / t) for j in range(9))
+    return out + "\n\n"

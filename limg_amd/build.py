@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liblimg_hip.so")
-SOURCES = ["limg_hip_kernels.hip", "limg_hip_fit_tpb.hip", "limg_hip_stream.hip", "limg_hip_blocked.hip", "limg_hip_synth.hip", "limg_hip_api.hip", "limg_hip_noise.cpp", "limg_hip_blocked_host.cpp"]
+SOURCES = ["limg_hip_kernels.hip", "limg_hip_fit_tpb.hip", "limg_hip_stream.hip", "limg_hip_blocked.hip", "limg_hip_synth.hip", "limg_hip_noise_gpu.hip", "limg_hip_api.hip", "limg_hip_noise.cpp", "limg_hip_blocked_host.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 # per-source extras.  limg_hip_kernels.hip: every atomic in it is issued by one lane (block queue, ticket, look-back descriptors); LLVM's atomic optimizer would still
 # wrap each in its wave-aggregation prologue (v_mbcnt x 2, compare, s_bcnt1, broadcast, add) -- five vector instructions per 8x8 block for nothing

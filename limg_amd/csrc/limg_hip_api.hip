@@ -20,6 +20,7 @@ namespace limg_hip
 {
   uint64_t chain_call(uint64_t h, unsigned n, uint8_t *noise64, bool forceSoft, bool pcg);
   uint64_t fill_noise_table(uint64_t h, uint8_t *noise, size_t count, bool pcg);
+  uint64_t chain_checkpoints(uint64_t h, size_t calls, size_t every, uint64_t *pOut, bool pcg);
 }
 
 using namespace limg_hip;
@@ -71,6 +72,11 @@ struct HostBuf
 
 struct limg_hip_context
 {
+  // The reference's entry points are re-entrant (scratch on the stack, src/limg.cpp:1890-1891; the only globals are CPUID flags, src/limg_simd.cpp:57-60), so a
+  // caller may encode from several threads at once.  A context owns device scratch, so the blocking host-pointer entries (what the shim's limg_encode3d_test & co.
+  // call) serialise on this mutex: any number of threads may share one context through them.  The asynchronous *_device entries enqueue work that uses that
+  // scratch after they return: one context per stream there (documented in limg_hip.h).
+  std::recursive_mutex hostEntry;
   int device = 0;
   limg_hip_options opt;
   DevBuf records, shifts, stripCalls, stripBase; // per-block / per-strip scratch
@@ -79,8 +85,14 @@ struct limg_hip_context
   size_t noiseCount = 0;                         // entries generated so far
   uint64_t noiseNext = kDitherSeed;              // chain value after the last generated entry
   DevBuf noiseDyn;                               // data-dependent chains (images with partial blocks)
+  DevBuf noiseCk;                                // the chain checkpoints (limg_noise_checkpoints.h) on the device: the GPU fills the noise table from them
   DevBuf park;                                   // persistent kernel: 2 x 8 KiB per workgroup
   DevBuf batchTable;                             // batched encode: one ImageIO per image
+  DevBuf stats;                                  // limg_hip_options.collect_stats: the reference's 3 + 27 bit counters of the last encode
+  hipStream_t statsStream = nullptr;
+  int statsState = 0;                            // 0 = none, 1 = on the device (8x8 path), 2 = in statsHost (merged-block encoder)
+  uint64_t statsHost[30] = { 0 };
+  uint64_t statsPixels = 0;
   DevBuf lookback;                               // fused path: ticket (16 B) then one 8-byte descriptor per work strip
   DevBuf accTable;                               // accurate search: automaton expanded to 32-byte entries (built on the first accurate encode)
   DevBuf devStatus;                              // sticky look-back timeout word: never touched by the per-launch memset, cleared by limg_hip_check_device_status
@@ -101,7 +113,10 @@ struct limg_hip_context
   int commRank = 0, commWorld = 1;
   // limg_hip_encode3d_chain_device: phase 2 is only valid right after phase 1 of the same strip (the context holds the intermediate results)
   const void *chainIn = nullptr;
-  size_t chainX = 0, chainY = 0;
+  size_t chainX = 0, chainY = 0, chainBefore = 0;
+  const void *chainFac[3] = { nullptr, nullptr, nullptr }; // phase 1 left the pre-dither factor bytes in these planes
+  int chainAlpha = 0, chainFast = 0;
+  uint32_t chainEf = 0;
   DevBuf commWords; // [0] this rank's value, [1] its chain base, [8 ...] the all-gathered values
   DevBuf streamFac, streamTiles, streamStatus, streamBuf; // stream packer: 3 factor planes, per-tile payload words; decode status word; host-entry staging
   // optional per-kernel timing (bench): 4 events per encode, recorded on the caller's stream, read back in one go
@@ -147,6 +162,26 @@ namespace
     if (pcg != c->noisePcg) c->noiseCount = 0;
     if (entries <= c->noiseCount) return limg_hip_success;
     const size_t want = ((entries + kNoiseChunk - 1) / kNoiseChunk) * kNoiseChunk;
+    size_t ckCount = 0, ckEvery = 0;
+    const uint64_t *ck = noise_checkpoints_host(&ckCount, &ckEvery);
+    if (!pcg && want <= ckCount * ckEvery && c->opt.host_noise_table == 0)
+    { // the AES stream, on the GPU from the embedded chain checkpoints (limg_hip_noise_gpu.hip): stream-ordered, ~1 ms, nothing crosses PCIe but the 128 KiB of
+      // checkpoints, once per context.  A larger table than the one at hand is filled from scratch (its prefix is the same stream).
+      limg_hip_result r;
+      if (!c->noiseCk.p)
+      {
+        if ((r = c->noiseCk.ensure(ckCount * 8)) != limg_hip_success) return r;
+        HIP_TRY(hipMemcpyAsync(c->noiseCk.p, ck, ckCount * 8, hipMemcpyHostToDevice, stream)); // static storage: outlives the copy
+      }
+      HIP_TRY(hipStreamSynchronize(stream)); // earlier encodes on this stream may still read the table that is about to be replaced
+      if ((r = c->noise.ensure(want * 64)) != limg_hip_success) return r;
+      launch_noise_fill((uint8_t *)c->noise.p, (const uint64_t *)c->noiseCk.p, want, stream);
+      HIP_TRY(hipGetLastError());
+      c->noiseCount = want;
+      c->noisePcg = false;
+      return limg_hip_success;
+    }
+    // PCG dither (a test / fallback mode), tables beyond the checkpoints' reach (images of more than 5.59 M blocks) or limg_hip_options.host_noise_table:
     // (re)generate on the host; one-time cost per context and image size class
     std::vector<uint8_t> host(want * 64);
     uint64_t h = kDitherSeed;
@@ -311,6 +346,7 @@ namespace
       if (pt.chainCount > 1) maxRows = p.blocksY - (pt.chainCount - 1) * pt.chainRows; // the last chain takes the remainder, never fewer rows than the others
       if ((r = grow_noise_table(c, ((size_t)maxRows * p.blocksX + chainBlocksBefore) * 3, stream)) != limg_hip_success) return r;
       p.noise = (const uint8_t *)c->noise.p;
+      p.noiseLast = (uint32_t)(c->noiseCount - 1);
     }
 
     if (chainPhase != 0 && (ragged || !dInfo || poolThreads != 0)) return limg_hip_error_InvalidParameter; // a chain shared between GPUs: whole 8x8 blocks, one chain
@@ -319,6 +355,18 @@ namespace
     // The float stage as its own launch, one lane per block (limg_hip_fit_tpb.hip), wherever every block is a whole 8x8: the E step then starts from the records.
     p.prefit = (!ragged && c->opt.legacy_float_stage == 0 && (((uintptr_t)p.records) & 15u) == 0) ? 1 : 0; // k_fit_tpb stores records 16 bytes at a time
     const bool fused = dInfo != nullptr && !ragged && (!c->forceSplit || batchCount > 1) && chainPhase == 0;
+    const bool wantStats = c->opt.collect_stats != 0 && dInfo != nullptr && chainPhase == 0;
+    auto stats = [&]() -> limg_hip_result
+    { // the reference's "Average Block Bits" counters (src/limg.cpp:1971-1999) of this encode, left on the device for limg_hip_last_stats
+      if (!wantStats) return limg_hip_success;
+      limg_hip_result rs;
+      if ((rs = c->stats.ensure(30 * 8)) != limg_hip_success) return rs;
+      HIP_TRY(hipMemsetAsync(c->stats.p, 0, 30 * 8, stream));
+      launch_shift_stats(p.shifts, p.blocksX, p.blocksY, p.blocksY * p.batchCount, p.sizeX, p.sizeY, (unsigned long long *)c->stats.p, stream);
+      c->statsStream = stream; c->statsState = 1; c->statsPixels = (uint64_t)sizeX * sizeY * batchCount;
+      return limg_hip_success;
+    };
+    if (chainPhase == 0) c->statsState = 0;
     if (batchCount > 1 && (!fused || !p.prefit || !fullPlanes)) return limg_hip_error_InvalidParameter; // the caller falls back to one encode per image
     if (fused)
     { // the persistent kernel's ticket (16 B) and one 8-byte look-back descriptor per work strip, zero at its start: k_fit_tpb clears them on its way (one launch
@@ -348,7 +396,7 @@ namespace
         HIP_TRY(hipMemsetAsync(c->devStatus.p, 0, 16, stream));
       }
       p.timeout = (uint32_t *)c->devStatus.p;
-      p.compactOut = compact != nullptr;
+      p.compactOut = compact != nullptr || wantStats; // the statistics are reduced from the raster-order shift words
       if ((r = c->park.ensure((size_t)(c->persistentWorkgroups / 5 * 6) * 2 * 8192)) != limg_hip_success) return r;
       p.park = (uint8_t *)c->park.p;
       mark(c, stream);
@@ -356,18 +404,20 @@ namespace
       mark(c, stream); mark(c, stream);
       if (!p.prefit) mark(c, stream); // 4 events per encode: with the float stage as its own launch the intervals are {k_fit_tpb, k_encode_persistent, -}
       HIP_TRY(hipGetLastError());
-      return limg_hip_success;
+      return stats();
     }
 
     if (chainPhase == 2)
     { // the E step and the scan of this very image ran in phase 1: records, shift words, strip bases and the pre-dither factor bytes are where they left them
+      mark(c, stream); // a chain encode records 4 events over its two phases: intervals {E step + scan, exchange between the phases, F step}
       launch_dither_store(p, channels, stream);
+      mark(c, stream);
       HIP_TRY(hipGetLastError());
       return limg_hip_success;
     }
     if (!p.prefit) mark(c, stream); // split path intervals: {k_fit_tpb + k_fit_search, scan, k_dither_store}
     launch_fit_search(p, channels, stream);
-    mark(c, stream);
+    if (chainPhase != 1) mark(c, stream);
     if (!dInfo)
     {
       mark(c, stream); mark(c, stream);
@@ -380,6 +430,7 @@ namespace
       launch_strip_scan(p, stream);
       if (chainPhase == 1)
       {
+        mark(c, stream);
         HIP_TRY(hipGetLastError());
         return limg_hip_success;
       }
@@ -413,12 +464,13 @@ namespace
       HIP_TRY(hipMemcpyAsync(p.stripBase, hBase.data(), strips * 4, hipMemcpyHostToDevice, stream));
       HIP_TRY(hipStreamSynchronize(stream)); // the host vectors die with this scope
       p.noise = (const uint8_t *)c->noiseDyn.p;
+      p.noiseLast = (uint32_t)totalCalls;
     }
     mark(c, stream);
     launch_dither_store(p, channels, stream);
     mark(c, stream);
     HIP_TRY(hipGetLastError());
-    return limg_hip_success;
+    return stats();
   }
 }
 
@@ -462,7 +514,7 @@ extern "C"
     limg_hip_context *c = *ppCtx;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = { &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->lookback, &c->devStatus, &c->accTable, &c->commWords, &c->park, &c->batchTable, &c->in, &c->planes, &c->cmp,
+    DevBuf *bufs[] = { &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->noiseCk, &c->stats, &c->lookback, &c->devStatus, &c->accTable, &c->commWords, &c->park, &c->batchTable, &c->in, &c->planes, &c->cmp,
                        &c->streamFac, &c->streamTiles, &c->streamStatus, &c->streamBuf,
                        &c->bFlags, &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bV, &c->bFac, &c->bNoise, &c->bNoiseBase };
     for (DevBuf *b : bufs) b->release();
@@ -518,6 +570,22 @@ extern "C"
     return limg_hip_success;
   }
 
+  limg_hip_result limg_hip_last_stats(limg_hip_context *c, uint64_t *pCounters30, uint64_t *pPixels)
+  {
+    if (!c || !pCounters30) return limg_hip_error_ArgumentNull;
+    if (c->statsState == 0) return limg_hip_error_InvalidParameter; // no encode with limg_hip_options.collect_stats since the last reset
+    if (c->statsState == 1)
+    {
+      HIP_TRY(hipSetDevice(c->device));
+      HIP_TRY(hipMemcpyAsync(c->statsHost, c->stats.p, 30 * 8, hipMemcpyDeviceToHost, c->statsStream));
+      HIP_TRY(hipStreamSynchronize(c->statsStream));
+      c->statsState = 2;
+    }
+    memcpy(pCounters30, c->statsHost, 30 * 8);
+    if (pPixels) *pPixels = c->statsPixels;
+    return limg_hip_success;
+  }
+
   limg_hip_result limg_hip_profile_begin(limg_hip_context *c)
   {
     if (!c) return limg_hip_error_ArgumentNull;
@@ -545,6 +613,24 @@ extern "C"
   }
 
   // ---- host-only helpers (no GPU needed; exposed so the host logic can be tested on CPU-only machines) --------------------
+  limg_hip_result limg_hip_noise_table_device(limg_hip_context *c, uint8_t *pOutDevice, size_t calls, void *stream)
+  {
+    if (!c || !pOutDevice) return limg_hip_error_ArgumentNull;
+    size_t ckCount = 0, ckEvery = 0;
+    const uint64_t *ck = noise_checkpoints_host(&ckCount, &ckEvery);
+    if (calls > ckCount * ckEvery || ((uintptr_t)pOutDevice & 15u) != 0) return limg_hip_error_InvalidParameter;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->noiseCk.p)
+    {
+      limg_hip_result r;
+      if ((r = c->noiseCk.ensure(ckCount * 8)) != limg_hip_success) return r;
+      HIP_TRY(hipMemcpyAsync(c->noiseCk.p, ck, ckCount * 8, hipMemcpyHostToDevice, (hipStream_t)stream));
+    }
+    launch_noise_fill(pOutDevice, (const uint64_t *)c->noiseCk.p, calls, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return limg_hip_success;
+  }
+
   limg_hip_result limg_hip_host_noise_table(uint8_t *pOut, size_t calls)
   {
     if (!pOut) return limg_hip_error_ArgumentNull;
@@ -556,6 +642,11 @@ extern "C"
   {
     if (pixelCount > 0xFFFFFFFFull) return 0;
     return chain_call(chainValue, (unsigned)pixelCount, pNoise64, (forceSoftwareAes & 1) != 0, (forceSoftwareAes & 2) != 0);
+  }
+
+  uint64_t limg_hip_host_chain_checkpoints(size_t calls, size_t every, uint64_t *pOut, int pcg)
+  {
+    return chain_checkpoints(kDitherSeed, calls, every, pOut, pcg != 0);
   }
 
   limg_hip_result limg_hip_host_partition(size_t sizeY, int poolThreads, uint32_t *pChainCount, uint32_t *pChainBlockRows)
@@ -636,11 +727,21 @@ extern "C"
   {
     if (phase != 1 && phase != 2) return limg_hip_error_InvalidParameter;
     if (!c || (phase == 1 && !pCallsDevice) || (phase == 2 && !pChainBaseDevice) || !pInfo) return limg_hip_error_ArgumentNull;
-    if (phase == 2 && (c->chainIn != pIn || c->chainX != sizeX || c->chainY != sizeY)) return limg_hip_error_InvalidParameter; // no phase 1 of this strip pending
+    // phase 2 continues the phase 1 the context holds: same strip, same planes (phase 1 left the pre-dither factor bytes in them), same parameters, and a noise
+    // table that was sized for the same chain position
+    if (phase == 2 && (c->chainIn != pIn || c->chainX != sizeX || c->chainY != sizeY || c->chainFac[0] != pInfo->pFactorsA || c->chainFac[1] != pInfo->pFactorsB ||
+                       c->chainFac[2] != pInfo->pFactorsC || c->chainAlpha != (hasAlpha != 0) || c->chainEf != errorFactor || c->chainFast != (fastBitCrushing != 0) ||
+                       c->chainBefore != blocksBefore))
+      return limg_hip_error_InvalidParameter; // no matching phase 1 pending
     c->chainIn = nullptr;
     const limg_hip_result r = encode_device(c, pIn, sizeX, sizeY, hasAlpha, pInfo, nullptr, errorFactor, 0, fastBitCrushing, (hipStream_t)stream, false, false, phase,
                          (unsigned long long *)pCallsDevice, (const unsigned long long *)pChainBaseDevice, blocksBefore);
-    if (r == limg_hip_success && phase == 1) { c->chainIn = pIn; c->chainX = sizeX; c->chainY = sizeY; }
+    if (r == limg_hip_success && phase == 1)
+    {
+      c->chainIn = pIn; c->chainX = sizeX; c->chainY = sizeY; c->chainBefore = blocksBefore;
+      c->chainFac[0] = pInfo->pFactorsA; c->chainFac[1] = pInfo->pFactorsB; c->chainFac[2] = pInfo->pFactorsC;
+      c->chainAlpha = hasAlpha != 0; c->chainEf = errorFactor; c->chainFast = fastBitCrushing != 0;
+    }
     return r;
   }
 
@@ -648,6 +749,7 @@ extern "C"
                                     int poolThreads, int fastBitCrushing)
   {
     if (!c || !pIn || !pInfo) return limg_hip_error_ArgumentNull;
+    std::lock_guard<std::recursive_mutex> hostLock(c->hostEntry);
     if (sizeX == 0 || sizeY == 0) return limg_hip_error_InvalidParameter;
     void *const *hp = reinterpret_cast<void *const *>(pInfo);
     for (int i = 0; i < 11; i++)
@@ -678,6 +780,7 @@ extern "C"
                                          int fastBitCrushing)
   {
     if (!c || !pIn) return limg_hip_error_ArgumentNull;
+    std::lock_guard<std::recursive_mutex> hostLock(c->hostEntry);
     if (sizeX == 0 || sizeY == 0) return limg_hip_error_InvalidParameter;
     HIP_TRY(hipSetDevice(c->device));
     const size_t px = sizeX * sizeY;
@@ -710,6 +813,7 @@ extern "C"
   double limg_hip_compare(limg_hip_context *c, const uint32_t *a, const uint32_t *b, size_t sizeX, size_t sizeY, int hasAlpha, double *pMse, double *pMax)
   {
     if (!c || !a || !b || sizeX == 0 || sizeY == 0) return NAN;
+    std::lock_guard<std::recursive_mutex> hostLock(c->hostEntry);
     if (hipSetDevice(c->device) != hipSuccess) return NAN;
     const size_t bytes = sizeX * sizeY * 4;
     if (c->in.ensure(bytes) != limg_hip_success || c->planes.ensure(bytes) != limg_hip_success) return NAN;
@@ -836,6 +940,7 @@ extern "C"
                                          uint32_t errorFactor, int poolThreads, int fastBitCrushing)
   {
     if (!c || !pIn || !pStream || !pBytes) return limg_hip_error_ArgumentNull;
+    std::lock_guard<std::recursive_mutex> hostLock(c->hostEntry);
     const size_t bound = limg_hip_stream_bound(sizeX, sizeY);
     if (bound == 0) return limg_hip_error_InvalidParameter;
     HIP_TRY(hipSetDevice(c->device));
@@ -857,6 +962,7 @@ extern "C"
   limg_hip_result limg_hip_decode_stream(limg_hip_context *c, const uint8_t *pStream, size_t streamBytes, uint32_t *pOut, size_t outPixels)
   {
     if (!c || !pStream || !pOut) return limg_hip_error_ArgumentNull;
+    std::lock_guard<std::recursive_mutex> hostLock(c->hostEntry);
     size_t sizeX = 0, sizeY = 0, total = 0;
     limg_hip_result r;
     if ((r = limg_hip_stream_info(pStream, streamBytes, &sizeX, &sizeY, nullptr, &total)) != limg_hip_success) return r;
@@ -1155,6 +1261,19 @@ extern "C"
     if (getenv("LIMG_HIP_DEBUG_TIMING")) fprintf(stderr, "worker: %d batches, enqueue %.2f ms, event wait %.2f ms, chain %.2f ms, store enqueue %.2f ms\n", dbgBatches, dbgEnqueue, dbgWait, busy[1], busy[2]);
     if (mergeFailed) return limg_hip_error_MemoryAllocationFailure;
     if (bandError) return limg_hip_error_Generic;
+    if (workerResult == limg_hip_success && c->opt.collect_stats)
+    { // src/limg.cpp:1561-1590 per rectangle: (8 - shift) bits for each of its pixels, and the pixels by shift
+      memset(c->statsHost, 0, sizeof(c->statsHost));
+      for (size_t i = 0; i < c->lastRegions.size(); i++)
+        for (int f = 0; f < 3; f++)
+        {
+          uint32_t sh = (hOut[i].shiftWord >> (8 * f)) & 0xFFu;
+          if (sh > 8) sh = 8;
+          c->statsHost[f] += (uint64_t)(8 - sh) * npx[i];
+          c->statsHost[3 + 9 * f + sh] += npx[i];
+        }
+      c->statsState = 2; c->statsPixels = (uint64_t)sizeX * sizeY;
+    }
     return workerResult;
   }
 
@@ -1178,6 +1297,7 @@ extern "C"
                                             int fastBitCrushing)
   {
     if (!c || !pIn || !pInfo) return limg_hip_error_ArgumentNull;
+    std::lock_guard<std::recursive_mutex> hostLock(c->hostEntry);
     if (sizeX == 0 || sizeY == 0) return limg_hip_error_InvalidParameter;
     HIP_TRY(hipSetDevice(c->device));
     const size_t px = sizeX * sizeY, stride = (px * 4 + 255) & ~(size_t)255;
@@ -1239,9 +1359,9 @@ extern "C"
     memcpy(&id, pId, sizeof(id));
     NCCL_TRY(rccl().CommInitRank(&c->comm, worldSize, id, rank));
     c->commRank = rank; c->commWorld = worldSize;
-    const limg_hip_result r = c->commWords.ensure((8 + (size_t)worldSize) * 8);
+    const limg_hip_result r = c->commWords.ensure((8 + 2 * (size_t)worldSize) * 8); // [0] own value, [1] chain base, [2..3] own (size, capacity), [8 ...] gathered
     if (r != limg_hip_success) return r;
-    HIP_TRY(hipMemset(c->commWords.p, 0, (8 + (size_t)worldSize) * 8));
+    HIP_TRY(hipMemset(c->commWords.p, 0, (8 + 2 * (size_t)worldSize) * 8));
     return limg_hip_success;
   }
 
@@ -1296,15 +1416,17 @@ extern "C"
     hipStream_t s = (hipStream_t)stream;
     const int world = c->commWorld;
     unsigned long long *words = (unsigned long long *)c->commWords.p;
-    // 1. every rank learns every size: one 8-byte all-gather
-    const unsigned long long mine = streamBytes;
-    HIP_TRY(hipMemcpyAsync(words, &mine, 8, hipMemcpyHostToDevice, s));
-    NCCL_TRY(rccl().AllGather(words, words + 8, 1, ncclUint64, c->comm, s));
-    std::vector<uint64_t> sizes(world), offs(world + 1);
-    HIP_TRY(hipMemcpyAsync(sizes.data(), words + 8, (size_t)world * 8, hipMemcpyDeviceToHost, s));
+    // 1. every rank learns every size AND the root's capacity: one 16-byte all-gather.  Whether the pieces fit is then decided by every rank from the same
+    //    numbers -- a root that alone found its buffer too small would leave its peers' sends unmatched
+    const unsigned long long mine[2] = { (unsigned long long)streamBytes, isRoot ? (unsigned long long)capacity : 0ull };
+    HIP_TRY(hipMemcpyAsync(words + 2, mine, 16, hipMemcpyHostToDevice, s));
+    NCCL_TRY(rccl().AllGather(words + 2, words + 8, 2, ncclUint64, c->comm, s));
+    std::vector<uint64_t> pairs(2 * (size_t)world), sizes(world), offs(world + 1);
+    HIP_TRY(hipMemcpyAsync(pairs.data(), words + 8, (size_t)world * 16, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    for (int r = 0; r < world; r++) sizes[r] = pairs[2 * (size_t)r];
     limg_hip_host_gather_offsets(sizes.data(), world, offs.data());
-    if (isRoot && offs[world] > capacity) return limg_hip_error_OutOfBounds; // every rank sees the same sizes: the peers would send into nothing
+    if (offs[world] > pairs[2 * (size_t)root + 1]) return limg_hip_error_OutOfBounds; // on EVERY rank: nothing is posted anywhere
     // 2. exactly the used bytes, point to point: each peer -> root transfer rides one xGMI link
     NCCL_TRY(rccl().GroupStart());
     ncclResult_t posted = ncclSuccess; // a failed post must not leave the group open: close it first, report afterwards

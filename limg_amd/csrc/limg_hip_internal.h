@@ -53,6 +53,7 @@ namespace limg_hip
     int32_t fullPlanes;    // 0: compact mode -- only the three factor planes (+ records / shift words) are written
     // dither noise: byte p of call k = low byte of the 16-bit lane the reference ANDs with ditherSize for pixel p
     const uint8_t *noise;
+    uint32_t noiseLast;    // index of the table's last entry: call indices are clamped to it (a chain base handed in by the caller, limg_hip_encode3d_chain_device phase 2, cannot make the F step read past the table)
     // fused single-kernel path: per-strip look-back descriptors (status << 32 | value), work ticket, error word
     unsigned long long *desc;
     uint32_t *ticket;   // [0] = next strip id
@@ -94,12 +95,15 @@ namespace limg_hip
     uint32_t *status; // bit 0: header mismatch, bit 1: inconsistent payload offsets
   };
 
+  const uint64_t *noise_checkpoints_host(size_t *pCount, size_t *pEvery);
+  void launch_noise_fill(uint8_t *noise, const uint64_t *dCheckpoints, size_t count, hipStream_t s);
   void launch_set_batch_table(ImageIO *dTable, const ImageIO *hTable, size_t count, hipStream_t s);
   void launch_fit_tpb(const EncodeParams &p, int channels, hipStream_t s);
   void launch_fit_search(const EncodeParams &p, int channels, hipStream_t s);
   void launch_encode_persistent(const EncodeParams &p, int channels, int workgroups, hipStream_t s);
   void launch_strip_scan(const EncodeParams &p, hipStream_t s);
   void launch_dither_store(const EncodeParams &p, int channels, hipStream_t s);
+  void launch_shift_stats(const uint32_t *dShifts, uint32_t blocksX, uint32_t blocksY, uint32_t rows, uint32_t sizeX, uint32_t sizeY, unsigned long long *dOut30, hipStream_t s);
   void launch_chain_base(const unsigned long long *dCalls, int rank, unsigned long long *dBase, hipStream_t s);
 
   // ---- merged-block encoder (limg_hip_blocked.hip; reference: limg_blocked_encode3d_test, src/limg.cpp:1774-1885, :2329-2453) ----

@@ -485,7 +485,7 @@ namespace limg_hip
         nz[k] = make_uint2(0u, 0u);
         if (((s - 1u) < 7u) && valid) // shifts 1..7 dither (src/limg.cpp:1951-1958)
         {
-          nz[k] = *reinterpret_cast<const uint2 *>(p.noise + (size_t)call * 64 + r * 8);
+          nz[k] = *reinterpret_cast<const uint2 *>(p.noise + (size_t)min(call, p.noiseLast) * 64 + r * 8);
           call++;
         }
       }
@@ -638,7 +638,7 @@ namespace limg_hip
           nz8[bb][k] = 0;
           if (s != 0 && s != 8)
           {
-            nz8[bb][k] = p.noise[(size_t)call * 64 + lane];
+            nz8[bb][k] = p.noise[(size_t)min(call, p.noiseLast) * 64 + lane];
             call++;
           }
         }
@@ -1732,6 +1732,42 @@ namespace limg_hip
       *base = run;
     }
   }
+  namespace
+  {
+    // The reference's bit statistics (src/limg.cpp:1971-1999, printed at :2232-2248): per factor the bits kept, summed over the pixels, and a histogram of the
+    // pixels by shift -- a function of the per-block shift words and the blocks' pixel counts alone.  out[0..2] += (8 - shift) * n, out[3 + 9 f + shift] += n.
+    __global__ __launch_bounds__(256) void k_shift_stats(const uint32_t *shifts, uint32_t blocksX, uint32_t blocksY, uint32_t rows /* blocksY x images */, uint32_t sizeX, uint32_t sizeY,
+                                                         unsigned long long *out)
+    {
+      __shared__ uint32_t s_acc[30];
+      if (threadIdx.x < 30) s_acc[threadIdx.x] = 0;
+      __syncthreads();
+      const uint64_t total = (uint64_t)blocksX * rows;
+      // a workgroup covers at most 256 * 16 blocks of <= 64 pixels and <= 8 bits each: the 32-bit partial sums cannot overflow
+      const uint64_t begin = (uint64_t)blockIdx.x * 4096u;
+      for (uint64_t i = begin + threadIdx.x; i < min(begin + 4096u, total); i += 256u)
+      {
+        const uint32_t row = (uint32_t)(i / blocksX), bx = (uint32_t)(i - (uint64_t)row * blocksX), by = row % blocksY;
+        const uint32_t rx = min(sizeX - bx * kBlock, (uint32_t)kBlock), ry = min(sizeY - by * kBlock, (uint32_t)kBlock), n = rx * ry;
+        const uint32_t w = shifts[i];
+#pragma unroll
+        for (int f = 0; f < 3; f++)
+        {
+          const uint32_t sh = min((w >> (8 * f)) & 0xFFu, 8u);
+          atomicAdd(&s_acc[f], (8u - sh) * n);
+          atomicAdd(&s_acc[3 + 9 * f + sh], n);
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x < 30 && s_acc[threadIdx.x]) atomicAdd(&out[threadIdx.x], (unsigned long long)s_acc[threadIdx.x]);
+    }
+  }
+  void launch_shift_stats(const uint32_t *dShifts, uint32_t blocksX, uint32_t blocksY, uint32_t rows, uint32_t sizeX, uint32_t sizeY, unsigned long long *dOut30, hipStream_t s)
+  {
+    const uint64_t total = (uint64_t)blocksX * rows;
+    hipLaunchKernelGGL(k_shift_stats, dim3((uint32_t)((total + 4095u) / 4096u)), dim3(256), 0, s, dShifts, blocksX, blocksY, rows, sizeX, sizeY, dOut30);
+  }
+
   void launch_chain_base(const unsigned long long *dCalls, int rank, unsigned long long *dBase, hipStream_t s) { hipLaunchKernelGGL(k_chain_base, dim3(1), dim3(1), 0, s, dCalls, rank, dBase); }
 
   void launch_strip_scan(const EncodeParams &p, hipStream_t s) { hipLaunchKernelGGL(k_strip_scan, dim3(1), dim3(1024), 0, s, p); }

@@ -169,6 +169,18 @@ namespace limg_hip
     return h;
   }
 
+  // Chain values of a chain of full-block calls: pOut[i] = the value call number i * every starts from (pOut[0] = h), for i * every < calls.  Returns the value
+  // after `calls` calls.  (Generator and checker of limg_noise_checkpoints.h.)
+  uint64_t chain_checkpoints(uint64_t h, size_t calls, size_t every, uint64_t *pOut, bool pcg)
+  {
+    for (size_t k = 0; k < calls; k++)
+    {
+      if (pOut && every && k % every == 0) pOut[k / every] = h;
+      h = chain_call(h, 64, nullptr, false, pcg);
+    }
+    return h;
+  }
+
   // Static table for chains made of full 8x8 blocks only: entries [first, first + count) given the chain value at `first`.
   // Returns the chain value after the last generated entry (so the table can be grown later).
   uint64_t fill_noise_table(uint64_t h, uint8_t *noise, size_t count, bool pcg)

@@ -15,11 +15,15 @@
 namespace
 {
   // the reference prints bit statistics to stdout (src/limg.cpp:2232-2258); silence them while a call runs.
+  bool g_keep_stdout = false; // ref_keep_stdout(1): let the statistics through (tools/make_golden_stats.py captures them as golden text)
+
   struct stdout_silencer
   {
     int saved;
     stdout_silencer()
     {
+      saved = -1;
+      if (g_keep_stdout) return;
       fflush(stdout);
       saved = dup(1);
       const int devnull = open("/dev/null", O_WRONLY);
@@ -29,6 +33,7 @@ namespace
     ~stdout_silencer()
     {
       fflush(stdout);
+      if (saved < 0) return;
       dup2(saved, 1);
       close(saved);
     }
@@ -61,6 +66,8 @@ namespace
 
 extern "C"
 {
+  void ref_keep_stdout(int keep) { g_keep_stdout = keep != 0; }
+
   int ref_encode3d(const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, uint32_t **p32 /* 8 planes, limg.h:31 order */, uint8_t **p8 /* A,B,C */, uint32_t errorFactor, int poolThreads, int fast, int dither_mode)
   {
     set_features(dither_mode);

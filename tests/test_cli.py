@@ -58,6 +58,8 @@ def test_single_file_matches_reference(cli, oracle, tmp_path):
     m = re.search(r"Image Perceptual RGB\(A\) PSNR: ([0-9.]+) dB", r.stdout)
     assert m and m.group(1) == "%.2f" % e["psnr"]
     assert re.search(r"Compression Average: ~\s*[0-9.]+ bits per pixel", r.stdout)
+    stats = json.load(open(os.path.join(gu.G, "stats.json")))["original_rgb"]["merged_blocks_stdout"]
+    assert stats[:stats.index("Compression Average")] in r.stdout  # upstream's own "Average Block Bits" block + shift histogram (src/limg.cpp:2232-2248), captured from the real reference
     names = dict(_TGA, limg_bpp="pBitsPerPixel", limg_block_idx_raw="pBlockIndex")
     for f, k in names.items():
         assert oracle.fnv(_read_tga(str(tmp_path / (f + ".tga")))) == e["planes"][k], (f, k)
@@ -72,6 +74,7 @@ def test_single_file_fixed_blocks_matches_reference(cli, oracle, tmp_path):
     m = re.search(r"Image Perceptual RGB\(A\) PSNR: ([0-9.]+) dB \(mean: ([0-9.]+)", r.stdout)
     assert m and m.group(1) == "40.70" and m.group(2) == "49.818"  # 40.6994 dB, mse 49.8179
     assert "decoding it reproduces the decoded image" in r.stdout
+    assert json.load(open(os.path.join(gu.G, "stats.json")))["original_rgb"]["fixed_blocks_stdout"] in r.stdout  # "Average Block Bits: 4.003 (A: 3.650 | B: 0.260 | C: 0.093)" + histogram
     want = gu.hashes()["original_rgb"]
     for f, k in _TGA.items():
         assert oracle.fnv(_read_tga(str(tmp_path / (f + ".tga")))) == want[k], (f, k)

@@ -103,6 +103,11 @@ def test_rccl_world_of_one(oracle):
         dec = g.decode_stream_device(got, n, W, H)
         torch.cuda.synchronize()
         assert np.array_equal(dec.cpu().numpy().view(np.uint32), want["pDecoded"])
+        # an output buffer that is too small: refused (the decision is taken from all-gathered numbers, so every rank of a larger job refuses alike)
+        small = torch.zeros((n // 2 + 15) // 16 * 16, dtype=torch.uint8, device="cuda")
+        with pytest.raises(limg_amd.LimgHipError):
+            g.gather_stream(st, n, root=0, out=small)
+        torch.cuda.synchronize()
         planes = g.alloc_planes_device(W, H)
         g.encode3d_single_chain_device(d_img, True, planes, 0)
         torch.cuda.synchronize()
@@ -113,3 +118,83 @@ def test_rccl_world_of_one(oracle):
         g.check()
     finally:
         g.close()
+
+
+RANK_SCRIPT = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["LIMG_ROOT"])
+import torch
+import torch.distributed as dist
+import limg_amd
+from limg_amd import shard
+from oracle.bind import Oracle, PLANES
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+dist.init_process_group("nccl", device_id=torch.device("cuda", rank))
+orc = Oracle()
+W, H = 512, 256
+img = orc.photo_noise(W, H, 21)
+want = orc.encode3d(img, True)                      # ONE chain over the whole image
+rows = shard.strip_rows(H, world)
+y0, y1 = rows[rank]
+g = limg_amd.LimgHip(rank)
+g.comm_init_from_torch(dist)
+strip = torch.from_numpy(img[y0:y1].view(np.int32)).cuda()
+planes = g.alloc_planes_device(W, y1 - y0)
+g.encode3d_single_chain_device(strip, True, planes, (y0 // 8) * (W // 8))
+torch.cuda.synchronize()
+for k in PLANES:
+    got = planes[k].cpu().numpy()
+    got = got.view(np.uint32) if got.dtype == np.int32 else got
+    assert np.array_equal(got, want[k][y0:y1]), (rank, k)
+# the compact streams of the strips, gathered on rank 0 over RCCL and decoded there
+st, n = g.encode_stream_device(strip, True)
+out = torch.zeros(sum(g.stream_bound(W, b - a) + 16 for a, b in rows), dtype=torch.uint8, device="cuda") if rank == 0 else None
+res = g.gather_stream(st, n, root=0, out=out)
+torch.cuda.synchronize()
+if rank == 0:
+    buf, offs = res
+    for r, (a, b) in enumerate(rows):
+        o0 = int(offs[r]); nb = int(offs[r + 1]) - o0
+        dec = g.decode_stream_device(buf[o0:o0 + nb], nb, W, b - a)
+        torch.cuda.synchronize()
+        # strip-restart streams: each strip's chain starts at the seed, so compare with the strip's own encode
+        assert np.array_equal(dec.cpu().numpy().view(np.uint32), orc.encode3d(img[a:b], True)["pDecoded"]), r
+# an undersized buffer on the root: EVERY rank must return OutOfBounds (no rank may be left with an unmatched send)
+small = torch.zeros(64, dtype=torch.uint8, device="cuda") if rank == 0 else None
+try:
+    g.gather_stream(st, n, root=0, out=small)
+    raise SystemExit("rank %d: undersized gather was accepted" % rank)
+except limg_amd.LimgHipError as e:
+    assert "103" in str(e), str(e)
+torch.cuda.synchronize()
+dist.barrier()
+g.comm_destroy(); g.check(); g.close()
+dist.destroy_process_group()
+print("rank %d ok" % rank)
+"""
+
+
+def test_rccl_two_ranks(tmp_path):
+    """RCCL with MORE than one rank (needs two GPUs: skipped on the one-GPU boxes this repo is developed on, so this path stays unmeasured until a multi-GPU node
+    runs the suite): the single dither chain through two strips against the one-chain oracle, the stream gather + decode on rank 0, and an undersized gather
+    buffer refused by both ranks."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rank.py"
+    script.write_text(RANK_SCRIPT)
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LIMG_ROOT=root,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs

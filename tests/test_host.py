@@ -287,3 +287,23 @@ def test_gather_offsets_and_chain_bases():
     calls = np.array([5, 0, 7, 2 ** 40, 1], dtype=np.uint64)
     assert limg_amd.host_chain_bases(calls).tolist() == [0, 5, 5, 12, 12 + 2 ** 40]
     assert limg_amd.host_gather_offsets(np.array([33], dtype=np.uint64)).tolist() == [0, 48]
+
+
+def test_noise_checkpoints_are_the_chain():
+    """limg_amd/csrc/limg_noise_checkpoints.h (what the GPU fills the noise table from) against a fresh serial walk of the dither chain by the host implementation
+    that tests/golden/chain.json pins to the reference: every one of the 16384 values, and the walk's known answers of SURVEY 8(c) on the way."""
+    import ctypes as C
+    import re
+    import limg_amd
+    L = limg_amd.load_library()
+    text = open(os.path.join(ROOT, "limg_amd", "csrc", "limg_noise_checkpoints.h")).read()
+    every = int(re.search(r"LIMG_NOISE_CHECKPOINT_EVERY (\d+)", text).group(1))
+    count = int(re.search(r"LIMG_NOISE_CHECKPOINT_COUNT (\d+)", text).group(1))
+    vals = np.array([int(x, 16) for x in re.findall(r"0x([0-9a-f]{16})ull", text)], dtype=np.uint64)
+    assert every == 1024 and count == 16384 and vals.size == count
+    walked = np.zeros(count, dtype=np.uint64)
+    L.limg_hip_host_chain_checkpoints(every * count, every, walked.ctypes.data_as(C.c_void_p), 0)
+    assert np.array_equal(vals, walked)
+    first = np.zeros(5, dtype=np.uint64)
+    L.limg_hip_host_chain_checkpoints(5, 1, first.ctypes.data_as(C.c_void_p), 0)
+    assert [hex(int(v)) for v in first] == ["0xca7f00d15badf00d", "0x4ae914d5e23b0473", "0x1db0e1e7cd750f32", "0x13d534ac987485a9", "0xd82d4ba61c55878b"]  # SURVEY 8(c) chain KAT

@@ -386,6 +386,7 @@ static int run_single_file(const Options &o, limg_thread_pool *pool)
   load_or_die(o.files[0], img);
   Planes p(img.count());
   printf("%" PRIu64 " x %" PRIu64 " pixels.\n", (uint64_t)img.w, (uint64_t)img.h);
+  limg_hip_shim::print_stats(true); // upstream's encoders print "Average Block Bits" and the shift histogram themselves (src/limg.cpp:2232-2248)
   const int64_t t0 = CurrentTimeNs();
   limg_result result;
   if (o.fixedBlocks)
