@@ -117,14 +117,17 @@ def cpu_baseline(width, seed, budget_s=30.0):
             res[build]["perf_1thread"] = q.size / best(lambda: ref.encode3d_perf(q, True, error_factor=100, pool_threads=0), 1) / 1e6
         del ref
     head = res.get("fastmath") or res["strict"]
-    key = "test_pool_allcores" if "test_pool_allcores" in head else "test_pool_gpu_share"
-    return {"value": round(head[key], 2), "unit": "Mpixels/s", "cores": pools["pool_allcores"] if key == "test_pool_allcores" else pools["pool_gpu_share"], "kind": "reference",
+    # value = the reference at the pool size that suits it best on this host (its own tool takes all host threads, which on a 256-thread box is its slowest setting:
+    # 1024 one-block-row strips and a polling pool); every setting is listed
+    key = max((k for k in head if k.startswith("test_pool")), key=lambda k: head[k])
+    return {"value": round(head[key], 2), "unit": "Mpixels/s", "cores": pools[key[len("test_"):]], "kind": "reference",
             "cpu": cpu_model(), "host_cores_available": avail, "pools": pools,
             "builds_Mpixels_per_s": {b: {k: round(v, 2) for k, v in d.items()} for b, d in res.items()},
-            "sample": "the whole %dx%d bench image (%.1f Mpx), the real reference compiled by oracle/build_ref.sh; value = its own configuration: -ffast-math build "
-                      "(project.lua:38), a thread pool of ALL %d host threads (src/main.cpp:165; 4 row strips per thread), limg_encode3d_test style (all planes + decode), best "
-                      "of 2; builds_Mpixels_per_s lists fast-math / strict-IEEE x _test / _perf style x pool of 16 / host threads over 8 GPUs (%d) / all host threads / single "
-                      "thread (single thread on the first quarter of the rows)" % (width, width, px / 1e6, pools["pool_allcores"], pools["pool_gpu_share"])}
+            "sample": "the whole %dx%d bench image (%.1f Mpx), the real reference compiled by oracle/build_ref.sh; value = its own build flags (-ffast-math, project.lua:38), "
+                      "limg_encode3d_test style (all planes + decode), at the BEST of three thread-pool sizes (%s; 4 row strips per pool thread, src/limg.cpp:2114-2134), best of 2 runs; "
+                      "builds_Mpixels_per_s lists fast-math / strict-IEEE x _test / _perf style x pool of 16 / host threads over 8 GPUs (%d) / all host threads (%d: what the "
+                      "reference's own tool takes, src/main.cpp:165) / single thread (single thread on the first quarter of the rows)"
+                      % (width, width, px / 1e6, key[len("test_"):], pools["pool_gpu_share"], pools["pool_allcores"])}
 
 
 def run_sharded(args, g, dist, rank, world):
@@ -150,19 +153,30 @@ def run_sharded(args, g, dist, rank, world):
         per = 8 // world
         rows = strips
         units = []
-        for sidx in range(rank * per, (rank + 1) * per):
-            y0, y1 = strips[sidx]
+        if args.single_chain:  # one chain through the whole image: a rank's consecutive strips are one taller strip (any world size that divides 8)
+            strips = [(strips[r * per][0], strips[(r + 1) * per - 1][1]) for r in range(world)]
+            rows = strips
+            y0, y1 = strips[rank]
             units.append((g.synth_device(kind, W, y1 - y0, seed=1, y0=y0), g.alloc_planes_device(W, y1 - y0)))
+        else:
+            for sidx in range(rank * per, (rank + 1) * per):
+                y0, y1 = strips[sidx]
+                units.append((g.synth_device(kind, W, y1 - y0, seed=1, y0=y0), g.alloc_planes_device(W, y1 - y0)))
         total_px = W * H
         name = ("one synthetic %dx%d RGBA %s image as 8 strips of whole block rows with restarted dither chains (== reference with a pool of 2 threads), "
-                "%d strips per rank" % (W, H, kind, per)) + (" -- SINGLE CHAIN through the strips (8-byte all-gather between E and F step)" if args.single_chain else "")
+                "%d strips per rank" % (W, H, kind, per) if not args.single_chain else
+                "one synthetic %dx%d RGBA %s image as %d strips of whole block rows, one per rank, ONE dither chain through all of them (== the reference with pThreadPool == nullptr; "
+                "8-byte all-gather between the E and the F step)" % (W, H, kind, world))
     torch.cuda.synchronize()
 
     single_chain = args.config == 5 and args.single_chain
     if single_chain:
-        if dist is None or dist.get_backend() != "nccl" or 8 != world:
-            raise SystemExit("--single-chain: one strip per rank over RCCL (8 ranks); its exchange-free halves are covered by tests/test_gpu_collective.py")
-        g.comm_init_from_torch(dist)
+        if world == 1:  # a communicator of one rank: the exchange degenerates to a copy (what a one-GPU box can run)
+            g.comm_init(g.comm_unique_id(), 0, 1)
+        elif dist is None or dist.get_backend() != "nccl":
+            raise SystemExit("--single-chain: one strip per rank over RCCL; its exchange-free halves are covered by tests/test_gpu_collective.py")
+        else:
+            g.comm_init_from_torch(dist)
         g._comm_ready = True
         before = [(y0 // 8) * (W // 8) for (y0, _) in strips]
 
@@ -224,7 +238,7 @@ def run_sharded(args, g, dist, rank, world):
         t0 = time.perf_counter()
         if args.config == 5 and args.gather_stream:
             # the north-star's shape: only the bitstream crosses xGMI (limg_hip_gather_stream: RCCL behind the C ABI); rank 0 decodes every strip into its rows
-            per = 8 // world
+            per = 1 if single_chain else 8 // world
             full = torch.empty((H, W), dtype=torch.int32, device="cuda") if rank == 0 else None
             cap = sum(g.stream_bound(W, y1 - y0) + 16 for (y0, y1) in rows[::per][:world]) if rank == 0 else 0
             gbuf = torch.empty(cap, dtype=torch.uint8, device="cuda") if rank == 0 else None
@@ -245,7 +259,7 @@ def run_sharded(args, g, dist, rank, world):
                     y0, y1 = rows[k]
                     assert torch.equal(full[y0:y1], units[k][1]["pDecoded"]), "stream round trip differs from pDecoded"
         elif args.config == 5:
-            per = 8 // world
+            per = 1 if single_chain else 8 // world
             for k in range(per):   # strip k of every rank; rows of the gathered pieces come from the strip table
                 planes = units[k][1] if on_gpu else {n: v.cpu() for n, v in units[k][1].items()}
                 piece_rows = [rows[r * per + k] for r in range(world)]
@@ -524,6 +538,8 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))
 
+    if not os.environ.get("LIMG_KEEP_NCCL_DEBUG"):
+        os.environ["NCCL_DEBUG"] = "WARN"  # RCCL's version banner goes to stdout, where the one JSON line belongs
     import torch
     import numpy as np
     import limg_amd
@@ -660,7 +676,8 @@ def main():
         perf_ms = float(kperf[1:, 0].mean()) if len(kperf) > 1 else None
 
         kavg = kernels.mean(axis=0) if len(kernels) else np.zeros(3)
-        kms = float(kavg.sum())  # fused: k_fit_tpb + k_encode_persistent (or the one persistent launch with --legacy-float-stage); split: the three intervals
+        # the kernels listed in roofline.kernels_ms, nothing else: fused = k_fit_tpb + k_encode_persistent (the one persistent launch with --legacy-float-stage); split = the three intervals
+        kms = float(kavg.sum()) if args.split else (float(kavg[0]) if args.legacy_float_stage else float(kavg[0] + kavg[1]))
         achieved = bytes_per_px * px / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         pmc = pmc_entry(workload_key(args, W, H))
         traffic = None if not pmc or pmc.get("fetch_kib") is None else int((2 * pmc["fetch_kib"] + pmc["write_kib"]) * 1024)  # gfx950: FETCH_SIZE counts half the bytes

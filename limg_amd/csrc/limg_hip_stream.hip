@@ -26,6 +26,8 @@ namespace limg_hip
     constexpr int kTile = 256;
     constexpr int kEntry = 56;
     constexpr int kGroupBytes = 8 * 192; // payload of 8 blocks, worst case
+    constexpr int kPackedLimit = 2700;   // |record value| up to which the packed decode's 16-bit terms are exact (limg_hip_kernels.hip "a9, packed form": 3 * 2700 + 1 < 0x2000)
+    typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
 
     __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
     __device__ __forceinline__ int mad_i24(int a, int b, int c) { int r; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
@@ -237,7 +239,7 @@ namespace limg_hip
     __global__ __launch_bounds__(kTile, 4) void k_stream_decode(const DecodeParams p)
     {
       __shared__ __align__(16) int sNm[kTile][24];
-      __shared__ uint32_t sBits[kTile], sOff[kTile], sMul[kTile], sBx[kTile], sBy[kTile];
+      __shared__ uint32_t sBits[kTile], sOff[kTile], sMul[kTile], sBx[kTile], sBy[kTile], sFlags[kTile];
       __shared__ __align__(16) uint8_t sStage[4][kGroupBytes + 16];
       const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
       const uint32_t tile = blockIdx.x, g = tile * kTile + tid;
@@ -263,7 +265,7 @@ namespace limg_hip
 #pragma unroll
         for (int i = 0; i < 7; i++) { const uint2 v = ep[i]; e[2 * i] = v.x; e[2 * i + 1] = v.y; }
         const uint32_t sw = e[12];
-        uint32_t bits = 0, mul = 0;
+        uint32_t bits = 0, mul = 0, big = 0;
 #pragma unroll
         for (int f = 0; f < 3; f++)
         {
@@ -278,14 +280,28 @@ namespace limg_hip
             const int mnv = (int)(int16_t)(e[f * 4 + (c >> 1)] >> (16 * (c & 1)));
             const int mxv = (int)(int16_t)(e[f * 4 + 2 + (c >> 1)] >> (16 * (c & 1)));
             int n = mxv - mnv, m = mnv;
+            big |= (mnv > kPackedLimit || mnv < -kPackedLimit || mxv > kPackedLimit || mxv < -kPackedLimit) ? 1u : 0u;
             if (c < 3)
             {
               if (s > 7) { n = 0; if (f > 0) m = 0; } // src/limg_decode.h:150-170
             }
             else if (channels == 3) { n = 0; m = 0xFFFF; } // src/limg_decode.h:95-97
             sNm[tid][f * 4 + c] = n;
-            sNm[tid][12 + f * 4 + c] = (int)(((uint32_t)m << 8) + 128u);
+            sNm[tid][12 + f * 4 + c] = (int)(((uint32_t)m << 8) + 128u + (uint32_t)(c < 2 ? (f == 2 ? 0x200000 : 0x300000) : 0)); // R and G carry the packed form's biases
           }
+        }
+        { // per-block flags of the packed decode (same rules as the F step's phase_f_prepare, limg_hip_kernels.hip)
+          uint32_t fl = big;
+          if (channels == 3) fl |= 255u << 8;
+          else
+          {
+            const int a0 = (int)(int16_t)(e[1] >> 16), a1 = (int)(int16_t)(e[3] >> 16), b0 = (int)(int16_t)(e[5] >> 16), b1 = (int)(int16_t)(e[7] >> 16), c0 = (int)(int16_t)(e[9] >> 16),
+                      c1 = (int)(int16_t)(e[11] >> 16); // lane 3 of dirA_min, dirA_max, dirB_offset, dirB_mag, dirC_offset, dirC_mag
+            int a = a0 + b0 + c0;
+            a = a < 0 ? 0 : (a > 255 ? 255 : a);
+            fl |= (a0 != a1 || b0 != b1 || c0 != c1) ? 2u : ((uint32_t)a << 8);
+          }
+          sFlags[tid] = fl;
         }
         sBits[tid] = bits; sMul[tid] = mul; sOff[tid] = e[13];
         const uint32_t by = g / p.blocksX;
@@ -352,6 +368,8 @@ namespace limg_hip
         }
         const uint32_t t = G.t, bw = G.bw, myOff = G.myOff, off0 = G.off0;
         const bool valid = G.valid;
+        const uint32_t fl = valid ? sFlags[t] : 0u;
+        const bool generic = __builtin_amdgcn_ballot_w64((fl & 1u) != 0u) != 0ull, anyAlpha = __builtin_amdgcn_ballot_w64((fl & 2u) != 0u) != 0ull; // wave-uniform
         wave_lds_fence();
         if (valid)
         {
@@ -374,30 +392,71 @@ namespace limg_hip
           const uint32_t mulw = sMul[t];
           const int mulA = (int)(mulw & 0x3FF), mulB = (int)((mulw >> 10) & 0x3FF), mulC = (int)((mulw >> 20) & 0x3FF);
           const int *nm = sNm[t];
-          const int4 nA = *reinterpret_cast<const int4 *>(nm), nB = *reinterpret_cast<const int4 *>(nm + 4), nC = *reinterpret_cast<const int4 *>(nm + 8);
-          const int4 mA = *reinterpret_cast<const int4 *>(nm + 12), mB = *reinterpret_cast<const int4 *>(nm + 16), mC = *reinterpret_cast<const int4 *>(nm + 20);
-          const int nAa[4] = { nA.x, nA.y, nA.z, nA.w }, nBa[4] = { nB.x, nB.y, nB.z, nB.w }, nCa[4] = { nC.x, nC.y, nC.z, nC.w };
-          const int mAa[4] = { mA.x, mA.y, mA.z, mA.w }, mBa[4] = { mB.x, mB.y, mB.z, mB.w }, mCa[4] = { mC.x, mC.y, mC.z, mC.w };
           // values 0..3 of a row sit in the low dword (4 b <= 32 bits), values 4..7 in the low dword of (packed >> 4 b)
           uint32_t lo[3], hi[3];
 #pragma unroll
           for (int k = 0; k < 3; k++) { lo[k] = (uint32_t)packed[k]; hi[k] = (uint32_t)(packed[k] >> (4 * bb[k])); }
           uint32_t px[8];
+          if (!generic)
+          { // a16 in the packed form of the F step (limg_hip_kernels.hip phase_f_rows): factor by factor, per factor three 24-bit multiply-adds per pixel, the R and G
+            // terms packed by one v_perm_b32 (>> 8 included) and biased (0x3000 + 0x3000 + 0x2000 = 0x8000) so that plain 32-bit adds sum the halves independently
+            uint32_t accRG[8];
+            int accB[8], accA[8];
+            const int mulK[3] = { mulA, mulB, mulC };
 #pragma unroll
-          for (int i = 0; i < 8; i++)
-          {
-            // a16: dec_k = value * mul_k; est_c = sum_k (dec_k * n_k[c] + (m_k[c] << 8) + 128) >> 8; clamp.  24-bit multiplies are exact
-            // here (dec <= 255 * 256, |n| <= 65535) and v_mad_i32_i24 keeps the low 32 bits like PMULLD.
-            const int dA = (int)mul_u24(bfe(i < 4 ? lo[0] : hi[0], (i & 3) * bb[0], bb[0]), (uint32_t)mulA);
-            const int dB = (int)mul_u24(bfe(i < 4 ? lo[1] : hi[1], (i & 3) * bb[1], bb[1]), (uint32_t)mulB);
-            const int dC = (int)mul_u24(bfe(i < 4 ? lo[2] : hi[2], (i & 3) * bb[2], bb[2]), (uint32_t)mulC);
-            int e[4];
+            for (int k = 0; k < 3; k++)
+            {
+              const int4 n = *reinterpret_cast<const int4 *>(nm + 4 * k), m = *reinterpret_cast<const int4 *>(nm + 12 + 4 * k);
 #pragma unroll
-            for (int c = 0; c < 4; c++)
-              e[c] = med3_i32(add3(mad_i24(dA, nAa[c], mAa[c]) >> 8, mad_i24(dB, nBa[c], mBa[c]) >> 8, mad_i24(dC, nCa[c], mCa[c]) >> 8), 0, 255);
-            px[i] = lshl_or((uint32_t)e[3], 24, lshl_or((uint32_t)e[2], 16, lshl_or((uint32_t)e[1], 8, (uint32_t)e[0])));
+              for (int i = 0; i < 8; i++)
+              {
+                const int d = (int)mul_u24(bfe(i < 4 ? lo[k] : hi[k], (i & 3) * bb[k], bb[k]), (uint32_t)mulK[k]);
+                const int t0 = mad_i24(d, n.x, m.x), t1 = mad_i24(d, n.y, m.y), t2 = mad_i24(d, n.z, m.z);
+                const uint32_t rg = __builtin_amdgcn_perm((uint32_t)t1, (uint32_t)t0, 0x06050201u);
+                if (k == 0) { accRG[i] = rg; accB[i] = t2 >> 8; } else { accRG[i] += rg; accB[i] += t2 >> 8; }
+                if (anyAlpha)
+                {
+                  const int ta = mad_i24(d, n.w, m.w) >> 8;
+                  if (k == 0) accA[i] = ta; else accA[i] += ta;
+                  asm volatile("" : "+v"(accA[i]));
+                }
+                asm volatile("" : "+v"(accRG[i]), "+v"(accB[i])); // materialised here (otherwise the packing sinks to the next factor's adds and the products stay live)
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            const uint32_t alphaConst = fl & 0xFF00u;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+            {
+              ushort2_t ev = __builtin_bit_cast(ushort2_t, accRG[i]); // estimate + 0x8000 in both halves
+              ev = __builtin_elementwise_max(ev, __builtin_bit_cast(ushort2_t, 0x80008000u));
+              ev = __builtin_elementwise_min(ev, __builtin_bit_cast(ushort2_t, 0x80FF80FFu));
+              uint32_t ba = (uint32_t)med3_i32(accB[i], 0, 255);
+              if (anyAlpha) ba |= (uint32_t)med3_i32(accA[i], 0, 255) << 8; else ba |= alphaConst;
+              px[i] = __builtin_amdgcn_perm(ba, __builtin_bit_cast(uint32_t, ev), 0x05040200u);
+            }
           }
-          if (y < p.sizeY)
+          else
+          { // record values beyond the packed form's range (never from a fit of byte pixels): 32-bit terms, the low 32 bits of the products like PMULLD
+#pragma unroll 1
+            for (int i = 0; i < 8; i++)
+            {
+              const uint32_t sel = (uint32_t)i & 3u;
+              const int dA = (int)mul_u24(bfe(i < 4 ? lo[0] : hi[0], sel * bb[0], bb[0]), (uint32_t)mulA);
+              const int dB = (int)mul_u24(bfe(i < 4 ? lo[1] : hi[1], sel * bb[1], bb[1]), (uint32_t)mulB);
+              const int dC = (int)mul_u24(bfe(i < 4 ? lo[2] : hi[2], sel * bb[2], bb[2]), (uint32_t)mulC);
+              uint32_t out = 0;
+#pragma unroll
+              for (int c = 0; c < 4; c++)
+              {
+                const int bA = c < 2 ? 0x300000 : 0, bC = c < 2 ? 0x200000 : 0;
+                const int est = add3(mad_i24(dA, nm[c], nm[12 + c] - bA) >> 8, mad_i24(dB, nm[4 + c], nm[16 + c] - bA) >> 8, mad_i24(dC, nm[8 + c], nm[20 + c] - bC) >> 8);
+                out |= (uint32_t)med3_i32(est, 0, 255) << (8 * c);
+              }
+              if (y < p.sizeY && x0 + i < p.sizeX) p.out[(size_t)y * p.sizeX + x0 + i] = out;
+            }
+          }
+          if (y < p.sizeY && !generic)
           {
             uint32_t *dst = p.out + (size_t)y * p.sizeX + x0;
             if (rowAligned && x0 + 8 <= p.sizeX)

@@ -26,7 +26,7 @@ def main():
     g = limg_amd.LimgHip(0)
     rng = np.random.default_rng(args.seed)
     t0 = time.time()
-    n = {"fixed": 0, "stream": 0, "blocked": 0}
+    n = {"fixed": 0, "stream": 0, "blocked": 0, "batch": 0}
     last = t0
     while time.time() - t0 < args.seconds:
         w = int(rng.integers(1, args.max_blocks)) * 8 + (int(rng.integers(0, 8)) if rng.random() < 0.4 else 0)
@@ -52,7 +52,7 @@ def main():
         recipe = dict(w=w, h=h, gen=gen, seed=seed, alpha=alpha, ef=ef, fast=fast, pcg=pcg, pool=pool, split=split, legacy=legacy)
         kw = dict(error_factor=ef, fast=fast)
         g.set_options(force_split=split, dither_pcg=pcg, legacy_float_stage=legacy)
-        mode = ["fixed", "stream", "blocked"][int(rng.integers(0, 3))]
+        mode = ["fixed", "stream", "blocked", "batch"][int(rng.integers(0, 4))]
         if mode == "fixed":
             want = orc.encode3d(img, alpha, pool_threads=pool, dither_mode=int(pcg), **kw)
             got = g.encode3d(img, alpha, pool_threads=pool, **kw)
@@ -64,6 +64,24 @@ def main():
             bad = [] if (st.size == ref.size and np.array_equal(st, ref)) else ["stream bytes"]
             if not np.array_equal(g.decode_stream(st), want["pDecoded"]):
                 bad.append("decode")
+        elif mode == "batch":
+            # limg_hip_encode3d_batch_device: 2..4 images of this shape (this one + variations of it) in one launch pair, each against its own single-image oracle encode
+            import torch
+            cnt = int(rng.integers(2, 5))
+            host = [img] + [np.ascontiguousarray(np.roll(img, int(rng.integers(1, 64)), axis=1) ^ np.uint32(int(rng.integers(0, 1 << 24)))) for _ in range(cnt - 1)]
+            dev = [torch.from_numpy(x.view(np.int32)).cuda() for x in host]
+            outs = [g.alloc_planes_device(w, h) for _ in host]
+            g.set_options(force_split=split, dither_pcg=pcg, legacy_float_stage=legacy, test_batch_chunk=int(rng.integers(0, 4)))
+            g.encode3d_batch_device(dev, alpha, outs, pool_threads=pool, **kw)
+            torch.cuda.synchronize()
+            bad = []
+            for x, pl in zip(host, outs):
+                want = orc.encode3d(x, alpha, pool_threads=pool, dither_mode=int(pcg), **kw)
+                for k in PLANES:
+                    got = pl[k].cpu().numpy()
+                    got = got.view(np.uint32) if got.dtype == np.int32 else got
+                    if not np.array_equal(got, want[k]):
+                        bad.append(k)
         else:
             want = orc.blocked_encode3d(img, alpha, dither_mode=int(pcg), **kw)
             got = g.blocked_encode3d(img, alpha, **kw)
