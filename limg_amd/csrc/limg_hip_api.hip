@@ -397,10 +397,12 @@ namespace
       }
       p.timeout = (uint32_t *)c->devStatus.p;
       p.compactOut = compact != nullptr || wantStats; // the statistics are reduced from the raster-order shift words
-      if ((r = c->park.ensure((size_t)(c->persistentWorkgroups / 5 * 6) * 2 * 8192)) != limg_hip_success) return r;
+      if ((r = c->park.ensure((size_t)(c->persistentWorkgroups / 5 * 8) * 2 * 8192)) != limg_hip_success) return r; // room for up to 8 workgroups per CU (A/B builds)
       p.park = (uint8_t *)c->park.p;
       mark(c, stream);
-      launch_encode_persistent(p, channels, p.prefit ? c->persistentWorkgroups / 5 * 6 : c->persistentWorkgroups, stream); // 6 workgroups per CU once the float stage is out (7 fit and were measured: no faster, the kernel is issue-bound)
+      int wgPerCu = p.prefit ? 6 : 5; // 6 workgroups per CU once the float stage is out (7 fit and were measured: no faster)
+      if (const char *e = getenv("LIMG_HIP_WG_PER_CU")) wgPerCu = atoi(e) > 0 ? atoi(e) : wgPerCu; // A/B of builds with other launch bounds (tools/ab.sh)
+      launch_encode_persistent(p, channels, c->persistentWorkgroups / 5 * wgPerCu, stream); // 6 workgroups per CU once the float stage is out (7 fit and were measured: no faster, the kernel is issue-bound)
       mark(c, stream); mark(c, stream);
       if (!p.prefit) mark(c, stream); // 4 events per encode: with the float stage as its own launch the intervals are {k_fit_tpb, k_encode_persistent, -}
       HIP_TRY(hipGetLastError());

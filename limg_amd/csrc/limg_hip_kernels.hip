@@ -189,11 +189,34 @@ namespace limg_hip
     {
       const SearchEntry *tab = reinterpret_cast<const SearchEntry *>(table);
       uint32_t bestA = 0, bestB = 0, bestC = 0, minBe = 0xFFFFFFFFu;
+      // Measured and NOT adopted (LIMG_ACC_CACHE=1 builds it): the accurate search walks the shift cube row by row -- c innermost
+      // (src/limg_bit_crush.h:700-760) -- so factor C's shift changes with nearly every one of its ~70 trials per block while it only takes nine values; its terms for
+      // the shifts 0..7 can be built once per block and picked per trial out of a 16-register vector with the wave-uniform shift as the index (VGPR index mode:
+      // s_set_gpr_idx_on, two v_mov, s_set_gpr_idx_off; one 16-wide vector because LLVM expands a dynamic extract of up to 8 elements into compares and selects).
+      // At equal occupancy that is 2 % faster (4.39 vs 4.49 ms at 5 workgroups per CU), but its 16 registers cost the sixth workgroup per CU, which is worth 7.5 %
+      // (4.16 ms without the cache at 6).
+#ifndef LIMG_ACC_CACHE
+#define LIMG_ACC_CACHE 0
+#endif
+      typedef uint32_t u32x16_t __attribute__((ext_vector_type(16)));
+      u32x16_t cT;
+      if (LIMG_ACC_CACHE)
+      {
+        constexpr uint32_t mulOf[8] = { 1, 2, 4, 8, 17, 36, 85, 255 }; // (1 << s) + decode_bias(s)
+#pragma unroll
+        for (int sft = 0; sft < 8; sft++)
+        {
+          uint32_t rg; int bl;
+          make_terms(t.fC, (uint32_t)sft, mulOf[sft], t.nC, t.mC, rg, bl);
+          cT[sft] = rg; cT[8 + sft] = (uint32_t)bl;
+        }
+      }
       { // the first triple is the fast search's: built unconditionally, so that the cached terms need no initial value
         constexpr uint32_t root[8] = LIMG_SEARCH_ROOT;
         rebuild_A(t, root[0] & 31u, root[5]);
         rebuild_B(t, root[3], root[6]);
-        rebuild_C(t, root[4], root[7]);
+        if (LIMG_ACC_CACHE) { t.tC_RG = cT[root[4]]; t.tC_B = (int)cT[8 + root[4]]; t.cC = root[4]; }
+        else rebuild_C(t, root[4], root[7]);
       }
       uint8s_t e = sload8(tab, 0u);
       while (!(e[0] >> 31))
@@ -201,7 +224,14 @@ namespace limg_hip
         const uint32_t a = e[0] & 31u;
         if (a != t.cA) rebuild_A(t, a, e[5]);
         if (e[3] != t.cB) rebuild_B(t, e[3], e[6]);
-        if (e[4] != t.cC) rebuild_C(t, e[4], e[7]);
+        if (!LIMG_ACC_CACHE) { if (e[4] != t.cC) rebuild_C(t, e[4], e[7]); }
+        else if (e[4] != t.cC)
+        {
+          const uint32_t c = e[4];
+          if (c > 7) { t.tC_RG = (uint32_t)term_bias(2) * 0x10001u; t.tC_B = 0; }
+          else { t.tC_RG = cT[c]; t.tC_B = (int)cT[8 + c]; }
+          t.cC = c;
+        }
         const uint32_t err = trial_pixel_error<FULL>(t, active);
         uint32_t off = e[2];
         if (__builtin_amdgcn_ballot_w64(err > maxPixel32) == 0ull)
@@ -312,6 +342,23 @@ namespace limg_hip
         }
         reinterpret_cast<uint4 *>(L.cst)[k * kStripBlocks + sb] = make_uint4(v, v, v, v);
       }
+      if (lane < kBlocksPerWave)
+      { // per-block flags of the decode: whether the alpha lane is one value for the block (and which); bit 0 -- a record value beyond the packed form's range, never
+        // from a fit of byte pixels -- is OR-ed in below by whichever lane meets such a value
+        const int sb = wave * kBlocksPerWave + lane;
+        const int16_t *rec = L.rec + sb * L.recStride;
+        uint32_t fl;
+        if (CH == 3) fl = 255u << 8; // src/limg_decode.h:95-97: the three 0xFFFF minima clamp to 255
+        else
+        {
+          const bool varies = rec[7] != rec[3] || rec[15] != rec[11] || rec[23] != rec[19]; // an alpha normal (max - min) is never zeroed, not even at shift 8 (SURVEY 0.7)
+          int a = rec[3] + rec[11] + rec[19]; // ((m << 8) + 128) >> 8 == m for each of the three terms
+          a = a < 0 ? 0 : (a > 255 ? 255 : a);
+          fl = varies ? 2u : ((uint32_t)a << 8);
+        }
+        L.flags[sb] = fl;
+      }
+      wave_lds_fence();
 #pragma unroll
       for (int r = 0; r < 2; r++)
       {
@@ -321,7 +368,9 @@ namespace limg_hip
           const int b = idx / 12, fc = idx - b * 12, f = fc >> 2, c = fc & 3, sb = wave * kBlocksPerWave + b;
           const int16_t *rec = L.rec + sb * L.recStride;
           const uint32_t sh = (L.shift[sb] >> (8 * f)) & 0xFF;
-          int n = rec[f * 8 + 4 + c] - rec[f * 8 + c], m = rec[f * 8 + c];
+          const int lo = rec[f * 8 + c], hi = rec[f * 8 + 4 + c];
+          if ((uint32_t)(lo + recordLimit) > 2u * (uint32_t)recordLimit || (uint32_t)(hi + recordLimit) > 2u * (uint32_t)recordLimit) atomicOr(&L.flags[sb], 1u); // |value| > limit
+          int n = hi - lo, m = lo;
           if (c < 3)
           {
             if (sh > 7) { n = 0; if (f > 0) m = 0; }
@@ -331,24 +380,6 @@ namespace limg_hip
           dst[f * 4 + c] = n;
           dst[12 + f * 4 + c] = (int)(((uint32_t)m << 8) + 128u + (uint32_t)(c < 2 ? (f == 2 ? 0x200000 : 0x300000) : 0)); // + decode_bias(f, c)
         }
-      }
-      if (lane < kBlocksPerWave)
-      { // per-block flags of the decode: records beyond the packed form's range (never from a fit of byte pixels), and whether the alpha lane is one value for the block
-        const int sb = wave * kBlocksPerWave + lane;
-        const int16_t *rec = L.rec + sb * L.recStride;
-        uint32_t big = 0;
-#pragma unroll
-        for (int i = 0; i < 24; i++) { const int v = rec[i]; big |= (v > recordLimit || v < -recordLimit) ? 1u : 0u; }
-        uint32_t fl = big;
-        if (CH == 3) fl |= 255u << 8; // src/limg_decode.h:95-97: the three 0xFFFF minima clamp to 255
-        else
-        {
-          const bool varies = rec[7] != rec[3] || rec[15] != rec[11] || rec[23] != rec[19]; // an alpha normal (max - min) is never zeroed, not even at shift 8 (SURVEY 0.7)
-          int a = rec[3] + rec[11] + rec[19]; // ((m << 8) + 128) >> 8 == m for each of the three terms
-          a = a < 0 ? 0 : (a > 255 ? 255 : a);
-          fl |= varies ? 2u : ((uint32_t)a << 8);
-        }
-        L.flags[sb] = fl;
       }
     }
 
@@ -907,7 +938,9 @@ namespace limg_hip
     // PREFIT: the float stage already ran in k_fit_tpb (limg_hip_fit_tpb.hip, one lane per block); this step loads the records and goes on with phase E.
     // id: the strip's number in ticket / look-back order (all images of a batch); local: its number inside its image (geometry); rowBase: the image's first
     // block row in the per-block scratch arrays; head0: the id of the image's first strip
-    template <int CH, bool PERSIST, bool FAST, bool PREFIT, class P, class IO>
+    // ACC: the accurate search (fastBitCrushing == false) instead of the default one -- a kernel variant of its own, so that neither search's registers and code
+    // weigh on the other
+    template <int CH, bool PERSIST, bool FAST, bool PREFIT, bool ACC, class P, class IO>
     __device__ __forceinline__ void fit_search_strip(const P &p, const IO &io, const uint32_t id, const uint32_t local, const uint32_t rowBase, const uint32_t head0, uint8_t *lds,
                                                      uint8_t *park, const int tid)
     {
@@ -1365,9 +1398,7 @@ namespace limg_hip
             t.mA[0] += (int)(R << 8); t.mA[1] += (int)(G << 8); t.mA[2] += t.pxB << 8;
             // (the flag goes through an opaque scalar: hoisted out of the block loop as a boolean it comes back as a lane mask that is negated with two vector
             //  instructions per block)
-            int fastNow = p.fast;
-            asm volatile("" : "+s"(fastNow));
-            if (fastNow)
+            if (!ACC)
             {
               if (n == 64) search_fast_automaton<true>(t, true, p.maxPixel32, blockLimit, shift);
               else search_fast_automaton<false>(t, active, p.maxPixel32, blockLimit, shift);
@@ -1382,7 +1413,7 @@ namespace limg_hip
           {
             // out-of-range record (never produced by a fit of byte pixels; kept so that no input can break exactness):
             // generic 32-bit trial, deliberately a real call so that none of it is speculated into the common path
-            const uint32_t packed = (uint32_t)sgpr((int)search_generic(px, fA, fB, fC, blkE->rec, active, p.maxPixel32, maxBlockN, p.fast != 0)); // uniform: keeps the shift triple (and the bookkeeping below) on the scalar unit for the common path too
+            const uint32_t packed = (uint32_t)sgpr((int)search_generic(px, fA, fB, fC, blkE->rec, active, p.maxPixel32, maxBlockN, !ACC)); // uniform: keeps the shift triple (and the bookkeeping below) on the scalar unit for the common path too
             shift[0] = packed & 0xFF; shift[1] = (packed >> 8) & 0xFF; shift[2] = (packed >> 16) & 0xFF;
           }
         }
@@ -1606,11 +1637,11 @@ namespace limg_hip
     }
 
     // ---- kernels ---------------------------------------------------------------------------------------------------------
-    template <int CH, bool FAST, bool PREFIT>
+    template <int CH, bool FAST, bool PREFIT, bool ACC>
     __global__ __launch_bounds__(kThreads) void k_fit_search(const EncodeParams p)
     {
       __shared__ __attribute__((aligned(16))) uint8_t s_lds[lds_layout<PREFIT>().total];
-      fit_search_strip<CH, false, FAST, PREFIT>(p, p.io, blockIdx.x, blockIdx.x, 0u, 0u, s_lds, nullptr, (int)threadIdx.x);
+      fit_search_strip<CH, false, FAST, PREFIT, ACC>(p, p.io, blockIdx.x, blockIdx.x, 0u, 0u, s_lds, nullptr, (int)threadIdx.x);
     }
 
     template <int CH>
@@ -1630,8 +1661,11 @@ namespace limg_hip
     // earlier strip has long published its call count, so the look-back does not wait; and since the workgroups of a CU
     // drift apart, E and F steps of different workgroups overlap on every CU.
     // Progress: a look-back only waits for strips with smaller tickets; those were drawn earlier, and an E step never waits.
-    template <int CH, bool FAST, bool PREFIT>
-    __global__ __launch_bounds__(kThreads, PREFIT ? 6 : 5) void k_encode_persistent(const EncodeParams p)
+    template <int CH, bool FAST, bool PREFIT, bool ACC>
+#ifndef LIMG_ACC_WG
+#define LIMG_ACC_WG 6
+#endif
+    __global__ __launch_bounds__(kThreads, PREFIT ? (ACC ? LIMG_ACC_WG : 6) : 5) void k_encode_persistent(const EncodeParams p)
     {
       __shared__ __attribute__((aligned(16))) uint8_t s_lds[lds_layout<PREFIT>().total];
       __shared__ uint32_t s_ticket;
@@ -1668,7 +1702,7 @@ namespace limg_hip
         {
           if (pe->batchCount > 1) img = t / pe->imageStrips; // once per strip, on the scalar unit
           const uint32_t head0 = img * pe->imageStrips;
-          fit_search_strip<CH, true, FAST, PREFIT>(*pe, *io_of(pe, img), t, t - head0, img * pe->blocksY, head0, s_lds, park + slot * kParkBytes, tid_e);
+          fit_search_strip<CH, true, FAST, PREFIT, ACC>(*pe, *io_of(pe, img), t, t - head0, img * pe->blocksY, head0, s_lds, park + slot * kParkBytes, tid_e);
         }
         if (prev != 0xFFFFFFFFu)
         {
@@ -1691,22 +1725,28 @@ namespace limg_hip
     }
   } // namespace
 
-  // kernel variant by (channels, float mode, float stage already done by k_fit_tpb)
-#define LIMG_DISPATCH(KERNEL, GRID, BLOCK, S, P)                                                        \
+  // kernel variant by (channels, float mode, float stage already done by k_fit_tpb, accurate search)
+#define LIMG_DISPATCH_ACC(KERNEL, GRID, BLOCK, S, P, ACC)                                               \
   do                                                                                                    \
   {                                                                                                     \
     const int v_ = (channels == 4 ? 4 : 0) | ((P).floatFast ? 2 : 0) | ((P).prefit ? 1 : 0);            \
     switch (v_)                                                                                         \
     {                                                                                                   \
-    case 0: hipLaunchKernelGGL((KERNEL<3, false, false>), GRID, BLOCK, 0, S, P); break;                 \
-    case 1: hipLaunchKernelGGL((KERNEL<3, false, true>), GRID, BLOCK, 0, S, P); break;                  \
-    case 2: hipLaunchKernelGGL((KERNEL<3, true, false>), GRID, BLOCK, 0, S, P); break;                  \
-    case 3: hipLaunchKernelGGL((KERNEL<3, true, true>), GRID, BLOCK, 0, S, P); break;                   \
-    case 4: hipLaunchKernelGGL((KERNEL<4, false, false>), GRID, BLOCK, 0, S, P); break;                 \
-    case 5: hipLaunchKernelGGL((KERNEL<4, false, true>), GRID, BLOCK, 0, S, P); break;                  \
-    case 6: hipLaunchKernelGGL((KERNEL<4, true, false>), GRID, BLOCK, 0, S, P); break;                  \
-    default: hipLaunchKernelGGL((KERNEL<4, true, true>), GRID, BLOCK, 0, S, P); break;                  \
+    case 0: hipLaunchKernelGGL((KERNEL<3, false, false, ACC>), GRID, BLOCK, 0, S, P); break;            \
+    case 1: hipLaunchKernelGGL((KERNEL<3, false, true, ACC>), GRID, BLOCK, 0, S, P); break;             \
+    case 2: hipLaunchKernelGGL((KERNEL<3, true, false, ACC>), GRID, BLOCK, 0, S, P); break;             \
+    case 3: hipLaunchKernelGGL((KERNEL<3, true, true, ACC>), GRID, BLOCK, 0, S, P); break;              \
+    case 4: hipLaunchKernelGGL((KERNEL<4, false, false, ACC>), GRID, BLOCK, 0, S, P); break;            \
+    case 5: hipLaunchKernelGGL((KERNEL<4, false, true, ACC>), GRID, BLOCK, 0, S, P); break;             \
+    case 6: hipLaunchKernelGGL((KERNEL<4, true, false, ACC>), GRID, BLOCK, 0, S, P); break;             \
+    default: hipLaunchKernelGGL((KERNEL<4, true, true, ACC>), GRID, BLOCK, 0, S, P); break;             \
     }                                                                                                   \
+  } while (0)
+#define LIMG_DISPATCH(KERNEL, GRID, BLOCK, S, P)                                                        \
+  do                                                                                                    \
+  {                                                                                                     \
+    if ((P).fast || !(P).crushBits) LIMG_DISPATCH_ACC(KERNEL, GRID, BLOCK, S, P, false);                \
+    else LIMG_DISPATCH_ACC(KERNEL, GRID, BLOCK, S, P, true);                                            \
   } while (0)
 
   void launch_fit_search(const EncodeParams &p, int channels, hipStream_t s)
