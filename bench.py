@@ -292,7 +292,8 @@ def run_sharded(args, g, dist, rank, world):
         kavg = kernels.mean(axis=0) if len(kernels) else np.zeros(3)
         ksum = float(kavg.sum())  # k_fit_tpb + k_encode_persistent of one unit (single chain: the E/scan, exchange and F intervals)
         px_per_launch = (units[0][0].numel() if units else 0) * (len(units) if batched else 1)
-        pmc = pmc_entry("config%d_%s%s" % (args.config, "batched" if batched else "single", "" if args.contexts == 1 else "_ctx%d" % args.contexts))
+        pmc_key = "config%d_%s%s" % (args.config, "batched" if batched else "single", "" if args.contexts == 1 else "_ctx%d" % args.contexts)
+        pmc = pmc_entry(pmc_key)
         achieved = ALGO_BYTES_PER_PX * px_per_launch / (ksum * 1e-3) / 1e9 if ksum > 0 else 0.0
         line = {
             "metric": "encode Mpixels/s, RGBA (limg_encode3d_test-equivalent: all 11 planes stored), BASELINE configs[%d]" % (args.config - 1),
@@ -305,7 +306,8 @@ def run_sharded(args, g, dist, rank, world):
                        "gather_backend": None if dist is None else dist.get_backend(), "gathered": "LMG3 streams, decoded on rank 0" if args.gather_stream else "planes"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": None if not pmc or pmc.get("fetch_kib") is None else int((2 * pmc["fetch_kib"] + pmc["write_kib"]) * 1024),
-                         "valu_busy": None if not pmc else pmc.get("valu_busy"), "pmc_source": None if not pmc else pmc.get("source"),
+                         "valu_busy": None if not pmc else pmc.get("valu_busy"), "pmc_source": None if not pmc else pmc.get("source"), "pmc_key": pmc_key,
+                         "valu_instr_per_block": None if not pmc or not pmc.get("valu_instr_per_launch") else round(pmc["valu_instr_per_launch"] / (px_per_launch / 64.0), 1),
                          "algorithmic_bytes_per_launch": int(ALGO_BYTES_PER_PX * px_per_launch), "launch_pairs_per_step": launches_per_step,
                          "kernels_ms": {"k_fit_tpb": round(float(kavg[0]), 4), "k_encode_persistent": round(float(kavg[1]), 4)} if not single_chain else
                                        {"E step + scan": round(float(kavg[0]), 4), "all-gather + base": round(float(kavg[1]), 4), "F step": round(float(kavg[2]), 4)},
@@ -460,7 +462,9 @@ def run_stream(args, g, dist, rank, world, W, H):
             "config": {"workload": "synthetic %dx%d RGBA %s (seed 1+rank) per GPU, errorFactor %d" % (W, H, args.workload, args.error_factor),
                        "stream_bytes": int(nbytes), "stream_bytes_per_px": round(nbytes / px, 4), "roundtrip_equals_pDecoded": same,
                        "decode_Mpixels_per_s": round(world * px * args.steps / el_d / 1e6, 1), "decode_ms_per_step": round(el_d * 1e3 / args.steps, 4)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": None if not pmc_entry("stream_%dx%d_%s" % (W, H, args.workload)) else int((2 * pmc_entry("stream_%dx%d_%s" % (W, H, args.workload))["fetch_kib"] + pmc_entry("stream_%dx%d_%s" % (W, H, args.workload))["write_kib"]) * 1024),
+                         "valu_busy": (pmc_entry("stream_%dx%d_%s" % (W, H, args.workload)) or {}).get("valu_busy"), "pmc_key": "stream_%dx%d_%s" % (W, H, args.workload),
                          "algorithmic_bytes_per_launch": int(dec_bytes),
                          "kernels_ms": {"k_fit_tpb+k_encode_persistent": round(enc_ms, 4), "k_stream_count+scan+pack": round(pack_ms, 4), "k_stream_decode": round(dec_ms, 4)},
                          "note": "roofline object = k_stream_decode: (stream bytes + 4 B/px written) / its average duration"},

@@ -1564,8 +1564,11 @@ namespace limg_hip
 
       if (PERSIST)
       {
+        // (rolled on purpose: unrolled, the second loop became 19 dword loads and ~100 vector instructions of address arithmetic per wave; its 384 dwords go as 96 16-byte pieces)
+        static_assert(kStripBlocks * 12 * 4 == 96 * 16, "record copy");
+#pragma unroll 1
         for (int i = tid; i < 384; i += kThreads) *reinterpret_cast<uint4 *>(L.fac + (i >> 4) * kFacRow + (i & 15) * 16) = reinterpret_cast<const uint4 *>(park + kParkFac)[i];
-        for (int i = tid; i < kStripBlocks * 12; i += kThreads) reinterpret_cast<uint32_t *>(s_rec)[i] = reinterpret_cast<const uint32_t *>(park + kParkRec)[i];
+        if (tid < 96) reinterpret_cast<uint4 *>(s_rec)[tid] = reinterpret_cast<const uint4 *>(park + kParkRec)[tid];
         if (tid < kStripBlocks) L.shift[tid] = (uint32_t)tid < nBlocks ? reinterpret_cast<const uint32_t *>(park + kParkShift)[tid] : 0u; // nothing is parked for blocks past the right edge
       }
       else
