@@ -132,7 +132,9 @@ namespace
   constexpr size_t kNoiseChunk = 1u << 16; // table growth granularity (entries)
 
   // The accurate search's automaton (tools/make_search_table.py, src/limg_bit_crush.h:668-830) in the form the kernel's scalar loads want: 8 dwords per state,
-  // every field in a dword of its own = { a | phase2 << 5 | final << 31, byte offset on pass, byte offset on fail, b, c, mul(a), mul(b), mul(c) }.
+  // every field in a dword of its own = { a | phase2 << 5 | final << 31, byte offset on pass, byte offset on fail, b, c, mul(a), mul(b), mul(c) }.  Bits 24..26 of the two
+  // offsets say which factors' shifts the SUCCESSOR's triple changes against this state's (A, B, C): a state of this DAG has several predecessors, so the change mask is a
+  // property of the edge -- with it the kernel needs no record of the shifts its cached terms were built for and no three compares per trial.
   limg_hip_result ensure_accurate_table(limg_hip_context *c)
   {
     if (c->accTable.p) return limg_hip_success;
@@ -149,6 +151,19 @@ namespace
       e[1] = (w1 & 0xFFFFu) * 32u; e[2] = (w1 >> 16) * 32u;
       e[3] = b; e[4] = cc;
       e[5] = mul[a]; e[6] = mul[b]; e[7] = mul[cc];
+    }
+    static_assert((size_t)LIMG_SEARCH_ACC_STATES * 32u < (1u << 24), "offsets leave bits 24..26 free");
+    for (size_t i = 0; i < (size_t)LIMG_SEARCH_ACC_STATES; i++)
+    {
+      uint32_t *e = &wide[i * 8];
+      if (e[0] >> 31) continue;
+      for (int k = 1; k <= 2; k++)
+      {
+        const uint32_t *n = &wide[(e[k] / 32u) * 8];
+        uint32_t mask = 0;
+        if (!(n[0] >> 31)) mask = ((n[0] & 31u) != (e[0] & 31u) ? 1u : 0u) | (n[3] != e[3] ? 2u : 0u) | (n[4] != e[4] ? 4u : 0u);
+        e[k] |= mask << 24;
+      }
     }
     limg_hip_result r = c->accTable.ensure(wide.size() * 4);
     if (r != limg_hip_success) return r;

@@ -219,19 +219,24 @@ namespace limg_hip
         else rebuild_C(t, root[4], root[7]);
       }
       uint8s_t e = sload8(tab, 0u);
+      // which factors state 0's triple changes against the root triple built above (every later edge carries its mask in bits 24..26 of the successor offset)
+      constexpr uint32_t rootT[8] = LIMG_SEARCH_ROOT;
+      uint32_t mask = ((e[0] & 31u) != (rootT[0] & 31u) ? 1u : 0u) | (e[3] != rootT[3] ? 2u : 0u) | (e[4] != rootT[4] ? 4u : 0u);
       while (!(e[0] >> 31))
       {
         const uint32_t a = e[0] & 31u;
-        if (a != t.cA) rebuild_A(t, a, e[5]);
-        if (e[3] != t.cB) rebuild_B(t, e[3], e[6]);
-        if (!LIMG_ACC_CACHE) { if (e[4] != t.cC) rebuild_C(t, e[4], e[7]); }
-        else if (e[4] != t.cC)
+        if (mask & 1u) rebuild_A(t, a, e[5]);
+        if (mask & 2u) rebuild_B(t, e[3], e[6]);
+        if (LIMG_ACC_CACHE)
         {
-          const uint32_t c = e[4];
-          if (c > 7) { t.tC_RG = (uint32_t)term_bias(2) * 0x10001u; t.tC_B = 0; }
-          else { t.tC_RG = cT[c]; t.tC_B = (int)cT[8 + c]; }
-          t.cC = c;
+          if (mask & 4u)
+          {
+            const uint32_t c = e[4];
+            if (c > 7) { t.tC_RG = (uint32_t)term_bias(2) * 0x10001u; t.tC_B = 0; }
+            else { t.tC_RG = cT[c]; t.tC_B = (int)cT[8 + c]; }
+          }
         }
+        else if (mask & 4u) rebuild_C(t, e[4], e[7]);
         const uint32_t err = trial_pixel_error<FULL>(t, active);
         uint32_t off = e[2];
         if (__builtin_amdgcn_ballot_w64(err > maxPixel32) == 0ull)
@@ -243,7 +248,8 @@ namespace limg_hip
             if (!(e[0] & 0x20u) || be < minBe) { bestA = a; bestB = e[3]; bestC = e[4]; minBe = be; }
           }
         }
-        e = sload8(tab, off);
+        mask = off >> 24;
+        e = sload8(tab, off & 0xFFFFFFu);
       }
       shift[0] = bestA; shift[1] = bestB; shift[2] = bestC;
     }
