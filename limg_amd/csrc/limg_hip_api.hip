@@ -80,6 +80,7 @@ struct limg_hip_context
   int device = 0;
   limg_hip_options opt;
   DevBuf records, shifts, stripCalls, stripBase; // per-block / per-strip scratch
+  DevBuf invN;                                   // per block 1 / |normal|^2 of the three factors (k_fit_tpb -> E step)
   DevBuf noise;                                  // static dither noise table (full-block chains)
   bool noisePcg = false;                         // which generator the table was built with
   size_t noiseCount = 0;                         // entries generated so far
@@ -312,6 +313,8 @@ namespace
     else { if ((r = c->records.ensure(blocks * sizeof(limg_hip_block_record))) != limg_hip_success) return r; p.records = (limg_hip_block_record *)c->records.p; }
     if (compact && compact->pShifts) p.shifts = compact->pShifts;
     else { if ((r = c->shifts.ensure(blocks * 4)) != limg_hip_success) return r; p.shifts = (uint32_t *)c->shifts.p; }
+    if ((r = c->invN.ensure(blocks * 16)) != limg_hip_success) return r;
+    p.invN = (float *)c->invN.p;
     if ((r = c->stripCalls.ensure(strips * 4)) != limg_hip_success) return r;
     if ((r = c->stripBase.ensure(strips * 4)) != limg_hip_success) return r;
     p.stripCalls = (uint32_t *)c->stripCalls.p; p.stripBase = (uint32_t *)c->stripBase.p;
@@ -531,7 +534,7 @@ extern "C"
     limg_hip_context *c = *ppCtx;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = { &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->noiseCk, &c->stats, &c->lookback, &c->devStatus, &c->accTable, &c->commWords, &c->park, &c->batchTable, &c->in, &c->planes, &c->cmp,
+    DevBuf *bufs[] = { &c->invN, &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->noiseCk, &c->stats, &c->lookback, &c->devStatus, &c->accTable, &c->commWords, &c->park, &c->batchTable, &c->in, &c->planes, &c->cmp,
                        &c->streamFac, &c->streamTiles, &c->streamStatus, &c->streamBuf,
                        &c->bFlags, &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bV, &c->bFac, &c->bNoise, &c->bNoiseBase };
     for (DevBuf *b : bufs) b->release();

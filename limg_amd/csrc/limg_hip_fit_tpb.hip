@@ -30,7 +30,9 @@ namespace limg_hip
     template <bool DIRECT> constexpr int tpb_waves() { return DIRECT ? 4 : 2; } // waves per workgroup: they share one copy of the table
 
     template <int CH, bool FAST, bool DIRECT>
-    __global__ __launch_bounds__(64 * tpb_waves<DIRECT>()) void k_fit_tpb(const EncodeParams p)
+    // (8 waves per SIMD asked for explicitly: left to itself the compiler settles on 61 registers or on 132 depending on details of the epilogue; measured equal in
+    //  speed on large images -- the kernel is issue-bound -- but a 4096^2 image is a single round of 4096 waves, where residency is what there is)
+    __global__ __launch_bounds__(64 * tpb_waves<DIRECT>(), DIRECT ? ((FAST && CH == 3) ? 7 : 8) : 1) void k_fit_tpb(const EncodeParams p)
     {
       constexpr int kTpbWaves = tpb_waves<DIRECT>();
       __shared__ __attribute__((aligned(16))) uint32_t s_pxAll[kTpbWaves][DIRECT ? 4 : 64 * kTpbStride];
@@ -252,30 +254,47 @@ namespace limg_hip
       uint32_t words[16];
 #pragma unroll
       for (int c = 0; c < 4; c++) words[c] = __float_as_uint(comp(avg, c));
-      int16_t rec[24];
+      // Factor by factor, so that nothing but the factor's eight values is live: the record's int16 pairs, and -- a7 (limg_init_color_error_state_3d,
+      // src/limg_internal.h:426-452) -- 1 / (n . n) of the INTEGER normal max - min in the serial limg_dot order, 0 for an all-zero normal.  Here that is three
+      // divisions per 64 blocks; in the E step (lane == pixel, one lane per (block, factor, channel)) it was four DPP broadcasts and a correctly rounded division per
+      // lane and strip: ~7 vector instructions per block.
+      float inv[3];
 #pragma unroll
-      for (int k = 0; k < 6; k++)
+      for (int r = 0; r < 3; r++)
       {
-        const int r = k >> 1;
         const bool dead = r == 0 ? deadA : (r == 1 ? deadB : deadC);
         const V4 &dir = r == 0 ? dirA : (r == 1 ? dirB : dirC);
+        int16_t lo[4], hi[4];
+        float sum = 0.0f;
+        bool nz = false;
 #pragma unroll
         for (int c = 0; c < 4; c++)
         {
-          float m = mm[k], dv = comp(dir, c);
-          if (dead) { m = 0.0f; dv = 0.0f; }
-          float val = m * dv;
-          if (r == 0) val = comp(avg, c) + val;
-          int q = cvt_rne(val);
-          if (CH == 3 && c == 3) q = 0;
-          rec[k * 4 + c] = (int16_t)q;
+          float dv = comp(dir, c), mLo = mm[2 * r], mHi = mm[2 * r + 1];
+          if (dead) { mLo = 0.0f; mHi = 0.0f; dv = 0.0f; }
+          float vLo = mLo * dv, vHi = mHi * dv;
+          if (r == 0) { vLo = comp(avg, c) + vLo; vHi = comp(avg, c) + vHi; }
+          int qLo = cvt_rne(vLo), qHi = cvt_rne(vHi);
+          if (CH == 3 && c == 3) { qLo = 0; qHi = 0; }
+          lo[c] = (int16_t)qLo; hi[c] = (int16_t)qHi;
+          if (CH == 4 || c < 3)
+          {
+            const float n = (float)((int)hi[c] - (int)lo[c]);
+            const float sq = n * n;
+            sum = sum + sq; // ((0 + s0) + s1) + s2 (+ s3)
+            nz = nz || sq != 0.0f;
+          }
         }
+        inv[r] = nz ? (FAST ? __builtin_amdgcn_rcpf(sum) : 1.0f / sum) : 0.0f;
+        words[4 + 4 * r] = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+        words[5 + 4 * r] = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+        words[6 + 4 * r] = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+        words[7 + 4 * r] = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
       }
-#pragma unroll
-      for (int i = 0; i < 12; i++) words[4 + i] = (uint32_t)(uint16_t)rec[2 * i] | ((uint32_t)(uint16_t)rec[2 * i + 1] << 16);
       uint4 *dst = reinterpret_cast<uint4 *>(p.records + (size_t)byS * p.blocksX + bx0 + lane);
 #pragma unroll
       for (int i = 0; i < 4; i++) dst[i] = make_uint4(words[4 * i], words[4 * i + 1], words[4 * i + 2], words[4 * i + 3]);
+      reinterpret_cast<float4 *>(p.invN)[(size_t)byS * p.blocksX + bx0 + lane] = make_float4(inv[0], inv[1], inv[2], 0.0f);
     }
   }
 

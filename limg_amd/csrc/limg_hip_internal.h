@@ -45,6 +45,7 @@ namespace limg_hip
     uint32_t chainCount, chainRows; // chain c (< chainCount-1) owns block rows [c*chainRows, (c+1)*chainRows); the last owns the rest
     // per-block scratch / compact outputs
     limg_hip_block_record *records;
+    float *invN;           // per block 4 floats: 1 / |normal|^2 of factors A, B, C (src/limg_internal.h:426-452), 0; written by k_fit_tpb next to the record, read by the E step
     uint32_t *shifts;      // per block: sA | sB<<8 | sC<<16 | calls<<24
     uint32_t *stripCalls;  // per work strip: number of dither calls (blocksY * stripsX, raster order)
     uint32_t *stripBase;   // per work strip: index of its first dither call inside its chain (exclusive scan)

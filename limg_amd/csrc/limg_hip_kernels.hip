@@ -1013,7 +1013,9 @@ namespace limg_hip
           const int b = r * 4 + (lane >> 4), w = lane & 15;
           const uint32_t sb = wave * kBlocksPerWave + b, bx = strip * kStripBlocks + sb;
           uint32_t val = 0;
-          if (bx < p.blocksX) val = reinterpret_cast<const uint32_t *>(p.records + (size_t)byS * p.blocksX + bx)[w];
+          if (bx < p.blocksX) val = w >= 4 ? reinterpret_cast<const uint32_t *>(p.records + (size_t)byS * p.blocksX + bx)[w] // (the averages in words 0..3 are not needed here)
+                                           : reinterpret_cast<const uint32_t *>(p.invN)[((size_t)byS * p.blocksX + bx) * 4 + w];      // 1 / |n|^2 of A, B, C from k_fit_tpb
+          if (w < 3) reinterpret_cast<BlkE *>(&blk[b])->invN[w] = __uint_as_float(val); // its place in the phase-E view (nothing else of the float-stage fields is live with PREFIT)
           if (w >= 4)
           {
             reinterpret_cast<uint32_t *>(blk[b].rec)[w - 4] = val;
@@ -1277,6 +1279,7 @@ namespace limg_hip
           const int b = idx / 12, fc = idx - b * 12, f = fc >> 2, c = fc & 3;
           const int lo = blk[b].rec[f * 8 + c], hi = blk[b].rec[f * 8 + 4 + c];
           nrm[r] = (float)(hi - lo); off[r] = (float)lo;
+          if (PREFIT) { invn[r] = 0.0f; continue; } // k_fit_tpb left 1 / |n|^2 with the record
           const float sq = nrm[r] * nrm[r];
           const float s0 = __int_as_float(dpp<0x00, 0xF>(0, __float_as_int(sq))), s1 = __int_as_float(dpp<0x55, 0xF>(0, __float_as_int(sq)));
           const float s2 = __int_as_float(dpp<0xAA, 0xF>(0, __float_as_int(sq))), s3 = __int_as_float(dpp<0xFF, 0xF>(0, __float_as_int(sq)));
@@ -1295,7 +1298,7 @@ namespace limg_hip
             const int b = idx / 12, fc = idx - b * 12, f = fc >> 2, c = fc & 3;
             BlkE *e = reinterpret_cast<BlkE *>(&blk[b]);
             e->nrm[f][slot_of(c)] = nrm[r]; e->off[f][slot_of(c)] = off[r]; // slot order x0 x2 x1 x3, see V4
-            if (c == 0) e->invN[f] = invn[r];
+            if (!PREFIT && c == 0) e->invN[f] = invn[r];
             if (PREFIT && c < 3)
             { // the packed trial's integer operands (negated, see "a9, packed form"), once per block here instead of per lane in phase E
               int *tc = s_trialc + (wave * kBlocksPerWave + b) * kTrialConstDw;
