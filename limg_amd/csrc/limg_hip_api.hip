@@ -121,7 +121,7 @@ struct limg_hip_context
   DevBuf commWords; // [0] this rank's value, [1] its chain base, [8 ...] the all-gathered values
   DevBuf streamFac, streamTiles, streamStatus, streamBuf; // stream packer: 3 factor planes, per-tile payload words; decode status word; host-entry staging
   // optional per-kernel timing (bench): 4 events per encode, recorded on the caller's stream, read back in one go
-  int persistentWorkgroups = 1280; // 5 per CU (LDS- and VGPR-limited), set from the device's CU count at init
+  int persistentWorkgroups = 1280; // 5 x the device's CU count (set at init): the unit the launches scale (x 6 / 5 with the float stage in its own kernel)
   bool forceSplit = false; // options: run the three-kernel path even where the fused kernel applies (A/B, tests)
   bool profiling = false;
   std::vector<hipEvent_t> events;

@@ -11,7 +11,8 @@
 //   chain position              : the dither chain order of src/limg.cpp:1893,1951-1958 = exclusive prefix of the per-block
 //                                 dither-call counts (decoupled look-back in the persistent kernel, k_strip_scan in the split path)
 //
-// Kernels: k_encode_persistent (one launch per image: every workgroup loops over work strips, E step of a new strip then the
+// Kernels: k_encode_persistent (one launch per image -- or per list of images of one shape, limg_hip_encode3d_batch_device: the tickets
+// then run through the strips of image 0, image 1, ... --: every workgroup loops over work strips, E step of a new strip then the
 // F step of the strip it fitted one iteration earlier) and the three-launch split path k_fit_search / k_strip_scan /
 // k_dither_store (images with partial edge blocks, whose chain has to be walked on the host; `_perf` mode; A/B testing).
 // For images made of whole blocks the float stage (channel sums, direction fit, extrema, record) runs before them as its own
@@ -20,7 +21,8 @@
 //
 // Work decomposition: one 256-thread workgroup owns a "work strip" of 32 adjacent 8x8 image blocks (256 x 8 pixels): its
 // eight 1 KiB pixel rows are read with 16-byte-per-lane loads into LDS, each of the 4 waves then owns 8 blocks and works
-// with lane == pixel (wave64 == 64 pixels == one block).  Per-block control flow (the shift search) is wave-uniform.
+// with lane == pixel (wave64 == 64 pixels == one block) in the E step; per-block control flow (the shift search) is wave-uniform.
+// The F step's per-pixel part works with lane == (block of the wave's 8, block row), 8 pixels per lane (phase_f_rows).
 //
 // Float-stage numerics are those of the reference's SSE4.1 path executed strictly (see DESIGN.md "numerics"):
 //   * DPPS summation order (x0y0 + x1y1) + (x2y2 + x3y3), no FMA contraction (built with -ffp-contract=off);
@@ -922,8 +924,8 @@ namespace limg_hip
     constexpr int kLdsStrip = 0, kLdsV = kLdsStrip + 8 * kRowDw * 4, kLdsVBytes = kWaves * kBatch * kVDw * 4;
     constexpr int kLdsBlk = kLdsV + kLdsVBytes, kLdsCalls = kLdsBlk + kStripBlocks * 192, kLdsTotal = kLdsCalls + 32; // 4 per-wave call counts + the phase-E block queue
     static_assert(kLdsTotal <= 32768 - 16, "5 workgroups per CU");
-    // PREFIT (float stage done by k_fit_tpb): the parked-contribution area shrinks to the 6 KiB factor-byte staging area, and what sets the size is the F
-    // step's overlay (26 KiB) => 6 workgroups per CU
+    // PREFIT (float stage done by k_fit_tpb): the parked-contribution area shrinks to the 7.5 KiB factor-byte staging area; E layout 24.3 KiB, F overlay 23.9 KiB
+    // => 6 workgroups per CU
     struct LdsLayout { int v, blk, calls, trialc, total; };
     constexpr int kTrialConstDw = 20; // per block: nA[3] nB[3] nC[3] mA[3] mB[3] mC[3] (+2 pad): the integer view of the record the packed trial multiplies with
     template <bool PREFIT> __device__ __host__ constexpr LdsLayout lds_layout()
