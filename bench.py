@@ -642,7 +642,7 @@ def main():
     # cold cost of a SECOND, smaller size class on the warm context (the noise table is a prefix stream and the scratch only grows: nothing is rebuilt), and of a
     # fresh context whose table is built on the host the way rounds 1-2 did (limg_hip_options.host_noise_table), for comparison
     cold = {}
-    if rank == 0 and not args.no_host_rate and W >= 4096:
+    if rank == 0 and n_gpus == 1 and not args.no_host_rate and W >= 4096:
         w2 = W // 2
         img2 = g.synth_device(args.workload, w2, w2, seed=5)
         planes2 = g.alloc_planes_device(w2, w2)
