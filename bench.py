@@ -63,7 +63,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(width, seed, budget_s=30.0):
+def cpu_baseline(width, seed, budget_s=30.0, height=None):
     """The reference's own CPU path on this host, same image as the GPU leg (whole image, not a band): both builds of oracle/_ref (the project's own
     fast-math flags, project.lua:38, and the strict-IEEE build the parity tests pin), `_test` style (all planes + decode, src/limg.cpp:2105-2138) and
     `_perf` style (nothing stored, :2140-2173), single thread and thread pool.  `value` = the reference's own configuration: fast-math, pool, `_test` style
@@ -95,8 +95,9 @@ def cpu_baseline(width, seed, budget_s=30.0):
                 "value_is_not_the_reference": True,
                 "sample": "first %d rows of the bench image through the scalar CPU oracle with %d worker threads; oracle/_ref is not built here, so this is NOT "
                           "the reference's SIMD path (expect ~10x below it)" % (rows, pool)}
-    img = orc.photo_noise(width, width, seed)
-    px = width * width
+    height = height or width
+    img = orc.photo_noise(width, height, seed)
+    px = width * height
     # pools: the box's share for one of its 8 GPUs (host threads / 8), all host threads (what the reference's own tool takes: limg_threading_max_threads(),
     # src/main.cpp:165), and the 16 of rounds 1-2 for continuity.  The reference makes 4 row strips per pool thread (src/limg.cpp:2114-2134).
     pools = {"pool16": max(1, min(avail, 16)), "pool_gpu_share": max(1, avail // 8), "pool_allcores": avail}
@@ -112,7 +113,7 @@ def cpu_baseline(width, seed, budget_s=30.0):
             res[build]["test_" + name] = px / best(lambda: ref.encode3d(img, True, error_factor=100, pool_threads=pool), 2) / 1e6
             res[build]["perf_" + name] = px / best(lambda: ref.encode3d_perf(img, True, error_factor=100, pool_threads=pool), 2) / 1e6
         if time.perf_counter() - t_start < budget_s * 0.7:  # single thread: a quarter of the image is enough (linear in the rows)
-            q = np.ascontiguousarray(img[: width // 4])
+            q = np.ascontiguousarray(img[: height // 4])
             res[build]["test_1thread"] = q.size / best(lambda: ref.encode3d(q, True, error_factor=100, pool_threads=0), 1) / 1e6
             res[build]["perf_1thread"] = q.size / best(lambda: ref.encode3d_perf(q, True, error_factor=100, pool_threads=0), 1) / 1e6
         del ref
@@ -127,7 +128,7 @@ def cpu_baseline(width, seed, budget_s=30.0):
                       "limg_encode3d_test style (all planes + decode), at the BEST of three thread-pool sizes (%s; 4 row strips per pool thread, src/limg.cpp:2114-2134), best of 2 runs; "
                       "builds_Mpixels_per_s lists fast-math / strict-IEEE x _test / _perf style x pool of 16 / host threads over 8 GPUs (%d) / all host threads (%d: what the "
                       "reference's own tool takes, src/main.cpp:165) / single thread (single thread on the first quarter of the rows)"
-                      % (width, width, px / 1e6, key[len("test_"):], pools["pool_gpu_share"], pools["pool_allcores"])}
+                      % (width, height, px / 1e6, key[len("test_"):], pools["pool_gpu_share"], pools["pool_allcores"])}
 
 
 def run_sharded(args, g, dist, rank, world):
@@ -190,8 +191,12 @@ def run_sharded(args, g, dist, rank, world):
         name += ", round-robin over %d contexts / HIP streams" % args.contexts
 
     batched = args.config == 4 and len(ctxs) == 1 and not args.no_batch and len(units) > 1
+    if args.sub_images or args.wg_per_cu:
+        g.set_options(batch_sub_images=args.sub_images, test_wg_per_cu=args.wg_per_cu)
     if batched:
-        name += ", the rank's %d images in ONE launch pair (limg_hip_encode3d_batch_device)" % len(units)
+        name += (", the rank's %d images in ONE launch pair (limg_hip_encode3d_batch_device)" % len(units) if not args.sub_images else
+                 ", the rank's %d images as a pipeline of sub-batches of %d (limg_hip_encode3d_batch_device, batch_sub_images: k_fit_tpb of sub-batch k + 1 next to the persistent "
+                 "kernel of sub-batch k)" % (len(units), args.sub_images))
 
     def step():
         if batched:  # the reference's per-file loop (src/main.cpp:278-323) as one call: one k_fit_tpb grid + one persistent launch over all images
@@ -227,6 +232,11 @@ def run_sharded(args, g, dist, rank, world):
         elapsed = float(t.item())
     torch.cuda.synchronize()
     g.check()
+    if single_chain:
+        info = g.comm_info()
+        collective = {"backend": None if dist is None else dist.get_backend(), "world_size": world, "rccl_version": info["rccl_version"], "comm_ranks": info["ranks"]}
+    else:
+        collective = collective_evidence(g, dist, rank, world)
 
     # reassembly on rank 0 (config 5: the strips of the one image; config 4: every image's planes), timed apart
     gather_ms = None
@@ -292,7 +302,7 @@ def run_sharded(args, g, dist, rank, world):
         kavg = kernels.mean(axis=0) if len(kernels) else np.zeros(3)
         ksum = float(kavg.sum())  # k_fit_tpb + k_encode_persistent of one unit (single chain: the E/scan, exchange and F intervals)
         px_per_launch = (units[0][0].numel() if units else 0) * (len(units) if batched else 1)
-        pmc_key = "config%d_%s%s" % (args.config, "batched" if batched else "single", "" if args.contexts == 1 else "_ctx%d" % args.contexts)
+        pmc_key = "config%d_%s%s%s" % (args.config, "batched" if batched else "single", "" if args.contexts == 1 else "_ctx%d" % args.contexts, "" if not args.sub_images else "_sub%d" % args.sub_images)
         pmc = pmc_entry(pmc_key)
         achieved = ALGO_BYTES_PER_PX * px_per_launch / (ksum * 1e-3) / 1e9 if ksum > 0 else 0.0
         line = {
@@ -303,6 +313,7 @@ def run_sharded(args, g, dist, rank, world):
             "config": {"workload": name + ", errorFactor %d, fast bit-crush" % args.error_factor,
                        "parallelism": "no data-path collective; plane reassembly on rank 0 timed apart",
                        "gather_ms": None if gather_ms is None else round(gather_ms, 3), "gathered_bytes_rank0": gathered_bytes,
+                       "collective": collective,
                        "gather_backend": None if dist is None else dist.get_backend(), "gathered": "LMG3 streams, decoded on rank 0" if args.gather_stream else "planes"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": None if not pmc or pmc.get("fetch_kib") is None else int((2 * pmc["fetch_kib"] + pmc["write_kib"]) * 1024),
@@ -509,7 +520,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--size", type=int, default=8192)
+    ap.add_argument("--size", default="8192", help="N (an N x N image) or WxH, e.g. 8192x8190: sizes that are not multiples of 8 take the ragged paths (config.ragged)")
     ap.add_argument("--workload", default="photo_noise", choices=["photo_noise", "random_gradient"])
     ap.add_argument("--error-factor", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -537,7 +548,16 @@ def main():
     ap.add_argument("--single-chain", action="store_true", help="--config 5 on 8 ranks: one dither chain through all strips (limg_hip_encode3d_single_chain_device) instead of "
                                                                     "the reference's strip-restart semantics")
     ap.add_argument("--share-gpus", action="store_true", help="rehearsal only: allow more ranks than GPUs (ranks share cards, gloo instead of RCCL)")
+    ap.add_argument("--sub-images", type=int, default=0, help="--config 4: limg_hip_options.batch_sub_images -- the list as a pipeline of sub-batches of this many images "
+                                                                 "(float stage of sub-batch k + 1 next to the persistent kernel of sub-batch k)")
+    ap.add_argument("--wg-per-cu", type=int, default=0, help="A/B: limg_hip_options.test_wg_per_cu (workgroups per CU of the persistent kernel, 1..6)")
+    ap.add_argument("--whole-image-ragged", action="store_true", help="A/B: height-ragged images through the whole-image ragged path (host walk over every dither call)")
     args = ap.parse_args()
+    if "x" in str(args.size):
+        args.width, args.height = (int(v) for v in str(args.size).split("x"))
+    else:
+        args.width = args.height = int(args.size)
+    args.size = args.width  # (the square-size uses below: configs 4 / 5, cpu_baseline)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))
@@ -579,7 +599,7 @@ def main():
         torch.cuda.set_device(0)
     n_gpus = world
 
-    W = H = args.size
+    W, H = args.width, args.height
     g = limg_amd.LimgHip(dev)
     if args.blocked:
         run_blocked(args, g, dist, rank, n_gpus, W, H)
@@ -599,15 +619,18 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
-    g.set_options(forced_shift=(args.forced_shift,) * 3 if args.forced_shift >= 0 else None, force_split=args.split, float_fast=(args.float_mode == "fast"), legacy_float_stage=args.legacy_float_stage)
+    g.set_options(forced_shift=(args.forced_shift,) * 3 if args.forced_shift >= 0 else None, force_split=args.split, float_fast=(args.float_mode == "fast"), legacy_float_stage=args.legacy_float_stage,
+                  test_wg_per_cu=args.wg_per_cu, test_whole_image_ragged=args.whole_image_ragged)
+    ragged = (W % 8 != 0) or (H % 8 != 0)
+    ragged_fast = ragged and W % 8 == 0 and H > 8 and not (args.whole_image_ragged or args.split or args.legacy_float_stage)
     img = g.synth_device(args.workload, W, H, seed=1 + rank)
     planes = g.alloc_planes_device(W, H)
     rec = sh = None
     if args.compact:
         planes = {k: planes[k] for k in limg_amd.P8 + ("pDecoded",)}  # pDecoded only as a scratch target for the PSNR line below
         full = planes.pop("pDecoded")
-        rec = torch.empty(((W // 8) * (H // 8), 16), dtype=torch.int32, device="cuda")
-        sh = torch.empty((W // 8) * (H // 8), dtype=torch.int32, device="cuda")
+        rec = torch.empty((((W + 7) // 8) * ((H + 7) // 8), 16), dtype=torch.int32, device="cuda")
+        sh = torch.empty(((W + 7) // 8) * ((H + 7) // 8), dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
 
     def step():
@@ -638,11 +661,12 @@ def main():
         elapsed = float(t.item())
     torch.cuda.synchronize()
     g.check()  # a look-back timeout inside the timed loop would void the line
+    collective = collective_evidence(g, dist, rank, n_gpus)
 
     # cold cost of a SECOND, smaller size class on the warm context (the noise table is a prefix stream and the scratch only grows: nothing is rebuilt), and of a
     # fresh context whose table is built on the host the way rounds 1-2 did (limg_hip_options.host_noise_table), for comparison
     cold = {}
-    if rank == 0 and n_gpus == 1 and not args.no_host_rate and W >= 4096:
+    if rank == 0 and n_gpus == 1 and not args.no_host_rate and W >= 4096 and W == H:
         w2 = W // 2
         img2 = g.synth_device(args.workload, w2, w2, seed=5)
         planes2 = g.alloc_planes_device(w2, w2)
@@ -681,11 +705,11 @@ def main():
 
         kavg = kernels.mean(axis=0) if len(kernels) else np.zeros(3)
         # the kernels listed in roofline.kernels_ms, nothing else: fused = k_fit_tpb + k_encode_persistent (the one persistent launch with --legacy-float-stage); split = the three intervals
-        kms = float(kavg.sum()) if args.split else (float(kavg[0]) if args.legacy_float_stage else float(kavg[0] + kavg[1]))
+        kms = float(kavg.sum()) if (args.split or ragged) else (float(kavg[0]) if args.legacy_float_stage else float(kavg[0] + kavg[1]))
         achieved = bytes_per_px * px / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         pmc = pmc_entry(workload_key(args, W, H))
         traffic = None if not pmc or pmc.get("fetch_kib") is None else int((2 * pmc["fetch_kib"] + pmc["write_kib"]) * 1024)  # gfx950: FETCH_SIZE counts half the bytes
-        blocks = (W // 8) * (H // 8)
+        blocks = ((W + 7) // 8) * ((H + 7) // 8)
         valu = None
         if pmc and pmc.get("valu_instr_per_launch") and kms > 0:
             rate = pmc["valu_instr_per_launch"] / (kms * 1e-3)
@@ -705,6 +729,9 @@ def main():
                                    % (W, H, "RGB (hasAlpha = false)" if args.rgb else "RGBA", args.workload, args.error_factor, "ACCURATE" if args.accurate else "fast")
                                    + ("" if args.forced_shift < 0 else ", forced shift %d" % args.forced_shift)
                                    + (", COMPACT outputs (8.06 B/px)" if args.compact else "") + (", FAST float stage" if args.float_mode == "fast" else ""),
+                       "ragged": None if not ragged else ("width in whole blocks, last block row partial: fast path + last row (limg_hip_api.hip encode_height_ragged)" if ragged_fast else
+                                                          "whole-image ragged path: lane == pixel float stage, three launches, host chain walk over every dither call"),
+                       "collective": collective,
                        "images_per_step": n_gpus, "parallelism": "independent image per GPU, no data-path collective", "psnr_db": None if psnr != psnr else round(psnr, 4),
                        "first_encode_ms": round(first_encode_ms, 2), "cold": cold,
                        "perf_style_ms": None if perf_ms is None else round(perf_ms, 4),
@@ -712,16 +739,21 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(bytes_per_px * px),
-                         "kernels_ms": ({"k_fit_search": round(float(kavg[0]), 4), "k_strip_scan": round(float(kavg[1]), 4), "k_dither_store": round(float(kavg[2]), 4)}
+                         "kernels_ms": ({"k_fit_tpb (block rows above the last)": round(float(kavg[0]), 4), "k_encode_persistent (block rows above the last)": round(float(kavg[1]), 4),
+                                         "last block row: k_fit_search + shift words D2H + host chain walk + noise H2D + k_dither_store": round(float(kavg[2]), 4)} if ragged_fast else
+                                        {"k_fit_search (lane == pixel float stage)": round(float(kavg[0]), 4), "shift words D2H + host chain walk over every dither call + noise H2D": round(float(kavg[1]), 4),
+                                         "k_dither_store": round(float(kavg[2]), 4)} if ragged else
+                                        {"k_fit_search": round(float(kavg[0]), 4), "k_strip_scan": round(float(kavg[1]), 4), "k_dither_store": round(float(kavg[2]), 4)}
                                         if args.split else ({"k_encode_persistent": round(float(kavg[0]), 4)} if args.legacy_float_stage else
                                                             {"k_fit_tpb": round(float(kavg[0]), 4), "k_encode_persistent": round(float(kavg[1]), 4)})),
                          "valu": valu, "pmc_key": workload_key(args, W, H),
-                         "note": ("whole encode = 3 launches; achieved = 39 B/px * pixels / sum of the three average kernel durations (HIP events)" if args.split else
+                         "note": ("image with partial edge blocks: achieved = 39 B/px * pixels / the sum of the three intervals, host stage included (HIP events on the launch stream)" if ragged else
+                                  "whole encode = 3 launches; achieved = 39 B/px * pixels / sum of the three average kernel durations (HIP events)" if args.split else
                                   "whole encode = k_fit_tpb (float stage, one lane per block) + one persistent launch; achieved = 39 B/px * pixels / the sum of their average durations "
                                   "(HIP events on the launch stream). "
                                   "The kernel is VALU-issue-bound, not HBM-bound: see `valu`")},
         }
-        if n_gpus == 1 and not args.no_host_rate and not (args.split or args.compact or args.forced_shift >= 0):
+        if n_gpus == 1 and not args.no_host_rate and not (args.split or args.compact or args.forced_shift >= 0 or ragged):
             try:  # what a service encoding a stream of images gets: two contexts on two HIP streams, images alternating (never `value`: the kernels overlap)
                 line["config"]["two_streams"] = two_stream_rate(g, img, planes, W, H, args)
             except Exception as e:
@@ -733,13 +765,37 @@ def main():
                 line["config"]["host_entry"] = {"error": repr(e)}
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(W, 1)
+                line["cpu_baseline"] = cpu_baseline(W, 1, height=H)
             except Exception as e:  # the checker must never sink the measurement
                 line["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(line), flush=True)
     g.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def collective_evidence(g, dist, rank, world):
+    """--gpus N > 1: what RCCL itself says about the job, so that a SCALE record shows the N ranks RCCL saw: torch.distributed's backend and world size, and -- through
+    the library's own communicator (limg_hip_comm_init over the id rank 0 made; ncclCommCount / ncclGetVersion behind limg_hip_comm_info) -- every rank's view, all-gathered:
+    the line is refused unless all ranks report the same `comm_ranks` == N.  Outside the timed region."""
+    if dist is None:
+        return None
+    import torch
+    ev = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": None, "comm_ranks": None}
+    if dist.get_backend() != "nccl":
+        ev["note"] = "gloo rehearsal: no RCCL communicator"
+        return ev
+    g.comm_init_from_torch(dist)
+    info = g.comm_info()
+    t = torch.tensor([info["ranks"], info["rank"], info["rccl_version"]], dtype=torch.int64, device="cuda")
+    allv = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(allv, t)
+    g.comm_destroy()
+    views = [[int(v) for v in a.tolist()] for a in allv]
+    if any(v[0] != world for v in views) or sorted(v[1] for v in views) != list(range(world)):
+        raise SystemExit("bench.py: RCCL communicator does not span the %d ranks asked for: %r" % (world, views))
+    ev.update({"rccl_version": info["rccl_version"], "comm_ranks": info["ranks"], "comm_user_ranks": [v[1] for v in views]})
+    return ev
 
 
 def two_stream_rate(g, img, planes, W, H, args, n_images=12):

@@ -75,6 +75,13 @@ typedef struct limg_hip_options
                                   instead of filling it on the GPU from the embedded chain checkpoints.  Same bytes; A/B switch for tests */
   int32_t test_batch_chunk;    /* test hook, 0 = default: limg_hip_encode3d_batch_device puts at most this many images into one launch pair (default: as many as 1 GiB
                                   of per-block scratch holds) */
+  int32_t batch_sub_images;    /* limg_hip_encode3d_batch_device: > 0 = run the list as a pipeline of sub-batches of this many images -- the float-stage kernel of
+                                  sub-batch k + 1 on a stream of the context's own next to the persistent kernel of sub-batch k (which then leaves it a residency
+                                  slot: 5 workgroups per CU instead of 6); 0 = one launch pair for the whole list.  Same planes either way */
+  int32_t test_wg_per_cu;      /* A/B hook, 0 = default: workgroups per CU of the persistent kernel's launch, 1 .. its launch bound (6; values above are ignored) */
+  int32_t test_whole_image_ragged; /* test hook, non-0: an image whose width is whole 8x8 blocks but whose last block row is partial goes through the whole-image
+                                  ragged path (host chain walk over every dither call) instead of fast path + last row; same planes either way */
+  int32_t test_fail_chain_phase1; /* test hook, non-0: limg_hip_encode3d_single_chain_device behaves as if this rank's E step had failed (abort rule below) */
 } limg_hip_options;
 
 typedef struct limg_hip_context limg_hip_context;
@@ -93,6 +100,7 @@ limg_hip_result limg_hip_init(int device, limg_hip_context **ppCtx);
 void limg_hip_shutdown(limg_hip_context **ppCtx);
 void limg_hip_default_options(limg_hip_options *pOptions);
 limg_hip_result limg_hip_set_options(limg_hip_context *pCtx, const limg_hip_options *pOptions);
+limg_hip_result limg_hip_get_options(const limg_hip_context *pCtx, limg_hip_options *pOptions); /* read, change one field, set: nothing else is reset */
 
 /* Replaces `limg_encode3d_test` (src/limg.h:35, src/limg.cpp:2175-2265).  HOST pointers; blocking.
  * poolThreads: 0 == `pThreadPool = nullptr` (one dither chain over the image); T > 0 == a pool of T threads, i.e. T*4
@@ -147,6 +155,11 @@ limg_hip_result limg_hip_check_device_status(limg_hip_context *pCtx);
  * Of the context's last encode made with limg_hip_options.collect_stats set (a batched encode: all its images together); waits for that encode.
  * The library itself prints nothing (SURVEY 8(b) "Side effects"); include/limg_hip_shim.hpp's limg_print_stats and tools/limg_hip_cli.cpp print upstream's lines. */
 limg_hip_result limg_hip_last_stats(limg_hip_context *pCtx, uint64_t *pCounters30, uint64_t *pPixels);
+/* limg_hip_encode3d / limg_hip_blocked_encode3d that ALSO return the counters of that very encode (upstream keeps them on the stack of the call, src/limg.cpp:1975-1976,
+ * so its printout is per call whatever other threads do): encode and fetch happen under the context's mutex, collect_stats is on for the call only.  What the C++
+ * shim's limg_encode3d_test / limg_blocked_encode3d_test call when limg_hip_shim::print_stats(true) is set -- safe from any number of threads on one context. */
+limg_hip_result limg_hip_encode3d_stats(limg_hip_context *pCtx, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, limg_hip_encode3d_info *pInfo,
+                                        uint32_t errorFactor, int poolThreads, int fastBitCrushing, uint64_t *pCounters30, uint64_t *pPixels);
 
 /* Per-kernel timing for the bench (HIP events recorded on the stream each profiled encode is launched on).
  * limg_hip_profile_end writes 3 floats per profiled encode: k_fit_search, k_strip_scan (or the host chain walk of ragged
@@ -192,6 +205,8 @@ typedef struct limg_hip_region { uint32_t ox, oy, rx, ry; } limg_hip_region; /* 
 /* HOST pointers, blocking. */
 limg_hip_result limg_hip_blocked_encode3d(limg_hip_context *pCtx, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, limg_hip_blocked_encode3d_info *pInfo,
                                           uint32_t errorFactor, int fastBitCrushing);
+limg_hip_result limg_hip_blocked_encode3d_stats(limg_hip_context *pCtx, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, limg_hip_blocked_encode3d_info *pInfo,
+                                                uint32_t errorFactor, int fastBitCrushing, uint64_t *pCounters30, uint64_t *pPixels);
 /* DEVICE pointers (pIn and the planes inside *pInfo); returns when everything has been enqueued on `stream` -- the call itself waits for
  * the intermediate device results its host stages need. */
 limg_hip_result limg_hip_blocked_encode3d_device(limg_hip_context *pCtx, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha,
@@ -281,6 +296,8 @@ limg_hip_result limg_hip_stream_info(const uint8_t *pStream, size_t streamBytes,
 limg_hip_result limg_hip_comm_unique_id(uint8_t *pId128);                                                  /* rank 0: ncclGetUniqueId */
 limg_hip_result limg_hip_comm_init(limg_hip_context *pCtx, const uint8_t *pId128, int rank, int worldSize); /* every rank: ncclCommInitRank on the context's device */
 limg_hip_result limg_hip_comm_destroy(limg_hip_context *pCtx);
+/* ncclCommUserRank / ncclCommCount of the context's communicator and ncclGetVersion (any pointer may be NULL): evidence for logs and bench lines. */
+limg_hip_result limg_hip_comm_info(limg_hip_context *pCtx, int *pRank, int *pRanks, int *pRcclVersion);
 /* pStream / pGathered are DEVICE pointers.  On `root`, piece r lands at pGathered + pOffsets[r] (16-byte aligned, ready for limg_hip_decode_stream_device);
  * pOffsets (host, worldSize + 1 entries) also receives the total.  Blocks until the sizes are known; the transfers are asynchronous on `stream`. */
 limg_hip_result limg_hip_gather_stream(limg_hip_context *pCtx, const uint8_t *pStream, size_t streamBytes, int root, uint8_t *pGathered, size_t capacity,
@@ -289,6 +306,11 @@ limg_hip_result limg_hip_gather_stream(limg_hip_context *pCtx, const uint8_t *pS
  * blocksBefore = number of 8x8 blocks in the strips of the ranks before this one (sizes the dither noise table).  DEVICE pointers, asynchronous. */
 limg_hip_result limg_hip_encode3d_single_chain_device(limg_hip_context *pCtx, const uint32_t *pIn, size_t sizeX, size_t stripRows, int hasAlpha,
                                                       const limg_hip_encode3d_info *pInfo, uint32_t errorFactor, int fastBitCrushing, size_t blocksBefore, void *stream);
+/* Abort rule of the two collective entries (the reference's analogue, row strips on one thread pool, cannot half-fail: src/limg.cpp:2114-2136): a rank never leaves its
+ * peers inside a collective.  limg_hip_gather_stream decides "fits / does not fit" from all-gathered numbers, so every rank returns limg_hip_error_OutOfBounds alike
+ * before anything is posted.  limg_hip_encode3d_single_chain_device: a rank whose own E step failed (bad arguments, allocation, launch) still joins the 8-byte
+ * all-gather, with the poison value ~0, and returns its error; on every other rank the call returns limg_hip_success (it is asynchronous), the F step stores
+ * NOTHING, and the next limg_hip_check_device_status of that context returns limg_hip_error_Generic ("a rank of the communicator aborted ..."), once. */
 /* The two halves of the above without the exchange, for callers that move the counts themselves (and for single-GPU tests of the chain arithmetic):
  * phase 1 = E step + scan, writes this strip's dither-call total to *pCallsDevice; phase 2 = F step, its first dither call is *pChainBaseDevice.
  * Phase 2 must follow phase 1 of the same strip on the same context with nothing in between (the context holds the strip's intermediate results);

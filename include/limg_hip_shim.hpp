@@ -15,6 +15,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
 #include <functional>
 #include <thread>
 #include <vector>
@@ -93,30 +94,26 @@ namespace limg_hip_shim
   // Upstream's limg_encode3d_test and limg_blocked_encode3d_test print their bit statistics themselves (src/limg.cpp:2232-2248, PRINT_TEST_OUTPUT is always defined);
   // the library is silent.  A caller that wants upstream's console output switches it on once -- limg_hip_shim::print_stats(true) -- and the two functions below then
   // print the same block, from the counters the GPU reduced (limg_hip_last_stats), after each encode.
-  inline bool &stats_flag() { static bool on = false; return on; }
-  inline void print_stats(const bool on)
+  // The flag is the shim's own (an atomic: any thread may flip it); no option of the shared context is touched -- the two functions below ask for the counters of
+  // THEIR encode through limg_hip_encode3d_stats / limg_hip_blocked_encode3d_stats, which encode and fetch under the context's mutex, so a thread always prints its own
+  // call's block, like upstream (counters on the call's stack, src/limg.cpp:1975-1976).
+  inline std::atomic<bool> &stats_flag() { static std::atomic<bool> on(false); return on; }
+  inline void print_stats(const bool on) { stats_flag().store(on); }
+  inline void print_stats_block(const uint64_t *a, const uint64_t pixels)
   {
-    stats_flag() = on;
-    limg_hip_context *c = context();
-    if (!c) return;
-    limg_hip_options o;
-    limg_hip_default_options(&o);
-    o.collect_stats = on ? 1 : 0;
-    limg_hip_set_options(c, &o);
-  }
-  inline void print_last_stats(limg_hip_context *c)
-  {
-    uint64_t a[30], pixels = 0;
-    if (limg_hip_last_stats(c, a, &pixels) != limg_hip_success || pixels == 0) return;
+    if (pixels == 0) return;
     const double t = (double)pixels;
-    printf("\nAverage Block Bits: %5.3f (A: %5.3f | B: %5.3f | C: %5.3f)\n\n", (a[0] + a[1] + a[2]) / t, a[0] / t, a[1] / t, a[2] / t);
-    for (size_t i = 0; i < 9; i++) printf(" %" PRIu64 " bit   ", (uint64_t)(8 - i));
+    // one buffer, one write: blocks of concurrent callers do not interleave line by line
+    char buf[1024];
+    int n = snprintf(buf, sizeof(buf), "\nAverage Block Bits: %5.3f (A: %5.3f | B: %5.3f | C: %5.3f)\n\n", (a[0] + a[1] + a[2]) / t, a[0] / t, a[1] / t, a[2] / t);
+    for (size_t i = 0; i < 9; i++) n += snprintf(buf + n, sizeof(buf) - (size_t)n, " %" PRIu64 " bit   ", (uint64_t)(8 - i));
     for (size_t f = 0; f < 3; f++)
     {
-      puts("");
-      for (size_t j = 0; j < 9; j++) printf("%7.4f  ", a[3 + f * 9 + j] * 100.0 / t);
+      n += snprintf(buf + n, sizeof(buf) - (size_t)n, "\n");
+      for (size_t j = 0; j < 9; j++) n += snprintf(buf + n, sizeof(buf) - (size_t)n, "%7.4f  ", a[3 + f * 9 + j] * 100.0 / t);
     }
-    puts("\n");
+    n += snprintf(buf + n, sizeof(buf) - (size_t)n, "\n\n");
+    fwrite(buf, 1, (size_t)n, stdout);
   }
 }
 
@@ -126,9 +123,13 @@ inline limg_result limg_encode3d_test(const uint32_t *pIn, const size_t sizeX, c
   static_assert(sizeof(limg_encode3d_info) == sizeof(limg_hip_encode3d_info), "layout");
   limg_hip_context *c = limg_hip_shim::context();
   if (!c) return limg_error_Generic;
-  const limg_result r = (limg_result)limg_hip_encode3d(c, pIn, sizeX, sizeY, hasAlpha ? 1 : 0, reinterpret_cast<limg_hip_encode3d_info *>(pInfo), errorFactor,
-                                                       limg_hip_shim::pool_threads(pThreadPool), fastBitCrushing ? 1 : 0);
-  if (r == limg_success && limg_hip_shim::stats_flag()) limg_hip_shim::print_last_stats(c);
+  if (!limg_hip_shim::stats_flag().load())
+    return (limg_result)limg_hip_encode3d(c, pIn, sizeX, sizeY, hasAlpha ? 1 : 0, reinterpret_cast<limg_hip_encode3d_info *>(pInfo), errorFactor,
+                                          limg_hip_shim::pool_threads(pThreadPool), fastBitCrushing ? 1 : 0);
+  uint64_t counters[30], pixels = 0;
+  const limg_result r = (limg_result)limg_hip_encode3d_stats(c, pIn, sizeX, sizeY, hasAlpha ? 1 : 0, reinterpret_cast<limg_hip_encode3d_info *>(pInfo), errorFactor,
+                                                             limg_hip_shim::pool_threads(pThreadPool), fastBitCrushing ? 1 : 0, counters, &pixels);
+  if (r == limg_success) limg_hip_shim::print_stats_block(counters, pixels);
   return r;
 }
 
@@ -147,9 +148,12 @@ inline limg_result limg_blocked_encode3d_test(const uint32_t *pIn, const size_t 
   static_assert(sizeof(limg_blocked_encode3d_info) == sizeof(limg_hip_blocked_encode3d_info), "layout");
   limg_hip_context *c = limg_hip_shim::context();
   if (!c) return limg_error_Generic;
-  const limg_result r = (limg_result)limg_hip_blocked_encode3d(c, pIn, sizeX, sizeY, hasAlpha ? 1 : 0, reinterpret_cast<limg_hip_blocked_encode3d_info *>(pInfo), errorFactor,
-                                                               fastBitCrushing ? 1 : 0);
-  if (r == limg_success && limg_hip_shim::stats_flag()) limg_hip_shim::print_last_stats(c);
+  if (!limg_hip_shim::stats_flag().load())
+    return (limg_result)limg_hip_blocked_encode3d(c, pIn, sizeX, sizeY, hasAlpha ? 1 : 0, reinterpret_cast<limg_hip_blocked_encode3d_info *>(pInfo), errorFactor, fastBitCrushing ? 1 : 0);
+  uint64_t counters[30], pixels = 0;
+  const limg_result r = (limg_result)limg_hip_blocked_encode3d_stats(c, pIn, sizeX, sizeY, hasAlpha ? 1 : 0, reinterpret_cast<limg_hip_blocked_encode3d_info *>(pInfo), errorFactor,
+                                                                     fastBitCrushing ? 1 : 0, counters, &pixels);
+  if (r == limg_success) limg_hip_shim::print_stats_block(counters, pixels);
   return r;
 }
 

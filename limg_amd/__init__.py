@@ -18,7 +18,8 @@ PLANES = P32 + P8
 
 # every symbol include/limg_hip.h declares (checked by tests/test_host.py without a GPU)
 ABI_SYMBOLS = (
-    "limg_hip_init", "limg_hip_shutdown", "limg_hip_default_options", "limg_hip_set_options", "limg_hip_encode3d", "limg_hip_encode3d_perf",
+    "limg_hip_init", "limg_hip_shutdown", "limg_hip_default_options", "limg_hip_set_options", "limg_hip_get_options", "limg_hip_encode3d", "limg_hip_encode3d_perf",
+    "limg_hip_encode3d_stats", "limg_hip_blocked_encode3d_stats",
     "limg_hip_encode3d_device", "limg_hip_encode3d_batch_device", "limg_hip_last_stats", "limg_hip_compare", "limg_hip_compare_device", "limg_hip_synth_random_gradient_device",
     "limg_hip_synth_photo_noise_device", "limg_hip_context_device_bytes", "limg_hip_version", "limg_hip_profile_begin", "limg_hip_profile_end",
     "limg_hip_host_noise_table", "limg_hip_noise_table_device", "limg_hip_host_chain_call", "limg_hip_host_chain_checkpoints", "limg_hip_host_partition", "limg_hip_check_device_status",
@@ -26,7 +27,7 @@ ABI_SYMBOLS = (
     "limg_hip_stream_info",
     "limg_hip_blocked_encode3d", "limg_hip_blocked_encode3d_device", "limg_hip_blocked_regions", "limg_hip_blocked_timing", "limg_hip_host_blocked_matches",
     "limg_hip_host_blocked_merge", "limg_hip_host_blocked_match_words", "limg_hip_host_blocked_match_bits",
-    "limg_hip_comm_unique_id", "limg_hip_comm_init", "limg_hip_comm_destroy", "limg_hip_gather_stream", "limg_hip_encode3d_single_chain_device",
+    "limg_hip_comm_unique_id", "limg_hip_comm_init", "limg_hip_comm_destroy", "limg_hip_comm_info", "limg_hip_gather_stream", "limg_hip_encode3d_single_chain_device",
     "limg_hip_encode3d_chain_device", "limg_hip_host_gather_offsets", "limg_hip_host_chain_bases",
 )
 COMM_ID_BYTES = 128
@@ -60,7 +61,8 @@ class CompactOut(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("forced_shift", C.c_int32 * 3), ("force_split_kernels", C.c_int32), ("dither_pcg", C.c_int32), ("test_record_limit", C.c_int32), ("float_mode", C.c_int32), ("legacy_float_stage", C.c_int32),
-                ("collect_stats", C.c_int32), ("host_noise_table", C.c_int32), ("test_batch_chunk", C.c_int32)]
+                ("collect_stats", C.c_int32), ("host_noise_table", C.c_int32), ("test_batch_chunk", C.c_int32), ("batch_sub_images", C.c_int32), ("test_wg_per_cu", C.c_int32),
+                ("test_whole_image_ragged", C.c_int32), ("test_fail_chain_phase1", C.c_int32)]
 
 
 def load_library(path=None):
@@ -82,6 +84,12 @@ def load_library(path=None):
     L.limg_hip_default_options.argtypes = [C.c_void_p]
     L.limg_hip_set_options.restype = C.c_int
     L.limg_hip_set_options.argtypes = [C.c_void_p, C.c_void_p]
+    L.limg_hip_get_options.restype = C.c_int
+    L.limg_hip_get_options.argtypes = [C.c_void_p, C.c_void_p]
+    L.limg_hip_encode3d_stats.restype = C.c_int
+    L.limg_hip_encode3d_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.limg_hip_blocked_encode3d_stats.restype = C.c_int
+    L.limg_hip_blocked_encode3d_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
     L.limg_hip_encode3d.restype = C.c_int
     L.limg_hip_encode3d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_int]
     L.limg_hip_encode3d_perf.restype = C.c_int
@@ -150,6 +158,8 @@ def load_library(path=None):
     L.limg_hip_comm_unique_id.argtypes = [C.c_void_p]
     L.limg_hip_comm_init.restype = C.c_int
     L.limg_hip_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.limg_hip_comm_info.restype = C.c_int
+    L.limg_hip_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.limg_hip_comm_destroy.restype = C.c_int
     L.limg_hip_comm_destroy.argtypes = [C.c_void_p]
     L.limg_hip_gather_stream.restype = C.c_int
@@ -246,7 +256,8 @@ class LimgHip:
         except Exception:
             pass
 
-    def set_options(self, forced_shift=None, force_split=False, dither_pcg=False, test_record_limit=0, float_fast=False, legacy_float_stage=False, test_batch_chunk=0, host_noise_table=False, collect_stats=False):
+    def set_options(self, forced_shift=None, force_split=False, dither_pcg=False, test_record_limit=0, float_fast=False, legacy_float_stage=False, test_batch_chunk=0, host_noise_table=False, collect_stats=False,
+                    batch_sub_images=0, test_wg_per_cu=0, test_whole_image_ragged=False, test_fail_chain_phase1=False):
         o = Options()
         self.lib.limg_hip_default_options(C.byref(o))
         if forced_shift is not None:
@@ -260,7 +271,16 @@ class LimgHip:
         o.test_batch_chunk = int(test_batch_chunk)
         o.host_noise_table = int(host_noise_table)
         o.collect_stats = int(collect_stats)
+        o.batch_sub_images = int(batch_sub_images)
+        o.test_wg_per_cu = int(test_wg_per_cu)
+        o.test_whole_image_ragged = int(test_whole_image_ragged)
+        o.test_fail_chain_phase1 = int(test_fail_chain_phase1)
         _check(self.lib.limg_hip_set_options(self.ctx, C.byref(o)), "limg_hip_set_options")
+
+    def get_options(self):
+        o = Options()
+        _check(self.lib.limg_hip_get_options(self.ctx, C.byref(o)), "limg_hip_get_options")
+        return o
 
     def set_forced_shift(self, shift=None):
         self.set_options(forced_shift=shift)
@@ -274,6 +294,19 @@ class LimgHip:
         info = Info(*[out[k].ctypes.data for k in PLANES])
         _check(self.lib.limg_hip_encode3d(self.ctx, _np_ptr(img), w, h, int(has_alpha), C.byref(info), error_factor, pool_threads, int(fast)), "limg_hip_encode3d")
         return out
+
+    def encode3d_stats(self, img, has_alpha, error_factor=100, pool_threads=0, fast=True):
+        """limg_hip_encode3d_stats: the planes AND the bit counters of this very encode -> (planes, counters[30], pixels)"""
+        img = np.ascontiguousarray(img, dtype=np.uint32)
+        h, w = img.shape
+        out = {k: np.zeros((h, w), dtype=np.uint32) for k in P32}
+        out.update({k: np.zeros((h, w), dtype=np.uint8) for k in P8})
+        info = Info(*[out[k].ctypes.data for k in PLANES])
+        cnt = np.zeros(30, dtype=np.uint64)
+        px = C.c_uint64(0)
+        _check(self.lib.limg_hip_encode3d_stats(self.ctx, _np_ptr(img), w, h, int(has_alpha), C.byref(info), error_factor, pool_threads, int(fast), _np_ptr(cnt), C.byref(px)),
+               "limg_hip_encode3d_stats")
+        return out, cnt, px.value
 
     def encode3d_perf(self, img, has_alpha, error_factor=100, pool_threads=0, fast=True):
         img = np.ascontiguousarray(img, dtype=np.uint32)
@@ -442,6 +475,12 @@ class LimgHip:
         t = torch.from_numpy(self.comm_unique_id() if rank == 0 else np.zeros(COMM_ID_BYTES, dtype=np.uint8)).to(dev)
         dist.broadcast(t, src=0)
         self.comm_init(t.cpu().numpy(), rank, world)
+
+    def comm_info(self):
+        """What RCCL says about the context's communicator: {"rank", "ranks" (ncclCommCount), "rccl_version"}."""
+        r, n, v = C.c_int(-1), C.c_int(0), C.c_int(0)
+        _check(self.lib.limg_hip_comm_info(self.ctx, C.byref(r), C.byref(n), C.byref(v)), "limg_hip_comm_info")
+        return {"rank": r.value, "ranks": n.value, "rccl_version": v.value}
 
     def comm_destroy(self):
         _check(self.lib.limg_hip_comm_destroy(self.ctx), "limg_hip_comm_destroy")

@@ -89,9 +89,13 @@ struct limg_hip_context
   DevBuf noiseCk;                                // the chain checkpoints (limg_noise_checkpoints.h) on the device: the GPU fills the noise table from them
   DevBuf park;                                   // persistent kernel: 2 x 8 KiB per workgroup
   DevBuf batchTable;                             // batched encode: one ImageIO per image
+  hipStream_t fitStream = nullptr;               // batched encode in sub-batches: k_fit_tpb of sub-batch k + 1 runs here, next to the persistent kernel of sub-batch k
+  std::vector<hipEvent_t> pipeEvents;            // ... and the events that fork it from / join it to the caller's stream
+  HostBuf hStage;                                // pinned staging of the ragged paths' host step (shift words down; chain bases and noise up)
   DevBuf stats;                                  // limg_hip_options.collect_stats: the reference's 3 + 27 bit counters of the last encode
   hipStream_t statsStream = nullptr;
   int statsState = 0;                            // 0 = none, 1 = on the device (8x8 path), 2 = in statsHost (merged-block encoder)
+  bool statsAccumulate = false;                  // a batched encode in several launch pairs: the pairs after the first add to the counters instead of restarting them
   uint64_t statsHost[30] = { 0 };
   uint64_t statsPixels = 0;
   DevBuf lookback;                               // fused path: ticket (16 B) then one 8-byte descriptor per work strip
@@ -172,6 +176,21 @@ namespace
     return limg_hip_success;
   }
 
+  // The chain checkpoints go to the device once per context, with a blocking copy: whichever stream fills a noise table later finds them there (an asynchronous
+  // copy on the first caller's stream would order nothing for a second stream), and a failed copy leaves no buffer behind that later encodes would trust.
+  limg_hip_result upload_checkpoints(limg_hip_context *c, const uint64_t *ck, size_t ckCount)
+  {
+    limg_hip_result r;
+    if ((r = c->noiseCk.ensure(ckCount * 8)) != limg_hip_success) return r;
+    if (hipMemcpy(c->noiseCk.p, ck, ckCount * 8, hipMemcpyHostToDevice) != hipSuccess)
+    {
+      c->noiseCk.release();
+      fprintf(stderr, "limg_hip: upload of the dither chain checkpoints failed\n");
+      return limg_hip_error_Generic;
+    }
+    return limg_hip_success;
+  }
+
   limg_hip_result grow_noise_table(limg_hip_context *c, size_t entries, hipStream_t stream)
   {
     const bool pcg = c->opt.dither_pcg != 0;
@@ -186,8 +205,7 @@ namespace
       limg_hip_result r;
       if (!c->noiseCk.p)
       {
-        if ((r = c->noiseCk.ensure(ckCount * 8)) != limg_hip_success) return r;
-        HIP_TRY(hipMemcpyAsync(c->noiseCk.p, ck, ckCount * 8, hipMemcpyHostToDevice, stream)); // static storage: outlives the copy
+        if ((r = upload_checkpoints(c, ck, ckCount)) != limg_hip_success) return r;
       }
       HIP_TRY(hipStreamSynchronize(stream)); // earlier encodes on this stream may still read the table that is about to be replaced
       if ((r = c->noise.ensure(want * 64)) != limg_hip_success) return r;
@@ -251,16 +269,62 @@ namespace
     return c < pt.chainCount - 1 ? c : pt.chainCount - 1;
   }
 
-  limg_hip_result encode_device(limg_hip_context *c, const uint32_t *dIn, size_t sizeX, size_t sizeY, int hasAlpha, const limg_hip_encode3d_info *dInfo,
-                                const limg_hip_compact_out *compact, uint32_t errorFactor, int poolThreads, int fast, hipStream_t stream, bool streamRaw = false, bool fitOnly = false,
-                                int chainPhase = 0, unsigned long long *dChainCalls = nullptr, const unsigned long long *dChainBase = nullptr, size_t chainBlocksBefore = 0,
-                                const ImageIO *batch = nullptr, size_t batchCount = 1)
+  // What the public entries add to the plain (single image, whole encode) call.
+  struct EncodeExtra
   {
+    bool streamRaw = false, fitOnly = false;
+    int chainPhase = 0; // 0 = whole encode; 1 = E step + scan only (writes *dChainCalls); 2 = F step only (reads *dChainBase).  1 and 2 always take the split path.
+    unsigned long long *dChainCalls = nullptr;
+    const unsigned long long *dChainBase = nullptr;
+    size_t chainBlocksBefore = 0;
     // batch (host array of batchCount entries, batchCount > 1): the images of a batched encode -- same shape, whole 8x8 blocks, all 11 planes -- in one launch
-    // pair; dIn / dInfo are then those of image 0.  The caller (limg_hip_encode3d_batch_device) has checked all of that.
-    // chainPhase: 0 = whole encode; 1 = E step + scan only (writes *dChainCalls); 2 = F step only (reads *dChainBase).  1 and 2 always take the split path.
+    // pair (or, limg_hip_options.batch_sub_images, a pipeline of launch pairs); dIn / dInfo are then those of image 0.  The caller has checked all of that.
+    const ImageIO *batch = nullptr;
+    size_t batchCount = 1;
+    // ---- a sub-image of a larger encode (the two parts of an image whose last block row is partial: encode_height_ragged) ----
+    bool inner = false;            // part of a larger encode: no statistics launch of its own, no reset of the context's chain / statistics state
+    int marks = 2;                 // profiling events: 2 = all four, 1 = all but the last, 0 = none
+    const Partition *part = nullptr; // the dither-chain partition of the WHOLE image (a sub-image cannot derive it from its own height)
+    size_t scratchRow0 = 0;        // this sub-image's first block row in the per-block scratch (and in the caller's compact outputs)
+    size_t scratchRows = 0;        // block rows the scratch must hold (0: this call's own)
+    const unsigned long long *dPrevDesc = nullptr; // ragged sub-image: its chain continues the one whose dither-call count is the low word of this look-back descriptor
+  };
+
+  limg_hip_result encode_height_ragged(limg_hip_context *c, const uint32_t *dIn, size_t sizeX, size_t sizeY, int hasAlpha, const limg_hip_encode3d_info *dInfo,
+                                       const limg_hip_compact_out *compact, uint32_t errorFactor, int poolThreads, int fast, hipStream_t stream, const EncodeExtra &x);
+
+  // The chain value the dither call number `calls` of a chain of full 8x8 blocks starts from: the nearest embedded checkpoint, then at most 1023 calls on foot.
+  bool chain_value_at(uint64_t calls, uint64_t *pValue)
+  {
+    size_t ckCount = 0, ckEvery = 0;
+    const uint64_t *ck = noise_checkpoints_host(&ckCount, &ckEvery);
+    if (calls / ckEvery >= ckCount) return false;
+    uint64_t h = ck[calls / ckEvery];
+    for (uint64_t i = 0; i < calls % ckEvery; i++) h = chain_call(h, 64, nullptr, false, false);
+    *pValue = h;
+    return true;
+  }
+
+  limg_hip_result ensure_pipe_events(limg_hip_context *c, size_t n)
+  {
+    if (!c->fitStream) HIP_TRY(hipStreamCreateWithFlags(&c->fitStream, hipStreamNonBlocking));
+    while (c->pipeEvents.size() < n)
+    {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      c->pipeEvents.push_back(e);
+    }
+    return limg_hip_success;
+  }
+
+  limg_hip_result encode_device(limg_hip_context *c, const uint32_t *dIn, size_t sizeX, size_t sizeY, int hasAlpha, const limg_hip_encode3d_info *dInfo,
+                                const limg_hip_compact_out *compact, uint32_t errorFactor, int poolThreads, int fast, hipStream_t stream, const EncodeExtra &x = EncodeExtra())
+  {
+    const int chainPhase = x.chainPhase;
+    const size_t batchCount = x.batchCount;
+    const ImageIO *const batch = x.batch;
     if (!c || !dIn) return limg_hip_error_ArgumentNull;
-    if (chainPhase == 0) c->chainIn = nullptr; // the context's per-block scratch is about to be reused
+    if (chainPhase == 0 && !x.inner) c->chainIn = nullptr; // the context's per-block scratch is about to be reused
     if (sizeX == 0 || sizeY == 0 || sizeX > 0x7FFFFFF8ull || sizeY > 0x7FFFFFF8ull) return limg_hip_error_InvalidParameter;
     bool fullPlanes = true;
     if (dInfo)
@@ -275,6 +339,18 @@ namespace
       fullPlanes = n32 == 8;
     }
     HIP_TRY(hipSetDevice(c->device));
+    const bool ragged = (sizeX % kBlock) != 0 || (sizeY % kBlock) != 0;
+    // An image whose WIDTH is whole blocks but whose last block row is partial (BASELINE config 1's shape class: 1024 x 618): every block row but the last
+    // is on the fast path (its dither chain is the seed's orbit, the noise table applies); only the last row needs the host to walk its chain.
+    if (ragged && sizeX % kBlock == 0 && sizeY > (size_t)kBlock && dInfo && chainPhase == 0 && batchCount == 1 && !x.inner && !x.fitOnly && !c->forceSplit &&
+        c->opt.legacy_float_stage == 0 && c->opt.dither_pcg == 0 && c->opt.test_whole_image_ragged == 0)
+    {
+      size_t ckCount = 0, ckEvery = 0;
+      (void)noise_checkpoints_host(&ckCount, &ckEvery);
+      if (((sizeX / kBlock) * ((sizeY + kBlock - 1) / kBlock)) * 3 <= ckCount * ckEvery)
+        return encode_height_ragged(c, dIn, sizeX, sizeY, hasAlpha, dInfo, compact, errorFactor, poolThreads, fast, stream, x);
+    }
+    auto mark_if = [&](int level) { if (x.marks >= level) mark(c, stream); };
 
     EncodeParams p;
     memset(&p, 0, sizeof(p));
@@ -300,28 +376,32 @@ namespace
     const bool forced = c->opt.forced_shift[0] >= 0 && c->opt.forced_shift[0] <= 8 && c->opt.forced_shift[1] >= 0 && c->opt.forced_shift[1] <= 8 &&
                         c->opt.forced_shift[2] >= 0 && c->opt.forced_shift[2] <= 8;
     for (int i = 0; i < 3; i++) p.forced[i] = forced ? c->opt.forced_shift[i] : -1;
-    p.floatFast = (c->opt.float_mode == 1 && !fitOnly) ? 1 : 0;
+    p.floatFast = (c->opt.float_mode == 1 && !x.fitOnly) ? 1 : 0;
     p.recordLimit = c->opt.test_record_limit > 0 ? c->opt.test_record_limit - 1 : 2700; // see kTermBias in limg_hip_kernels.hip: 3 * 2700 + 1 < 0x2000
-    const Partition pt = partition(sizeY, poolThreads);
+    const Partition pt = x.part ? *x.part : partition(sizeY, poolThreads);
     p.chainCount = pt.chainCount; p.chainRows = pt.chainRows;
 
     p.batchCount = (uint32_t)batchCount;
     p.imageStrips = p.stripsX * p.blocksY;
     const size_t blocks = (size_t)p.blocksX * p.blocksY * batchCount, strips = (size_t)p.stripsX * p.blocksY * batchCount; // of all images
+    // the per-block / per-strip scratch: sized for the larger encode this call may be a part of, addressed from this part's first block row
+    const size_t scratchRows = x.scratchRows > (size_t)p.blocksY * batchCount ? x.scratchRows : (size_t)p.blocksY * batchCount;
+    const size_t scratchBlocks = scratchRows * p.blocksX, scratchStrips = scratchRows * p.stripsX;
+    const size_t blockOff = x.scratchRow0 * p.blocksX, stripOff = x.scratchRow0 * p.stripsX;
     limg_hip_result r;
-    if (compact && compact->pRecords) p.records = compact->pRecords;
-    else { if ((r = c->records.ensure(blocks * sizeof(limg_hip_block_record))) != limg_hip_success) return r; p.records = (limg_hip_block_record *)c->records.p; }
-    if (compact && compact->pShifts) p.shifts = compact->pShifts;
-    else { if ((r = c->shifts.ensure(blocks * 4)) != limg_hip_success) return r; p.shifts = (uint32_t *)c->shifts.p; }
-    if ((r = c->invN.ensure(blocks * 16)) != limg_hip_success) return r;
-    p.invN = (float *)c->invN.p;
-    if ((r = c->stripCalls.ensure(strips * 4)) != limg_hip_success) return r;
-    if ((r = c->stripBase.ensure(strips * 4)) != limg_hip_success) return r;
-    p.stripCalls = (uint32_t *)c->stripCalls.p; p.stripBase = (uint32_t *)c->stripBase.p;
+    if (compact && compact->pRecords) p.records = compact->pRecords + blockOff;
+    else { if ((r = c->records.ensure(scratchBlocks * sizeof(limg_hip_block_record))) != limg_hip_success) return r; p.records = (limg_hip_block_record *)c->records.p + blockOff; }
+    if (compact && compact->pShifts) p.shifts = compact->pShifts + blockOff;
+    else { if ((r = c->shifts.ensure(scratchBlocks * 4)) != limg_hip_success) return r; p.shifts = (uint32_t *)c->shifts.p + blockOff; }
+    if ((r = c->invN.ensure(scratchBlocks * 16)) != limg_hip_success) return r;
+    p.invN = (float *)c->invN.p + blockOff * 4;
+    if ((r = c->stripCalls.ensure(scratchStrips * 4)) != limg_hip_success) return r;
+    if ((r = c->stripBase.ensure(scratchStrips * 4)) != limg_hip_success) return r;
+    p.stripCalls = (uint32_t *)c->stripCalls.p + stripOff; p.stripBase = (uint32_t *)c->stripBase.p + stripOff;
     p.storePlanes = dInfo != nullptr;
     p.fullPlanes = fullPlanes;
-    p.streamRaw = streamRaw && !fullPlanes;
-    p.fitOnly = fitOnly && !dInfo;
+    p.streamRaw = x.streamRaw && !fullPlanes;
+    p.fitOnly = x.fitOnly && !dInfo;
     if (dInfo) p.io.info = *dInfo;
     // 16-byte vector access straight on caller pointers only where the address is 16-byte aligned for every row: sliced or offset
     // device pointers take the dword paths
@@ -338,7 +418,6 @@ namespace
     p.vecDecoded = dInfo && fullPlanes && (sizeX % 4 == 0) && (((uintptr_t)dInfo->pDecoded) & 15u) == 0;
     p.vecFactors = dInfo && (sizeX % 16 == 0) && ((((uintptr_t)dInfo->pFactorsA) | ((uintptr_t)dInfo->pFactorsB) | ((uintptr_t)dInfo->pFactorsC)) & 15u) == 0;
     const int channels = hasAlpha ? 4 : 3;
-    const bool ragged = (sizeX % kBlock) != 0 || (sizeY % kBlock) != 0;
     if (batchCount > 1)
     { // the 16-byte access paths only if every image of the batch allows them; the table goes to the device behind whatever the stream still holds
       for (size_t i = 1; i < batchCount; i++)
@@ -361,53 +440,40 @@ namespace
     {
       // longest chain, in blocks: every block makes at most 3 dither calls
       uint32_t maxRows = p.blocksY;
-      if (pt.chainCount > 1) maxRows = p.blocksY - (pt.chainCount - 1) * pt.chainRows; // the last chain takes the remainder, never fewer rows than the others
-      if ((r = grow_noise_table(c, ((size_t)maxRows * p.blocksX + chainBlocksBefore) * 3, stream)) != limg_hip_success) return r;
+      if (pt.chainCount > 1 && (pt.chainCount - 1) * pt.chainRows < p.blocksY) maxRows = p.blocksY - (pt.chainCount - 1) * pt.chainRows; // the last chain takes the remainder, never fewer rows than the others
+      if ((r = grow_noise_table(c, ((size_t)maxRows * p.blocksX + x.chainBlocksBefore) * 3, stream)) != limg_hip_success) return r;
       p.noise = (const uint8_t *)c->noise.p;
       p.noiseLast = (uint32_t)(c->noiseCount - 1);
     }
 
     if (chainPhase != 0 && (ragged || !dInfo || poolThreads != 0)) return limg_hip_error_InvalidParameter; // a chain shared between GPUs: whole 8x8 blocks, one chain
-    p.chainCallsOut = chainPhase == 1 ? dChainCalls : nullptr;
-    p.chainBase = chainPhase == 2 ? dChainBase : nullptr;
+    p.chainCallsOut = chainPhase == 1 ? x.dChainCalls : nullptr;
+    p.chainBase = chainPhase == 2 ? x.dChainBase : nullptr;
     // The float stage as its own launch, one lane per block (limg_hip_fit_tpb.hip), wherever every block is a whole 8x8: the E step then starts from the records.
     p.prefit = (!ragged && c->opt.legacy_float_stage == 0 && (((uintptr_t)p.records) & 15u) == 0) ? 1 : 0; // k_fit_tpb stores records 16 bytes at a time
     const bool fused = dInfo != nullptr && !ragged && (!c->forceSplit || batchCount > 1) && chainPhase == 0;
     const bool wantStats = c->opt.collect_stats != 0 && dInfo != nullptr && chainPhase == 0;
     auto stats = [&]() -> limg_hip_result
     { // the reference's "Average Block Bits" counters (src/limg.cpp:1971-1999) of this encode, left on the device for limg_hip_last_stats
-      if (!wantStats) return limg_hip_success;
+      if (!wantStats || x.inner) return limg_hip_success;
       limg_hip_result rs;
       if ((rs = c->stats.ensure(30 * 8)) != limg_hip_success) return rs;
-      HIP_TRY(hipMemsetAsync(c->stats.p, 0, 30 * 8, stream));
+      if (!c->statsAccumulate) HIP_TRY(hipMemsetAsync(c->stats.p, 0, 30 * 8, stream));
       launch_shift_stats(p.shifts, p.blocksX, p.blocksY, p.blocksY * p.batchCount, p.sizeX, p.sizeY, (unsigned long long *)c->stats.p, stream);
-      c->statsStream = stream; c->statsState = 1; c->statsPixels = (uint64_t)sizeX * sizeY * batchCount;
+      c->statsStream = stream; c->statsState = 1;
+      c->statsPixels = (c->statsAccumulate ? c->statsPixels : 0) + (uint64_t)sizeX * sizeY * batchCount;
       return limg_hip_success;
     };
-    if (chainPhase == 0) c->statsState = 0;
-    if (batchCount > 1 && (!fused || !p.prefit || !fullPlanes)) return limg_hip_error_InvalidParameter; // the caller falls back to one encode per image
+    if (chainPhase == 0 && !x.inner && !c->statsAccumulate) c->statsState = 0;
+    if (batchCount > 1 && (!fused || !p.prefit || !fullPlanes)) return limg_hip_error_InvalidParameter; // (limg_hip_encode3d_batch_device sends such lists through one encode per image instead)
     if (fused)
     { // the persistent kernel's ticket (16 B) and one 8-byte look-back descriptor per work strip, zero at its start: k_fit_tpb clears them on its way (one launch
       // and its gaps less per image); without that kernel, a memset
-      if ((r = c->lookback.ensure(16 + strips * 8)) != limg_hip_success) return r;
+      if ((r = c->lookback.ensure(16 * (batchCount + 1) + strips * 8)) != limg_hip_success) return r; // (room for one ticket per sub-batch)
       p.ticket = (uint32_t *)c->lookback.p;
       p.desc = (unsigned long long *)((uint8_t *)c->lookback.p + 16);
       p.zeroLookback = p.prefit ? 1 : 0;
       if (!p.prefit) HIP_TRY(hipMemsetAsync(c->lookback.p, 0, 16 + strips * 8, stream));
-    }
-    if (p.prefit && chainPhase != 2)
-    {
-      mark(c, stream);
-      launch_fit_tpb(p, channels, stream);
-      if (p.fitOnly)
-      { // pass 1 of the merged-block encoder: the records are all it wants
-        mark(c, stream); mark(c, stream); mark(c, stream);
-        HIP_TRY(hipGetLastError());
-        return limg_hip_success;
-      }
-    }
-    if (fused)
-    {
       if (!c->devStatus.p)
       {
         if ((r = c->devStatus.ensure(16)) != limg_hip_success) return r;
@@ -415,14 +481,76 @@ namespace
       }
       p.timeout = (uint32_t *)c->devStatus.p;
       p.compactOut = compact != nullptr || wantStats; // the statistics are reduced from the raster-order shift words
-      if ((r = c->park.ensure((size_t)(c->persistentWorkgroups / 5 * 8) * 2 * 8192)) != limg_hip_success) return r; // room for up to 8 workgroups per CU (A/B builds)
+      if ((r = c->park.ensure((size_t)(c->persistentWorkgroups / 5 * 6) * 2 * 8192)) != limg_hip_success) return r; // 6 workgroups per CU: the kernel's launch bound
       p.park = (uint8_t *)c->park.p;
-      mark(c, stream);
-      int wgPerCu = p.prefit ? 6 : 5; // 6 workgroups per CU once the float stage is out (7 fit and were measured: no faster)
-      if (const char *e = getenv("LIMG_HIP_WG_PER_CU")) wgPerCu = atoi(e) > 0 ? atoi(e) : wgPerCu; // A/B of builds with other launch bounds (tools/ab.sh)
-      launch_encode_persistent(p, channels, c->persistentWorkgroups / 5 * wgPerCu, stream); // 6 workgroups per CU once the float stage is out (7 fit and were measured: no faster, the kernel is issue-bound)
-      mark(c, stream); mark(c, stream);
-      if (!p.prefit) mark(c, stream); // 4 events per encode: with the float stage as its own launch the intervals are {k_fit_tpb, k_encode_persistent, -}
+    }
+    // workgroups per CU of the persistent kernel: 6 once the float stage is out (7 fit and were measured: no faster, the kernel is issue-bound), 5 with it inside;
+    // limg_hip_options.test_wg_per_cu lowers it (A/B runs), never above the launch bound the park slots are sized for
+    auto wg_per_cu = [&](int deflt) { const int t = c->opt.test_wg_per_cu; return (t >= 1 && t < deflt) ? t : deflt; };
+
+    // A list of images as a PIPELINE of launch pairs (limg_hip_options.batch_sub_images): k_fit_tpb of sub-batch k + 1 runs on a stream of the context's own next to
+    // the persistent kernel of sub-batch k.  On content with short searches (BASELINE configs 2 / 4: ~2 trials per block) the persistent kernel waits for its plane
+    // stores a third of the time while k_fit_tpb is pure vector work: side by side they fill each other's gaps.  The persistent kernel leaves the float stage room
+    // to be resident: 5 workgroups per CU instead of 6 (at 6 x 80 VGPRs nothing else fits on a SIMD) for every sub-batch but the last.
+    const size_t subImages = (fused && batchCount > 1 && p.prefit && c->opt.batch_sub_images > 0) ? (size_t)c->opt.batch_sub_images : 0;
+    if (subImages > 0 && subImages < batchCount)
+    {
+      const size_t nSub = (batchCount + subImages - 1) / subImages;
+      if ((r = ensure_pipe_events(c, 2 * nSub + 1)) != limg_hip_success) return r;
+      const size_t imgBlocks = (size_t)p.blocksX * p.blocksY, imgStrips = (size_t)p.imageStrips;
+      auto sub = [&](size_t k) -> EncodeParams
+      {
+        EncodeParams q = p;
+        const size_t i0 = k * subImages, n = batchCount - i0 < subImages ? batchCount - i0 : subImages;
+        q.batch = p.batch + i0; q.batchCount = (uint32_t)n;
+        q.io = batch[i0]; // (what the kernels read when a sub-batch is a single image)
+        q.records = p.records + i0 * imgBlocks; q.shifts = p.shifts + i0 * imgBlocks; q.invN = p.invN + i0 * imgBlocks * 4;
+        uint8_t *lb = (uint8_t *)c->lookback.p + k * 16 + i0 * imgStrips * 8; // sub-batch k: its ticket, then the descriptors of its strips
+        q.ticket = (uint32_t *)lb; q.desc = (unsigned long long *)(lb + 16);
+        return q;
+      };
+      hipStream_t fs = c->fitStream;
+      hipEvent_t *ev = c->pipeEvents.data(); // [0]: fork; [1 + 2 k]: k_fit_tpb of sub-batch k done; [2 + 2 k]: the persistent kernel of sub-batch k is next on `stream`
+      mark_if(1);
+      HIP_TRY(hipEventRecord(ev[0], stream)); // everything the caller's stream holds so far (inputs, the image table, earlier encodes that use the scratch)
+      HIP_TRY(hipStreamWaitEvent(fs, ev[0], 0));
+      launch_fit_tpb(sub(0), channels, fs);
+      HIP_TRY(hipEventRecord(ev[1], fs));
+      for (size_t k = 0; k < nSub; k++)
+      {
+        HIP_TRY(hipStreamWaitEvent(stream, ev[1 + 2 * k], 0));
+        if (k == 0) mark_if(1); // (k_fit_tpb of the first sub-batch: the only float-stage work that runs alone)
+        if (k + 1 < nSub)
+        {
+          HIP_TRY(hipEventRecord(ev[2 + 2 * k], stream));
+          HIP_TRY(hipStreamWaitEvent(fs, ev[2 + 2 * k], 0));
+          launch_fit_tpb(sub(k + 1), channels, fs);
+          HIP_TRY(hipEventRecord(ev[3 + 2 * k], fs));
+        }
+        launch_encode_persistent(sub(k), channels, c->persistentWorkgroups / 5 * wg_per_cu(k + 1 < nSub ? 5 : 6), stream);
+      }
+      mark_if(1); mark_if(2);
+      HIP_TRY(hipGetLastError());
+      return stats();
+    }
+
+    if (p.prefit && chainPhase != 2)
+    {
+      mark_if(1);
+      launch_fit_tpb(p, channels, stream);
+      if (p.fitOnly)
+      { // pass 1 of the merged-block encoder: the records are all it wants
+        mark_if(1); mark_if(1); mark_if(2);
+        HIP_TRY(hipGetLastError());
+        return limg_hip_success;
+      }
+    }
+    if (fused)
+    {
+      mark_if(1);
+      launch_encode_persistent(p, channels, c->persistentWorkgroups / 5 * wg_per_cu(p.prefit ? 6 : 5), stream);
+      mark_if(1);
+      if (p.prefit) mark_if(2); else { mark_if(1); mark_if(2); } // 4 events per encode: with the float stage as its own launch the intervals are {k_fit_tpb, k_encode_persistent, -}
       HIP_TRY(hipGetLastError());
       return stats();
     }
@@ -435,12 +563,12 @@ namespace
       HIP_TRY(hipGetLastError());
       return limg_hip_success;
     }
-    if (!p.prefit) mark(c, stream); // split path intervals: {k_fit_tpb + k_fit_search, scan, k_dither_store}
+    if (!p.prefit) mark_if(1); // split path intervals: {k_fit_tpb + k_fit_search, scan, k_dither_store}
     launch_fit_search(p, channels, stream);
-    if (chainPhase != 1) mark(c, stream);
+    if (chainPhase != 1) mark_if(1);
     if (!dInfo)
     {
-      mark(c, stream); mark(c, stream);
+      mark_if(1); mark_if(2);
       HIP_TRY(hipGetLastError());
       return limg_hip_success; // `_perf` behaviour: nothing to dither into, nothing to store
     }
@@ -457,42 +585,99 @@ namespace
     }
     else
     {
-      // Partial edge blocks: the chain walk depends on each block's pixel count (G_N), so it is evaluated in raster
-      // order on the host from the per-block call counts (blocking; rare shape class -- config #1 is one).
-      std::vector<uint32_t> hShifts(blocks), hBase(strips);
-      HIP_TRY(hipMemcpyAsync(hShifts.data(), p.shifts, blocks * 4, hipMemcpyDeviceToHost, stream));
+      // Partial edge blocks: the chain walk depends on each block's pixel count (a call over N pixels is N / 8 AES rounds + N % 8 PCG steps: G_N), so it is
+      // evaluated in raster order on the host from the per-block call counts (blocking).  What crosses PCIe: the shift words down, then -- through pinned
+      // staging -- the strips' first call indices and 64 noise bytes per call up.
+      const size_t stageBytes = ((blocks * 4 + 15) & ~(size_t)15) + 16 + ((strips * 4 + 15) & ~(size_t)15);
+      if ((r = c->hStage.ensure(stageBytes + (blocks * 3 + 1) * 64)) != limg_hip_success) return r;
+      uint32_t *hShifts = (uint32_t *)c->hStage.p;
+      unsigned long long *hPrev = (unsigned long long *)((uint8_t *)c->hStage.p + ((blocks * 4 + 15) & ~(size_t)15));
+      uint32_t *hBase = (uint32_t *)(hPrev + 2);
+      uint8_t *hNoise = (uint8_t *)c->hStage.p + stageBytes;
+      HIP_TRY(hipMemcpyAsync(hShifts, p.shifts, blocks * 4, hipMemcpyDeviceToHost, stream));
+      if (x.dPrevDesc) HIP_TRY(hipMemcpyAsync(hPrev, x.dPrevDesc, 8, hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
-      size_t totalCalls = 0;
-      for (size_t i = 0; i < blocks; i++) totalCalls += hShifts[i] >> 24;
-      std::vector<uint8_t> hNoise((totalCalls + 1) * 64);
-      uint64_t h = kDitherSeed;
+      uint64_t h0 = kDitherSeed;
+      if (x.dPrevDesc)
+      { // the block rows above this sub-image ran through the persistent kernel: every strip's descriptor ends as the inclusive call count of its chain
+        if ((uint32_t)(*hPrev >> 32) != 2u || !chain_value_at((uint32_t)*hPrev, &h0))
+        {
+          fprintf(stderr, "limg_hip: the chain position of the last block row is unavailable (descriptor %016llx)\n", *hPrev);
+          return limg_hip_error_Generic;
+        }
+      }
+      uint64_t h = h0;
       size_t call = 0;
       for (uint32_t by = 0; by < p.blocksY; by++)
       {
-        if (by == 0 || chain_of_row(pt, by) != chain_of_row(pt, by - 1)) h = kDitherSeed;
+        if (by != 0 && chain_of_row(pt, by) != chain_of_row(pt, by - 1)) h = kDitherSeed;
         const unsigned ry = (unsigned)((sizeY - (size_t)by * kBlock) < kBlock ? (sizeY - (size_t)by * kBlock) : kBlock);
         for (uint32_t bx = 0; bx < p.blocksX; bx++)
         {
           if (bx % kStripBlocks == 0) hBase[(size_t)by * p.stripsX + bx / kStripBlocks] = (uint32_t)call;
           const unsigned rx = (unsigned)((sizeX - (size_t)bx * kBlock) < kBlock ? (sizeX - (size_t)bx * kBlock) : kBlock);
           const uint32_t calls = hShifts[(size_t)by * p.blocksX + bx] >> 24;
-          for (uint32_t k = 0; k < calls; k++, call++) h = chain_call(h, rx * ry, hNoise.data() + call * 64, false, c->opt.dither_pcg != 0);
+          for (uint32_t k = 0; k < calls && call < blocks * 3; k++, call++) h = chain_call(h, rx * ry, hNoise + call * 64, false, c->opt.dither_pcg != 0);
         }
       }
-      if ((r = c->noiseDyn.ensure(hNoise.size())) != limg_hip_success) return r;
-      HIP_TRY(hipMemcpyAsync(c->noiseDyn.p, hNoise.data(), hNoise.size(), hipMemcpyHostToDevice, stream));
-      HIP_TRY(hipMemcpyAsync(p.stripBase, hBase.data(), strips * 4, hipMemcpyHostToDevice, stream));
-      HIP_TRY(hipStreamSynchronize(stream)); // the host vectors die with this scope
+      const size_t totalCalls = call;
+      if ((r = c->noiseDyn.ensure((totalCalls + 1) * 64)) != limg_hip_success) return r;
+      HIP_TRY(hipMemcpyAsync(c->noiseDyn.p, hNoise, (totalCalls + 1) * 64, hipMemcpyHostToDevice, stream));
+      HIP_TRY(hipMemcpyAsync(p.stripBase, hBase, strips * 4, hipMemcpyHostToDevice, stream));
+      // (the staging buffer is the context's: the next encode that uses it synchronises with this stream before it writes -- see the D2H above)
       p.noise = (const uint8_t *)c->noiseDyn.p;
       p.noiseLast = (uint32_t)totalCalls;
     }
-    mark(c, stream);
+    mark_if(1);
     launch_dither_store(p, channels, stream);
-    mark(c, stream);
+    mark_if(2);
     HIP_TRY(hipGetLastError());
     return stats();
   }
+
+  // sizeX % 8 == 0, sizeY % 8 != 0, at least two block rows (reference: the rx x ry gather of src/limg.cpp:1899-1905 only ever sees ry < 8 in the last block row,
+  // and a dither call over 8 ry pixels is ry AES rounds, :824-879): the block rows above the last one are an image of whole blocks -- k_fit_tpb + persistent kernel
+  // with the chain partition of the WHOLE image -- and the last row goes through the split path's kernels as a one-row sub-image whose chain starts where the
+  // persistent kernel's last strip left it: that call count is the low word of the strip's look-back descriptor, and the chain value there comes from the embedded
+  // checkpoints (at most 1023 calls on foot).  The host's share is then one block row: blocksX shift words down, <= 3 blocksX calls of ry rounds, their noise up.
+  limg_hip_result encode_height_ragged(limg_hip_context *c, const uint32_t *dIn, size_t sizeX, size_t sizeY, int hasAlpha, const limg_hip_encode3d_info *dInfo,
+                                       const limg_hip_compact_out *compact, uint32_t errorFactor, int poolThreads, int fast, hipStream_t stream, const EncodeExtra &x)
+  {
+    const size_t topY = (sizeY / kBlock) * kBlock, blocksX = sizeX / kBlock, blocksY = topY / kBlock + 1, stripsX = (blocksX + kStripBlocks - 1) / kStripBlocks;
+    const Partition pt = partition(sizeY, poolThreads);
+    c->chainIn = nullptr;
+    c->statsState = 0;
+    limg_hip_result r;
+    EncodeExtra xt;
+    xt.streamRaw = x.streamRaw; xt.inner = true; xt.marks = 1; xt.part = &pt; xt.scratchRows = blocksY;
+    if ((r = encode_device(c, dIn, sizeX, topY, hasAlpha, dInfo, compact, errorFactor, poolThreads, fast, stream, xt)) != limg_hip_success) return r;
+    // the last block row
+    limg_hip_encode3d_info low = *dInfo;
+    {
+      void **pp = reinterpret_cast<void **>(&low);
+      for (int i = 0; i < 8; i++) if (pp[i]) pp[i] = (uint32_t *)pp[i] + topY * sizeX;
+      for (int i = 8; i < 11; i++) pp[i] = (uint8_t *)pp[i] + topY * sizeX;
+    }
+    EncodeExtra xb;
+    xb.streamRaw = x.streamRaw; xb.inner = true; xb.marks = 0; xb.scratchRow0 = blocksY - 1; xb.scratchRows = blocksY;
+    const Partition one = { 1, 0 };
+    xb.part = &one;
+    const bool sameChain = chain_of_row(pt, (uint32_t)blocksY - 1) == chain_of_row(pt, (uint32_t)blocksY - 2);
+    if (sameChain) xb.dPrevDesc = (const unsigned long long *)((const uint8_t *)c->lookback.p + 16) + ((blocksY - 1) * stripsX - 1);
+    if ((r = encode_device(c, dIn + topY * sizeX, sizeX, sizeY - topY, hasAlpha, &low, compact, errorFactor, 0, fast, stream, xb)) != limg_hip_success) return r;
+    mark(c, stream);
+    if (c->opt.collect_stats != 0)
+    {
+      if ((r = c->stats.ensure(30 * 8)) != limg_hip_success) return r;
+      HIP_TRY(hipMemsetAsync(c->stats.p, 0, 30 * 8, stream));
+      const uint32_t *shifts = (compact && compact->pShifts) ? compact->pShifts : (const uint32_t *)c->shifts.p;
+      launch_shift_stats(shifts, (uint32_t)blocksX, (uint32_t)blocksY, (uint32_t)blocksY, (uint32_t)sizeX, (uint32_t)sizeY, (unsigned long long *)c->stats.p, stream);
+      c->statsStream = stream; c->statsState = 1; c->statsPixels = (uint64_t)sizeX * sizeY;
+    }
+    return limg_hip_success;
+  }
 }
+
 
 extern "C"
 {
@@ -540,6 +725,9 @@ extern "C"
     for (DevBuf *b : bufs) b->release();
     HostBuf *hbufs[] = { &c->hFlags, &c->hRec, &c->hBits, &c->hDesc, &c->hOut, &c->hNoise, &c->hNoiseBase };
     for (HostBuf *b : hbufs) b->release();
+    c->hStage.release();
+    if (c->fitStream) (void)hipStreamDestroy(c->fitStream);
+    for (hipEvent_t e : c->pipeEvents) (void)hipEventDestroy(e);
     if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
     if (c->workStream) (void)hipStreamDestroy(c->workStream);
     for (hipEvent_t e : c->workEvent) if (e) (void)hipEventDestroy(e);
@@ -555,6 +743,13 @@ extern "C"
     if (!c || !o) return limg_hip_error_ArgumentNull;
     c->opt = *o;
     c->forceSplit = o->force_split_kernels != 0;
+    return limg_hip_success;
+  }
+
+  limg_hip_result limg_hip_get_options(const limg_hip_context *c, limg_hip_options *o)
+  {
+    if (!c || !o) return limg_hip_error_ArgumentNull;
+    *o = c->opt;
     return limg_hip_success;
   }
 
@@ -575,6 +770,13 @@ extern "C"
         fprintf(stderr, "limg_hip: look-back timeout in the fused encode kernel\n");
         return limg_hip_error_Generic;
       }
+      HIP_TRY(hipMemcpy(&word, (const uint8_t *)c->devStatus.p + 4, 4, hipMemcpyDeviceToHost));
+      if (word != 0)
+      {
+        HIP_TRY(hipMemset((uint8_t *)c->devStatus.p + 4, 0, 4));
+        fprintf(stderr, "limg_hip: a rank of the communicator aborted a single-chain encode; this rank's planes of that encode were not written\n");
+        return limg_hip_error_Generic;
+      }
     }
     if (c->streamStatus.p)
     {
@@ -593,6 +795,7 @@ extern "C"
   limg_hip_result limg_hip_last_stats(limg_hip_context *c, uint64_t *pCounters30, uint64_t *pPixels)
   {
     if (!c || !pCounters30) return limg_hip_error_ArgumentNull;
+    std::lock_guard<std::recursive_mutex> hostLock(c->hostEntry); // (the host-pointer entries write this state under the same lock)
     if (c->statsState == 0) return limg_hip_error_InvalidParameter; // no encode with limg_hip_options.collect_stats since the last reset
     if (c->statsState == 1)
     {
@@ -643,8 +846,7 @@ extern "C"
     if (!c->noiseCk.p)
     {
       limg_hip_result r;
-      if ((r = c->noiseCk.ensure(ckCount * 8)) != limg_hip_success) return r;
-      HIP_TRY(hipMemcpyAsync(c->noiseCk.p, ck, ckCount * 8, hipMemcpyHostToDevice, (hipStream_t)stream));
+      if ((r = upload_checkpoints(c, ck, ckCount)) != limg_hip_success) return r;
     }
     launch_noise_fill(pOutDevice, (const uint64_t *)c->noiseCk.p, calls, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
@@ -681,9 +883,12 @@ extern "C"
   size_t limg_hip_context_device_bytes(const limg_hip_context *c)
   {
     if (!c) return 0;
-    return c->records.cap + c->shifts.cap + c->stripCalls.cap + c->stripBase.cap + c->noise.cap + c->noiseDyn.cap + c->lookback.cap + c->park.cap + c->in.cap + c->planes.cap + c->cmp.cap +
-           c->streamFac.cap + c->streamTiles.cap + c->streamStatus.cap + c->streamBuf.cap + c->bMatch.cap + c->bRegions.cap + c->bOut.cap + c->bPx.cap + c->bV.cap +
-           c->bFac.cap + c->bNoise.cap + c->bNoiseBase.cap;
+    const DevBuf *bufs[] = { &c->records, &c->shifts, &c->invN, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->noiseCk, &c->lookback, &c->park, &c->batchTable, &c->stats,
+                             &c->accTable, &c->devStatus, &c->commWords, &c->in, &c->planes, &c->cmp, &c->streamFac, &c->streamTiles, &c->streamStatus, &c->streamBuf,
+                             &c->bFlags, &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bV, &c->bFac, &c->bNoise, &c->bNoiseBase };
+    size_t sum = 0;
+    for (const DevBuf *b : bufs) sum += b->cap;
+    return sum;
   }
 
   limg_hip_result limg_hip_encode3d_device(limg_hip_context *c, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, const limg_hip_encode3d_info *pInfo,
@@ -723,22 +928,24 @@ extern "C"
     if (c->opt.test_batch_chunk > 0) chunk = (size_t)c->opt.test_batch_chunk;
     const bool oneByOne = count == 1 || ragged || !full || c->opt.legacy_float_stage != 0 || c->forceSplit;
     std::vector<ImageIO> table;
-    for (size_t i0 = 0; i0 < count;)
+    limg_hip_result r = limg_hip_success;
+    for (size_t i0 = 0; i0 < count && r == limg_hip_success;)
     {
       const size_t n = oneByOne ? 1 : (count - i0 < chunk ? count - i0 : chunk);
-      limg_hip_result r;
+      c->statsAccumulate = i0 != 0; // limg_hip_last_stats: all images of the list together, however many launch pairs it took
       if (n == 1) r = encode_device(c, ppIn[i0], sizeX, sizeY, hasAlpha, &pInfos[i0], nullptr, errorFactor, poolThreads, fastBitCrushing, (hipStream_t)stream);
       else
       {
         table.resize(n);
         for (size_t i = 0; i < n; i++) { table[i].in = ppIn[i0 + i]; table[i].info = pInfos[i0 + i]; }
-        r = encode_device(c, ppIn[i0], sizeX, sizeY, hasAlpha, &pInfos[i0], nullptr, errorFactor, poolThreads, fastBitCrushing, (hipStream_t)stream, false, false, 0, nullptr, nullptr, 0,
-                          table.data(), n);
+        EncodeExtra x;
+        x.batch = table.data(); x.batchCount = n;
+        r = encode_device(c, ppIn[i0], sizeX, sizeY, hasAlpha, &pInfos[i0], nullptr, errorFactor, poolThreads, fastBitCrushing, (hipStream_t)stream, x);
       }
-      if (r != limg_hip_success) return r;
       i0 += n;
     }
-    return limg_hip_success;
+    c->statsAccumulate = false;
+    return r;
   }
 
   limg_hip_result limg_hip_encode3d_chain_device(limg_hip_context *c, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, const limg_hip_encode3d_info *pInfo,
@@ -754,14 +961,31 @@ extern "C"
                        c->chainBefore != blocksBefore))
       return limg_hip_error_InvalidParameter; // no matching phase 1 pending
     c->chainIn = nullptr;
-    const limg_hip_result r = encode_device(c, pIn, sizeX, sizeY, hasAlpha, pInfo, nullptr, errorFactor, 0, fastBitCrushing, (hipStream_t)stream, false, false, phase,
-                         (unsigned long long *)pCallsDevice, (const unsigned long long *)pChainBaseDevice, blocksBefore);
+    EncodeExtra x;
+    x.chainPhase = phase; x.dChainCalls = (unsigned long long *)pCallsDevice; x.dChainBase = (const unsigned long long *)pChainBaseDevice; x.chainBlocksBefore = blocksBefore;
+    const limg_hip_result r = encode_device(c, pIn, sizeX, sizeY, hasAlpha, pInfo, nullptr, errorFactor, 0, fastBitCrushing, (hipStream_t)stream, x);
     if (r == limg_hip_success && phase == 1)
     {
       c->chainIn = pIn; c->chainX = sizeX; c->chainY = sizeY; c->chainBefore = blocksBefore;
       c->chainFac[0] = pInfo->pFactorsA; c->chainFac[1] = pInfo->pFactorsB; c->chainFac[2] = pInfo->pFactorsC;
       c->chainAlpha = hasAlpha != 0; c->chainEf = errorFactor; c->chainFast = fastBitCrushing != 0;
     }
+    return r;
+  }
+
+  // The reference's limg_encode3d_test accumulates its bit statistics on its own stack (`accum_bits`, src/limg.cpp:1975-1976) and prints them before it returns
+  // (:2232-2248): they are always the statistics of THAT call, whatever other threads encode meanwhile.  Same here: the counters are fetched inside the region the
+  // context's mutex covers, and collect_stats is switched on for this call only -- no option of a shared context is modified for good.
+  limg_hip_result limg_hip_encode3d_stats(limg_hip_context *c, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, limg_hip_encode3d_info *pInfo, uint32_t errorFactor,
+                                          int poolThreads, int fastBitCrushing, uint64_t *pCounters30, uint64_t *pPixels)
+  {
+    if (!c || !pCounters30) return limg_hip_error_ArgumentNull;
+    std::lock_guard<std::recursive_mutex> hostLock(c->hostEntry);
+    const int32_t was = c->opt.collect_stats;
+    c->opt.collect_stats = 1;
+    limg_hip_result r = limg_hip_encode3d(c, pIn, sizeX, sizeY, hasAlpha, pInfo, errorFactor, poolThreads, fastBitCrushing);
+    if (r == limg_hip_success) r = limg_hip_last_stats(c, pCounters30, pPixels);
+    c->opt.collect_stats = was;
     return r;
   }
 
@@ -887,7 +1111,9 @@ extern "C"
     memset(&info, 0, sizeof(info));
     info.pFactorsA = (uint8_t *)c->streamFac.p; info.pFactorsB = info.pFactorsA + planeStride; info.pFactorsC = info.pFactorsB + planeStride;
     limg_hip_compact_out comp = { (limg_hip_block_record *)c->records.p, (uint32_t *)c->shifts.p };
-    if ((r = encode_device(c, pIn, sizeX, sizeY, hasAlpha, &info, &comp, errorFactor, poolThreads, fastBitCrushing, s, true)) != limg_hip_success) return r;
+    EncodeExtra xs;
+    xs.streamRaw = true;
+    if ((r = encode_device(c, pIn, sizeX, sizeY, hasAlpha, &info, &comp, errorFactor, poolThreads, fastBitCrushing, s, xs)) != limg_hip_success) return r;
 
     StreamParams sp;
     memset(&sp, 0, sizeof(sp));
@@ -1069,7 +1295,9 @@ extern "C"
     limg_hip_result r;
 
     // pass 1 (src/limg.cpp:1088-1119): every block's own fit = the 8x8 path's E step, records only
-    if ((r = encode_device(c, pIn, sizeX, sizeY, hasAlpha, nullptr, nullptr, errorFactor, 0, fastBitCrushing, s, false, true)) != limg_hip_success) return r;
+    EncodeExtra x1;
+    x1.fitOnly = true;
+    if ((r = encode_device(c, pIn, sizeX, sizeY, hasAlpha, nullptr, nullptr, errorFactor, 0, fastBitCrushing, s, x1)) != limg_hip_success) return r;
 
     BlockedParams bp;
     memset(&bp, 0, sizeof(bp));
@@ -1313,6 +1541,19 @@ extern "C"
     return limg_hip_success;
   }
 
+  limg_hip_result limg_hip_blocked_encode3d_stats(limg_hip_context *c, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, limg_hip_blocked_encode3d_info *pInfo,
+                                                  uint32_t errorFactor, int fastBitCrushing, uint64_t *pCounters30, uint64_t *pPixels)
+  { // (see limg_hip_encode3d_stats; upstream: src/limg.cpp:1561-1590 counters, printed by limg_blocked_encode3d_test itself)
+    if (!c || !pCounters30) return limg_hip_error_ArgumentNull;
+    std::lock_guard<std::recursive_mutex> hostLock(c->hostEntry);
+    const int32_t was = c->opt.collect_stats;
+    c->opt.collect_stats = 1;
+    limg_hip_result r = limg_hip_blocked_encode3d(c, pIn, sizeX, sizeY, hasAlpha, pInfo, errorFactor, fastBitCrushing);
+    if (r == limg_hip_success) r = limg_hip_last_stats(c, pCounters30, pPixels);
+    c->opt.collect_stats = was;
+    return r;
+  }
+
   limg_hip_result limg_hip_blocked_encode3d(limg_hip_context *c, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, limg_hip_blocked_encode3d_info *pInfo, uint32_t errorFactor,
                                             int fastBitCrushing)
   {
@@ -1379,9 +1620,28 @@ extern "C"
     memcpy(&id, pId, sizeof(id));
     NCCL_TRY(rccl().CommInitRank(&c->comm, worldSize, id, rank));
     c->commRank = rank; c->commWorld = worldSize;
-    const limg_hip_result r = c->commWords.ensure((8 + 2 * (size_t)worldSize) * 8); // [0] own value, [1] chain base, [2..3] own (size, capacity), [8 ...] gathered
-    if (r != limg_hip_success) return r;
+    limg_hip_result r2 = c->commWords.ensure((8 + 2 * (size_t)worldSize) * 8); // [0] own value, [1] chain base, [2..3] own (size, capacity), [8 ...] gathered
+    if (r2 != limg_hip_success) return r2;
     HIP_TRY(hipMemset(c->commWords.p, 0, (8 + 2 * (size_t)worldSize) * 8));
+    if (!c->devStatus.p)
+    { // the sticky status words (look-back timeout, aborted chain) exist from here on: the single-chain entry must not have to allocate on its error path
+      if ((r2 = c->devStatus.ensure(16)) != limg_hip_success) return r2;
+      HIP_TRY(hipMemset(c->devStatus.p, 0, 16));
+    }
+    return limg_hip_success;
+  }
+
+  // What RCCL itself says about the context's communicator: ncclCommCount / ncclCommUserRank / ncclGetVersion.  For bench lines and logs -- a record that names
+  // the ranks RCCL saw cannot be produced by a job that silently ran on fewer.
+  limg_hip_result limg_hip_comm_info(limg_hip_context *c, int *pRank, int *pRanks, int *pRcclVersion)
+  {
+    if (!c) return limg_hip_error_ArgumentNull;
+    if (!c->comm) return limg_hip_error_InvalidParameter;
+    if (!rccl().ok || !rccl().CommCount || !rccl().CommUserRank || !rccl().GetVersion) return limg_hip_error_Generic;
+    int v = 0;
+    if (pRanks) NCCL_TRY(rccl().CommCount(c->comm, pRanks));
+    if (pRank) NCCL_TRY(rccl().CommUserRank(c->comm, pRank));
+    if (pRcclVersion) { NCCL_TRY(rccl().GetVersion(&v)); *pRcclVersion = v; }
     return limg_hip_success;
   }
 
@@ -1472,17 +1732,26 @@ extern "C"
   limg_hip_result limg_hip_encode3d_single_chain_device(limg_hip_context *c, const uint32_t *pIn, size_t sizeX, size_t stripRows, int hasAlpha, const limg_hip_encode3d_info *pInfo,
                                                         uint32_t errorFactor, int fastBitCrushing, size_t blocksBefore, void *stream)
   {
-    if (!c || !pIn || !pInfo) return limg_hip_error_ArgumentNull;
-    if (!c->comm) return limg_hip_error_InvalidParameter;
+    if (!c) return limg_hip_error_ArgumentNull;
+    if (!c->comm) return limg_hip_error_InvalidParameter; // no communicator: nobody is waiting for this rank
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     unsigned long long *words = (unsigned long long *)c->commWords.p;
     limg_hip_result r;
-    // E step + scan: this strip's dither calls land in words[0] ...
-    if ((r = limg_hip_encode3d_chain_device(c, pIn, sizeX, stripRows, hasAlpha, pInfo, errorFactor, fastBitCrushing, 1, (uint64_t *)words, nullptr, blocksBefore, s)) != limg_hip_success) return r;
+    // E step + scan: this strip's dither calls land in words[0] ...  (bad arguments on this rank are a phase-1 failure like any other: see the abort rule)
+    if (!pIn || !pInfo) r = limg_hip_error_ArgumentNull;
+    else if (c->opt.test_fail_chain_phase1 != 0) r = limg_hip_error_Generic;
+    else r = limg_hip_encode3d_chain_device(c, pIn, sizeX, stripRows, hasAlpha, pInfo, errorFactor, fastBitCrushing, 1, (uint64_t *)words, nullptr, blocksBefore, s);
+    // Abort rule: a rank whose phase 1 failed must STILL join the exchange -- its peers are (about to be) inside ncclAllGather and would wait for it forever -- and
+    // joins it with a poison value instead of a call count.  Every rank's k_chain_base then sees the poison: it hands the F step a poisoned base (k_dither_store
+    // returns without storing anything) and raises the context's sticky status word, so that the peers' limg_hip_check_device_status reports the aborted chain;
+    // this rank returns its own error.  (The reference's analogue -- row strips on a thread pool, src/limg.cpp:2114-2136 -- cannot half-fail.)
+    const limg_hip_result phase1 = r;
+    if (phase1 != limg_hip_success) HIP_TRY(hipMemsetAsync(words, 0xFF, 8, s));
     // ... one 8-byte all-gather, the exclusive prefix over the ranks before this one on the device (stream-ordered, no host round trip) ...
     NCCL_TRY(rccl().AllGather(words, words + 8, 1, ncclUint64, c->comm, s));
-    launch_chain_base(words + 8, c->commRank, words + 1, s);
+    launch_chain_base(words + 8, c->commRank, c->commWorld, words + 1, (uint32_t *)c->devStatus.p + 1, s);
+    if (phase1 != limg_hip_success) return phase1;
     // ... and the F step indexes the noise stream from there: the 8-GPU result equals the single-threaded reference's (src/limg.cpp:1893, :2110)
     return limg_hip_encode3d_chain_device(c, pIn, sizeX, stripRows, hasAlpha, pInfo, errorFactor, fastBitCrushing, 2, nullptr, (const uint64_t *)(words + 1), blocksBefore, s);
   }

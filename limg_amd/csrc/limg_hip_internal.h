@@ -105,7 +105,7 @@ namespace limg_hip
   void launch_strip_scan(const EncodeParams &p, hipStream_t s);
   void launch_dither_store(const EncodeParams &p, int channels, hipStream_t s);
   void launch_shift_stats(const uint32_t *dShifts, uint32_t blocksX, uint32_t blocksY, uint32_t rows, uint32_t sizeX, uint32_t sizeY, unsigned long long *dOut30, hipStream_t s);
-  void launch_chain_base(const unsigned long long *dCalls, int rank, unsigned long long *dBase, hipStream_t s);
+  void launch_chain_base(const unsigned long long *dCalls, int rank, int world, unsigned long long *dBase, uint32_t *dAborted, hipStream_t s);
 
   // ---- merged-block encoder (limg_hip_blocked.hip; reference: limg_blocked_encode3d_test, src/limg.cpp:1774-1885, :2329-2453) ----
   // similarity bits are precomputed for candidate offsets dx, dy in [-kMatchLo, +kMatchHi] blocks around every seed: rectangles grow right / down from

@@ -1662,6 +1662,7 @@ namespace limg_hip
     __global__ __launch_bounds__(kThreads) void k_dither_store(const EncodeParams p)
     {
       __shared__ __attribute__((aligned(16))) uint8_t s_lds[kPhaseFBytes + kStripBlocks * 48];
+      if (p.chainBase && *p.chainBase == ~0ull) return; // cross-GPU chain aborted by a rank (k_chain_base): nothing is stored, the status word is already raised
       dither_store_strip<CH, false>(p, p.io, blockIdx.x, blockIdx.x, 0u, 0u, s_lds, nullptr, (int)threadIdx.x);
     }
 
@@ -1778,12 +1779,19 @@ namespace limg_hip
 
   namespace
   {
-    // exclusive prefix over the ranks before `rank` of the all-gathered per-rank dither-call totals
-    __global__ void k_chain_base(const unsigned long long *calls, int rank, unsigned long long *base)
+    // exclusive prefix over the ranks before `rank` of the all-gathered per-rank dither-call totals.  A rank whose E step failed joins the all-gather with ~0: the
+    // base is then poisoned too (k_dither_store stores nothing) and the context's sticky "aborted chain" word is raised for limg_hip_check_device_status.
+    __global__ void k_chain_base(const unsigned long long *calls, int rank, int world, unsigned long long *base, uint32_t *aborted)
     {
       unsigned long long run = 0;
-      for (int r = 0; r < rank; r++) run += calls[r];
-      *base = run;
+      bool poison = false;
+      for (int r = 0; r < world; r++)
+      {
+        poison = poison || calls[r] == ~0ull;
+        if (r < rank) run += calls[r];
+      }
+      *base = poison ? ~0ull : run;
+      if (poison) *aborted = 1u;
     }
   }
   namespace
@@ -1822,7 +1830,10 @@ namespace limg_hip
     hipLaunchKernelGGL(k_shift_stats, dim3((uint32_t)((total + 4095u) / 4096u)), dim3(256), 0, s, dShifts, blocksX, blocksY, rows, sizeX, sizeY, dOut30);
   }
 
-  void launch_chain_base(const unsigned long long *dCalls, int rank, unsigned long long *dBase, hipStream_t s) { hipLaunchKernelGGL(k_chain_base, dim3(1), dim3(1), 0, s, dCalls, rank, dBase); }
+  void launch_chain_base(const unsigned long long *dCalls, int rank, int world, unsigned long long *dBase, uint32_t *dAborted, hipStream_t s)
+  {
+    hipLaunchKernelGGL(k_chain_base, dim3(1), dim3(1), 0, s, dCalls, rank, world, dBase, dAborted);
+  }
 
   void launch_strip_scan(const EncodeParams &p, hipStream_t s) { hipLaunchKernelGGL(k_strip_scan, dim3(1), dim3(1024), 0, s, p); }
 

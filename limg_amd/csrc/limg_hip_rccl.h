@@ -21,6 +21,9 @@ namespace limg_hip
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;      // (the three below are evidence for the bench line, not needed by the data path)
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
     bool ok = false;
   };
 
@@ -40,6 +43,7 @@ namespace limg_hip
       LIMG_RCCL_SYM(GetUniqueId, "ncclGetUniqueId"); LIMG_RCCL_SYM(CommInitRank, "ncclCommInitRank"); LIMG_RCCL_SYM(CommDestroy, "ncclCommDestroy");
       LIMG_RCCL_SYM(AllGather, "ncclAllGather"); LIMG_RCCL_SYM(Send, "ncclSend"); LIMG_RCCL_SYM(Recv, "ncclRecv");
       LIMG_RCCL_SYM(GroupStart, "ncclGroupStart"); LIMG_RCCL_SYM(GroupEnd, "ncclGroupEnd"); LIMG_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+      LIMG_RCCL_SYM(CommCount, "ncclCommCount"); LIMG_RCCL_SYM(CommUserRank, "ncclCommUserRank"); LIMG_RCCL_SYM(GetVersion, "ncclGetVersion");
 #undef LIMG_RCCL_SYM
       x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.AllGather && x.Send && x.Recv && x.GroupStart && x.GroupEnd && x.GetErrorString;
       return x;

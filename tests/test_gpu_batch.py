@@ -63,6 +63,61 @@ def test_batch_chunks_and_fallbacks(gpu, oracle):
             assert not bad, (W, H, i, bad)
 
 
+@pytest.mark.parametrize("sub", [1, 2, 3])
+@pytest.mark.parametrize("alpha,pool,fast,ef", [(True, 0, True, 100), (False, 2, True, 25), (True, 0, False, 100)])
+def test_batch_as_pipeline_of_sub_batches(gpu, oracle, sub, alpha, pool, fast, ef):
+    """limg_hip_options.batch_sub_images: the list as a pipeline of launch pairs -- the float stage of sub-batch k + 1 on the context's own stream next to the
+    persistent kernel of sub-batch k (5 workgroups per CU) -- must give every image the planes of its single encode: 7 images in sub-batches of 1 / 2 / 3
+    (the last one short), twice in a row (the second pass reuses tickets, descriptors and events)."""
+    import torch
+    W, H = 512, 72
+    host = [oracle.photo_noise(W, H, 60 + i) if i % 2 == 0 else oracle.random_gradient(W, H, 60 + i, i != 3) for i in range(7)]
+    imgs = [torch.from_numpy(h.view(np.int32)).cuda() for h in host]
+    outs = [gpu.alloc_planes_device(W, H) for _ in imgs]
+    want = [oracle.encode3d(h, alpha, error_factor=ef, pool_threads=pool, fast=fast) for h in host]
+    gpu.set_options(batch_sub_images=sub)
+    try:
+        for rep in range(2):
+            for pl in outs:
+                for v in pl.values():
+                    v.zero_()
+            gpu.encode3d_batch_device(imgs, alpha, outs, error_factor=ef, pool_threads=pool, fast=fast)
+            torch.cuda.synchronize()
+            gpu.check()
+            for i, pl in enumerate(outs):
+                got = _host(pl)
+                bad = [(k, int((got[k] != want[i][k]).sum())) for k in PLANES if not np.array_equal(got[k], want[i][k])]
+                assert not bad, (sub, rep, i, bad)
+    finally:
+        gpu.set_options()
+
+
+def test_batch_stats_cover_the_whole_list(gpu, oracle):
+    """limg_hip_last_stats after a batched encode: all images of the list together, also when the list took several launch pairs (chunks) or a pipeline of
+    sub-batches (only the last chunk was counted)."""
+    import torch
+    W, H = 256, 16
+    host = [oracle.photo_noise(W, H, 70 + i) for i in range(7)]
+    imgs = [torch.from_numpy(h.view(np.int32)).cuda() for h in host]
+    outs = [gpu.alloc_planes_device(W, H) for _ in imgs]
+    want = np.zeros(30, dtype=np.uint64)
+    for h in host:
+        sh = oracle.encode3d(h, True, extras=True)["shifts"]
+        for f in range(3):
+            for s in range(9):
+                n = int((np.minimum(sh[:, :, f], 8) == s).sum()) * 64
+                want[3 + 9 * f + s] += n
+                want[f] += (8 - s) * n
+    for kw in (dict(), dict(test_batch_chunk=3), dict(batch_sub_images=2), dict(test_batch_chunk=4, batch_sub_images=3)):
+        gpu.set_options(collect_stats=True, **kw)
+        try:
+            gpu.encode3d_batch_device(imgs, True, outs)
+            cnt, px = gpu.last_stats()
+        finally:
+            gpu.set_options()
+        assert px == 7 * W * H and np.array_equal(cnt, want), (kw, px, cnt, want)
+
+
 def test_batch_argument_checks(gpu):
     import ctypes as C
     import torch
@@ -113,6 +168,23 @@ def test_batch_of_8_at_4096_equals_single_encodes(gpu, oracle):
             torch.cuda.synchronize()
             for k in PLANES:
                 assert torch.equal(single[k], outs[i][k]), (rep, i, k)
+    gpu.check()
+    # the same list as a pipeline of sub-batches of 2 and of 3 (float stage of the next sub-batch next to the persistent kernel of the current one)
+    for sub in (2, 3):
+        for pl in outs[:4]:
+            for v in pl.values():
+                v.zero_()
+        gpu.set_options(batch_sub_images=sub)
+        try:
+            gpu.encode3d_batch_device(imgs, True, outs[:4])
+        finally:
+            gpu.set_options()
+        torch.cuda.synchronize()
+        for i in range(4):
+            gpu.encode3d_device(imgs[i], True, single)
+            torch.cuda.synchronize()
+            for k in PLANES:
+                assert torch.equal(single[k], outs[i][k]), ("sub", sub, i, k)
     gpu.check()
     del imgs, outs, single
     torch.cuda.empty_cache()

@@ -114,6 +114,27 @@ def test_rccl_world_of_one(oracle):
         got = _np(planes)
         for k in PLANES:
             assert np.array_equal(got[k], want[k]), k
+        g.check()
+        # abort rule: a rank whose E step failed (test hook) still joins the all-gather -- with a poison value -- and returns its error; the call comes back
+        # (no rank is left waiting), no plane is written, and the context reports the aborted chain once
+        for v in planes.values():
+            v.zero_()
+        g.set_options(test_fail_chain_phase1=True)
+        try:
+            with pytest.raises(limg_amd.LimgHipError):
+                g.encode3d_single_chain_device(d_img, True, planes, 0)
+        finally:
+            g.set_options()
+        torch.cuda.synchronize()
+        assert all(int(v.count_nonzero().item()) == 0 for v in planes.values())
+        with pytest.raises(limg_amd.LimgHipError):
+            g.check()  # "a rank of the communicator aborted a single-chain encode"
+        g.check()      # sticky until reported once
+        g.encode3d_single_chain_device(d_img, True, planes, 0)  # and the context goes on working
+        torch.cuda.synchronize()
+        got = _np(planes)
+        for k in PLANES:
+            assert np.array_equal(got[k], want[k]), k
         g.comm_destroy()
         g.check()
     finally:
@@ -140,6 +161,9 @@ rows = shard.strip_rows(H, world)
 y0, y1 = rows[rank]
 g = limg_amd.LimgHip(rank)
 g.comm_init_from_torch(dist)
+torch.cuda.synchronize()
+dist.barrier()
+print("LIMG_COMM_UP rank %d" % rank, flush=True)   # rendezvous and communicator are done: a hang from here on is a failure of the code under test, not of the node
 strip = torch.from_numpy(img[y0:y1].view(np.int32)).cuda()
 planes = g.alloc_planes_device(W, y1 - y0)
 g.encode3d_single_chain_device(strip, True, planes, (y0 // 8) * (W // 8))
@@ -169,6 +193,28 @@ try:
 except limg_amd.LimgHipError as e:
     assert "103" in str(e), str(e)
 torch.cuda.synchronize()
+dist.barrier()
+# abort rule: rank 1's E step "fails" (test hook).  It must still join the all-gather (rank 0 would wait in it forever otherwise) and return its error;
+# rank 0's call returns, writes no plane and its context reports the aborted chain.
+for v in planes.values():
+    v.zero_()
+if rank == 1:
+    g.set_options(test_fail_chain_phase1=True)
+try:
+    g.encode3d_single_chain_device(strip, True, planes, (y0 // 8) * (W // 8))
+    failed = False
+except limg_amd.LimgHipError:
+    failed = True
+torch.cuda.synchronize()
+assert failed == (rank == 1), (rank, failed)
+assert all(int(v.count_nonzero().item()) == 0 for v in planes.values()), rank
+try:
+    g.check()
+    reported = False
+except limg_amd.LimgHipError:
+    reported = True
+assert reported, rank
+g.set_options()
 dist.barrier()
 g.comm_destroy(); g.check(); g.close()
 dist.destroy_process_group()
@@ -205,6 +251,10 @@ def test_rccl_two_ranks(tmp_path):
             timed_out = True
             pr.kill()
             outs.append(pr.communicate()[0])
-    if timed_out and not any("AssertionError" in o or "SystemExit" in o for o in outs):
-        pytest.skip("the two-rank RCCL job did not complete in 240 s on this node (rendezvous / fabric problem, not a result): " + " | ".join(o[-300:] for o in outs))
+    # Only a job that never got its communicator up may skip (rendezvous / fabric problem of the node).  Once both ranks have printed LIMG_COMM_UP a timeout is a
+    # hang of the code under test -- a deadlock is the likeliest failure of new collective code -- and fails the suite.
+    up = sum("LIMG_COMM_UP" in o for o in outs)
+    if timed_out and up < 2 and not any("AssertionError" in o or "SystemExit" in o for o in outs):
+        pytest.skip("the two-rank RCCL job did not get its communicator up in 240 s on this node (rendezvous / fabric problem, not a result): " + " | ".join(o[-300:] for o in outs))
+    assert not timed_out, ("two-rank RCCL job hung AFTER the communicator was up", [o[-600:] for o in outs])
     assert all(p.returncode == 0 for p in procs), outs

@@ -103,6 +103,58 @@ def test_ragged_and_edge_shapes(gpu, oracle, w, h, alpha):
         _assert_planes(gpu.encode3d(img, alpha, pool_threads=1), oracle.encode3d(img, alpha, pool_threads=1), (w, h, alpha, "pool"))
 
 
+@pytest.mark.parametrize("w,h", [(8, 9), (256, 12), (264, 17), (2048, 15), (512, 100), (1024, 301), (40, 1001)])
+@pytest.mark.parametrize("alpha", [True, False])
+def test_height_ragged_shapes(gpu, oracle, w, h, alpha):
+    """Width in whole 8x8 blocks, last block row partial (BASELINE config 1's class: 1024 x 618).  In the `fused` fixture mode the block rows above the last run
+    through k_fit_tpb + the persistent kernel and only the last row's dither chain is walked by the host, from the chain value the look-back descriptor of the
+    strip above names (encode_height_ragged); the other modes and test_whole_image_ragged take the whole-image ragged path.  All against the oracle -- with strip
+    partitions (the last strip owns the partial row), the accurate search, errorFactor 0 -- and the two paths against each other."""
+    img = oracle.photo_noise(w, h, 31) if w != 512 else oracle.random_gradient(w, h, 31, True)
+    want = oracle.encode3d(img, alpha)
+    _assert_planes(gpu.encode3d(img, alpha), want, (w, h, alpha))
+    gpu.set_options(test_whole_image_ragged=True)
+    try:
+        _assert_planes(gpu.encode3d(img, alpha), want, (w, h, alpha, "whole-image path"))
+    finally:
+        gpu.set_options()
+    for pool in ((1, 2, 3) if h >= 100 else (1,) if h >= 16 else ()):
+        _assert_planes(gpu.encode3d(img, alpha, pool_threads=pool), oracle.encode3d(img, alpha, pool_threads=pool), (w, h, alpha, "pool", pool))
+    if h == 100:
+        _assert_planes(gpu.encode3d(img, alpha, fast=False), oracle.encode3d(img, alpha, fast=False), (w, h, alpha, "accurate"))
+        _assert_planes(gpu.encode3d(img, alpha, error_factor=0), oracle.encode3d(img, alpha, error_factor=0), (w, h, alpha, "ef0"))
+        _assert_planes(gpu.encode3d(img, alpha, error_factor=25), oracle.encode3d(img, alpha, error_factor=25), (w, h, alpha, "ef25"))
+
+
+def test_height_ragged_at_4096(gpu, oracle):
+    """4096 x 4090 photo-noise: fast path + last row against the whole-image ragged path of the same build, every plane compared on the device; the bottom band
+    (rows 3968 ...: the last full block rows and the partial one) cannot be checked by the oracle alone -- its chain position depends on everything above -- so the
+    whole image goes through the oracle once (a few seconds)."""
+    import torch
+    if gpu.mode != "fused":
+        pytest.skip("one mode is enough at this size")
+    W, H = 4096, 4090
+    img = gpu.synth_device("photo_noise", W, H, seed=3)
+    a = gpu.alloc_planes_device(W, H)
+    b = gpu.alloc_planes_device(W, H)
+    gpu.encode3d_device(img, True, a)
+    gpu.set_options(test_whole_image_ragged=True)
+    try:
+        gpu.encode3d_device(img, True, b)
+    finally:
+        gpu.set_options()
+    torch.cuda.synchronize()
+    gpu.check()
+    for k in PLANES:
+        assert torch.equal(a[k], b[k]), k
+    host = img.cpu().numpy().view(np.uint32)
+    want = oracle.encode3d(host, True, worker_threads=8)
+    for k in PLANES:
+        got = a[k].cpu().numpy()
+        got = got.view(np.uint32) if got.dtype == np.int32 else got
+        assert np.array_equal(got, want[k]), k
+
+
 @pytest.mark.parametrize("ef", [0, 1, 2, 25, 50, 100, 200, 400, 3000, 4000000000])
 def test_error_factor_sweep(gpu, oracle, ef):
     img = oracle.photo_noise(256, 32, 17)

@@ -61,9 +61,11 @@ static void run(Job *j, std::atomic<int> *go)
 
 int main(int argc, char **argv)
 {
-  // argv: dir, then per job: w h alpha pool rounds
-  if (argc < 2 || (argc - 2) % 5 != 0) return 2;
+  // argv: dir, print-stats flag, then per job: w h alpha pool rounds
+  if (argc < 3 || (argc - 3) % 5 != 0) return 2;
   const std::string dir = argv[1];
+  if (atoi(argv[2])) limg_hip_shim::print_stats(true); // upstream prints its bit statistics from inside limg_encode3d_test (src/limg.cpp:2232-2248): per call, whatever other threads do
+  argv++; argc--;
   std::vector<Job> jobs((size_t)(argc - 2) / 5);
   for (size_t i = 0; i < jobs.size(); i++)
   {
@@ -105,7 +107,12 @@ def test_threaded_shim_program_builds(program):
 
 
 @pytest.mark.gpu
-def test_shim_from_four_threads(program, oracle):
+@pytest.mark.parametrize("stats", [0, 1])
+def test_shim_from_four_threads(program, oracle, stats):
+    """stats = 1: limg_hip_shim::print_stats(true) -- every call prints the "Average Block Bits" block of ITS encode (upstream keeps the counters on the call's stack,
+    src/limg.cpp:1975-1976).  The four jobs have four different blocks; stdout must hold each job's block exactly `rounds` times: a thread that printed another
+    thread's counters (the race ADVICE r03 describes: statistics fetched after the context's mutex was released) would shift the counts."""
+    import limg_amd
     exe, d = program
     imgs = []
     for i, (w, h, alpha, pool, rounds) in enumerate(JOBS):
@@ -113,8 +120,26 @@ def test_shim_from_four_threads(program, oracle):
         img.tofile(str(d / ("in%d.bin" % i)))
         imgs.append(img)
     args = [str(x) for j in JOBS for x in j]
-    r = subprocess.run([exe, str(d)] + args, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe, str(d), str(stats)] + args, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-1000:])
+    if stats:
+        out = r.stdout
+        blocks = []
+        for i, (w, h, alpha, pool, rounds) in enumerate(JOBS):
+            sh = oracle.encode3d(imgs[i], bool(alpha), pool_threads=pool, extras=True)["shifts"]
+            c = np.zeros(30, dtype=np.uint64)
+            for by in range(sh.shape[0]):
+                for bx in range(sh.shape[1]):
+                    n = min(8, w - 8 * bx) * min(8, h - 8 * by)
+                    for f in range(3):
+                        s_ = min(int(sh[by, bx, f]), 8)
+                        c[f] += (8 - s_) * n
+                        c[3 + 9 * f + s_] += n
+            blocks.append(limg_amd.format_stats(c, w * h))
+        assert len(set(blocks)) == len(blocks), "the jobs must have distinguishable statistics"
+        for i, b in enumerate(blocks):
+            assert out.count(b) == JOBS[i][4], (i, out.count(b), JOBS[i][4])
+        assert out.count("Average Block Bits") == sum(j[4] for j in JOBS)
     for i, (w, h, alpha, pool, rounds) in enumerate(JOBS):
         want = oracle.encode3d(imgs[i], bool(alpha), pool_threads=pool)
         raw = np.fromfile(str(d / ("out%d.bin" % i)), dtype=np.uint8)
