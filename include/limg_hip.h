@@ -75,12 +75,14 @@ typedef struct limg_hip_options
                                   instead of filling it on the GPU from the embedded chain checkpoints.  Same bytes; A/B switch for tests */
   int32_t test_batch_chunk;    /* test hook, 0 = default: limg_hip_encode3d_batch_device puts at most this many images into one launch pair (default: as many as 1 GiB
                                   of per-block scratch holds) */
-  int32_t batch_sub_images;    /* limg_hip_encode3d_batch_device: > 0 = run the list as a pipeline of sub-batches of this many images -- the float-stage kernel of
-                                  sub-batch k + 1 on a stream of the context's own next to the persistent kernel of sub-batch k (which then leaves it a residency
-                                  slot: 5 workgroups per CU instead of 6); 0 = one launch pair for the whole list.  Same planes either way */
+  int32_t batch_sub_images;    /* limg_hip_encode3d_batch_device runs a long list as a PIPELINE of sub-batches: the float-stage kernel of sub-batch k + 1 on a stream of
+                                  the context's own next to the persistent kernel of sub-batch k (which leaves it a residency slot: 5 workgroups per CU instead of 6).
+                                  0 = automatic (sub-batches of 8 for lists of 32 images and more, of 4 from 16 images, none below); > 0 = sub-batches of this many
+                                  images; < 0 = never: one launch pair for the whole list.  Same planes in every case */
   int32_t test_wg_per_cu;      /* A/B hook, 0 = default: workgroups per CU of the persistent kernel's launch, 1 .. its launch bound (6; values above are ignored) */
   int32_t test_whole_image_ragged; /* test hook, non-0: an image whose width is whole 8x8 blocks but whose last block row is partial goes through the whole-image
                                   ragged path (host chain walk over every dither call) instead of fast path + last row; same planes either way */
+  int32_t test_pipeline;       /* A/B hook of the sub-batch pipeline, 0 = defaults (see limg_hip_api.hip) */
   int32_t test_fail_chain_phase1; /* test hook, non-0: limg_hip_encode3d_single_chain_device behaves as if this rank's E step had failed (abort rule below) */
 } limg_hip_options;
 

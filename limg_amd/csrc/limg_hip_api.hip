@@ -492,21 +492,34 @@ namespace
     // the persistent kernel of sub-batch k.  On content with short searches (BASELINE configs 2 / 4: ~2 trials per block) the persistent kernel waits for its plane
     // stores a third of the time while k_fit_tpb is pure vector work: side by side they fill each other's gaps.  The persistent kernel leaves the float stage room
     // to be resident: 5 workgroups per CU instead of 6 (at 6 x 80 VGPRs nothing else fits on a SIMD) for every sub-batch but the last.
-    const size_t subImages = (fused && batchCount > 1 && p.prefit && c->opt.batch_sub_images > 0) ? (size_t)c->opt.batch_sub_images : 0;
+    // Measured on 4096^2 random-gradient lists (profiles/r04_pipeline_sweep.md): 64 images 66.5 -> 73.3 Gpixel/s in sub-batches of 8 (4: 70.9, 16: 71.9); 16 images
+    // +3.5 % in sub-batches of 4; 8 images and fewer: nothing to gain (the lone first float stage and the 5-workgroup launches cost what the overlap saves).
+    size_t subImages = 0;
+    if (fused && batchCount > 1 && p.prefit)
+    {
+      if (c->opt.batch_sub_images > 0) subImages = (size_t)c->opt.batch_sub_images;
+      else if (c->opt.batch_sub_images == 0) subImages = batchCount >= 32 ? 8 : (batchCount >= 16 ? 4 : 0);
+    }
     if (subImages > 0 && subImages < batchCount)
     {
-      const size_t nSub = (batchCount + subImages - 1) / subImages;
+      // A/B hook (limg_hip_options.test_pipeline): bits 0..3 = 1 + k_fit_tpb's wave priority, bits 4..7 = workgroups per CU of the overlapped persistent launches,
+      // bits 8..15 = images of the first sub-batch (whose float stage runs alone)
+      const uint32_t knobs = (uint32_t)c->opt.test_pipeline;
+      const int fitPrio = (knobs & 15u) ? (int)(knobs & 15u) - 1 : 0, wgOverlap = ((knobs >> 4) & 15u) ? (int)((knobs >> 4) & 15u) : 5;
+      const size_t firstSub = ((knobs >> 8) & 255u) && ((knobs >> 8) & 255u) < subImages ? (size_t)((knobs >> 8) & 255u) : subImages;
+      const size_t nSub = 1 + (batchCount - firstSub + subImages - 1) / subImages;
       if ((r = ensure_pipe_events(c, 2 * nSub + 1)) != limg_hip_success) return r;
       const size_t imgBlocks = (size_t)p.blocksX * p.blocksY, imgStrips = (size_t)p.imageStrips;
       auto sub = [&](size_t k) -> EncodeParams
       {
         EncodeParams q = p;
-        const size_t i0 = k * subImages, n = batchCount - i0 < subImages ? batchCount - i0 : subImages;
+        const size_t i0 = k == 0 ? 0 : firstSub + (k - 1) * subImages, want = k == 0 ? firstSub : subImages, n = batchCount - i0 < want ? batchCount - i0 : want;
         q.batch = p.batch + i0; q.batchCount = (uint32_t)n;
         q.io = batch[i0]; // (what the kernels read when a sub-batch is a single image)
         q.records = p.records + i0 * imgBlocks; q.shifts = p.shifts + i0 * imgBlocks; q.invN = p.invN + i0 * imgBlocks * 4;
         uint8_t *lb = (uint8_t *)c->lookback.p + k * 16 + i0 * imgStrips * 8; // sub-batch k: its ticket, then the descriptors of its strips
         q.ticket = (uint32_t *)lb; q.desc = (unsigned long long *)(lb + 16);
+        q.fitPrio = k == 0 ? 0 : fitPrio;
         return q;
       };
       hipStream_t fs = c->fitStream;
@@ -527,7 +540,7 @@ namespace
           launch_fit_tpb(sub(k + 1), channels, fs);
           HIP_TRY(hipEventRecord(ev[3 + 2 * k], fs));
         }
-        launch_encode_persistent(sub(k), channels, c->persistentWorkgroups / 5 * wg_per_cu(k + 1 < nSub ? 5 : 6), stream);
+        launch_encode_persistent(sub(k), channels, c->persistentWorkgroups / 5 * (k + 1 < nSub ? wgOverlap : wg_per_cu(6)), stream);
       }
       mark_if(1); mark_if(2);
       HIP_TRY(hipGetLastError());

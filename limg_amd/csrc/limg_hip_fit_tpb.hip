@@ -29,10 +29,49 @@ namespace limg_hip
     // speed -- it is issue-bound on its instruction count.
     template <bool DIRECT> constexpr int tpb_waves() { return DIRECT ? 4 : 2; } // waves per workgroup: they share one copy of the table
 
+    // The eight rows of a lane's block, two per iteration, the NEXT two already requested: a pass is a chain of (load 32 bytes, 8 pixels of arithmetic) per row, and
+    // with few waves on a SIMD -- a 4096^2 image is one round of 4 waves per SIMD, the sub-batch pipeline leaves this kernel one -- nothing else covers the load's
+    // latency.  (The last iteration re-requests rows 6 and 7: harmless, and the loop stays free of a branch.)
+#ifndef LIMG_TPB_WAVES_PER_SIMD
+#define LIMG_TPB_WAVES_PER_SIMD 5
+#endif
+    template <class BODY>
+    __device__ __forceinline__ void for_rows(const uint32_t *my, const uint32_t pitch, BODY &&body)
+    {
+#ifdef LIMG_TPB_NO_PREFETCH // A/B: the round-3 form, one row per iteration, loaded where it is used
+#pragma unroll 1
+      for (int r = 0; r < 8; r++)
+      {
+        const uint4 u = *reinterpret_cast<const uint4 *>(my + r * pitch), w = *reinterpret_cast<const uint4 *>(my + r * pitch + 4);
+        const uint32_t q[8] = { u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w };
+        body(r, q);
+      }
+      return;
+#endif
+      uint4 u0 = *reinterpret_cast<const uint4 *>(my), w0 = *reinterpret_cast<const uint4 *>(my + 4);
+      uint4 u1 = *reinterpret_cast<const uint4 *>(my + pitch), w1 = *reinterpret_cast<const uint4 *>(my + pitch + 4);
+#pragma unroll 1
+      for (int r = 0; r < 8; r += 2)
+      {
+        const uint32_t *nx = my + (r + 2 < 8 ? r + 2 : 6) * pitch;
+        const uint4 nu0 = *reinterpret_cast<const uint4 *>(nx), nw0 = *reinterpret_cast<const uint4 *>(nx + 4);
+        const uint4 nu1 = *reinterpret_cast<const uint4 *>(nx + pitch), nw1 = *reinterpret_cast<const uint4 *>(nx + pitch + 4);
+        {
+          const uint32_t q[8] = { u0.x, u0.y, u0.z, u0.w, w0.x, w0.y, w0.z, w0.w };
+          body(r, q);
+        }
+        {
+          const uint32_t q[8] = { u1.x, u1.y, u1.z, u1.w, w1.x, w1.y, w1.z, w1.w };
+          body(r + 1, q);
+        }
+        u0 = nu0; w0 = nw0; u1 = nu1; w1 = nw1;
+      }
+    }
+
     template <int CH, bool FAST, bool DIRECT>
     // (8 waves per SIMD asked for explicitly: left to itself the compiler settles on 61 registers or on 132 depending on details of the epilogue; measured equal in
     //  speed on large images -- the kernel is issue-bound -- but a 4096^2 image is a single round of 4096 waves, where residency is what there is)
-    __global__ __launch_bounds__(64 * tpb_waves<DIRECT>(), DIRECT ? ((FAST && CH == 3) ? 7 : 8) : 1) void k_fit_tpb(const EncodeParams p)
+    __global__ __launch_bounds__(64 * tpb_waves<DIRECT>(), DIRECT ? LIMG_TPB_WAVES_PER_SIMD : 1) void k_fit_tpb(const EncodeParams p)
     {
       constexpr int kTpbWaves = tpb_waves<DIRECT>();
       __shared__ __attribute__((aligned(16))) uint32_t s_pxAll[kTpbWaves][DIRECT ? 4 : 64 * kTpbStride];
@@ -41,6 +80,11 @@ namespace limg_hip
       // 8 KiB: T[j] = table[j ^ 0x400] << 11, the form unit4<..., TAB32> reads (entry in mantissa position, no index flip)
       __shared__ __attribute__((aligned(16))) uint32_t s_tab[FAST ? 4 : 2048];
       const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+      // Next to a persistent kernel (sub-batch pipeline) this kernel has ONE wave per SIMD against the other's five: at equal priority it would get a sixth of the
+      // issue slots and become the pipeline's critical path.  Raised above the E step's priority, its one wave takes what a single wave can issue.
+      if (p.fitPrio == 3) __builtin_amdgcn_s_setprio(3);
+      else if (p.fitPrio == 2) __builtin_amdgcn_s_setprio(2);
+      else if (p.fitPrio == 1) __builtin_amdgcn_s_setprio(1);
       if (!FAST)
       {
         const uint4 *src = reinterpret_cast<const uint4 *>(d_rsqrt_x86_tab);
@@ -127,11 +171,8 @@ namespace limg_hip
       float mm[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
       {
         V4 acc = zero4;
-#pragma unroll 1
-        for (int r = 0; r < 8; r++)
+        for_rows(my, pitch, [&](const int, const uint32_t (&q)[8])
         {
-          const uint4 u = *reinterpret_cast<const uint4 *>(my + r * pitch), w = *reinterpret_cast<const uint4 *>(my + r * pitch + 4);
-          const uint32_t q[8] = { u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w };
 #pragma unroll
           for (int i = 0; i < 8; i++)
           {
@@ -139,7 +180,7 @@ namespace limg_hip
             mask_alpha<CH>(d);
             acc = acc + unit4<CH, FAST, true, true>(tab, d, true);
           }
-        }
+        });
         finish_dir(acc, dirA, invA, zeroA);
       }
 
@@ -148,11 +189,8 @@ namespace limg_hip
       {
         V4 acc = zero4;
         float mn = 0.0f, mx = 0.0f; // upstream starts them at 0 (:633-634)
-#pragma unroll 1
-        for (int r = 0; r < 8; r++)
+        for_rows(my, pitch, [&](const int, const uint32_t (&q)[8])
         {
-          const uint4 u = *reinterpret_cast<const uint4 *>(my + r * pitch), w = *reinterpret_cast<const uint4 *>(my + r * pitch + 4);
-          const uint32_t q[8] = { u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w };
 #pragma unroll
           for (int i = 0; i < 8; i++)
           {
@@ -163,7 +201,7 @@ namespace limg_hip
             mask_alpha<CH>(e);
             acc = acc + unit4<CH, FAST, true, true>(tab, e, true);
           }
-        }
+        });
         mm[0] = mn; mm[1] = mx;
         finish_dir(acc, dirB, invB, zeroB);
       }
@@ -175,11 +213,8 @@ namespace limg_hip
         if (CH == 4)
         { // :701-738: factor B extrema, residual -> third direction; the A+B estimate of pixel 0 is what pass 4 measures every pixel against (:748-758)
           V4 acc = zero4;
-#pragma unroll 1
-          for (int r = 0; r < 8; r++)
+          for_rows(my, pitch, [&](const int r, const uint32_t (&q)[8])
           {
-            const uint4 u = *reinterpret_cast<const uint4 *>(my + r * pitch), w = *reinterpret_cast<const uint4 *>(my + r * pitch + 4);
-            const uint32_t q[8] = { u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w };
 #pragma unroll
             for (int i = 0; i < 8; i++)
             {
@@ -192,25 +227,22 @@ namespace limg_hip
               if (r == 0 && i == 0) est0 = estB;
               acc = acc + unit4<CH, FAST, true, true>(tab, pf - estB, true);
             }
-          }
+          });
           mm[2] = mnB; mm[3] = mxB;
           finish_dir(acc, dirC, invC, zeroC);
           // ---- pass 4 (:748-758) ----
           if (!zeroC)
           {
             float mnC = FLT_MAX, mxC = -FLT_MAX;
-#pragma unroll 1
-            for (int r = 0; r < 8; r++)
+            for_rows(my, pitch, [&](const int, const uint32_t (&q)[8])
             {
-              const uint4 u = *reinterpret_cast<const uint4 *>(my + r * pitch), w = *reinterpret_cast<const uint4 *>(my + r * pitch + 4);
-              const uint32_t q[8] = { u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w };
 #pragma unroll
               for (int i = 0; i < 8; i++)
               {
                 const float fC = dp4<CH, FAST>(px_to_v4(q[i]) - est0, dirC) * invC;
                 mnC = vmin(mnC, fC); mxC = vmax(mxC, fC);
               }
-            }
+            });
             mm[4] = mnC; mm[5] = mxC;
           }
         }
@@ -223,11 +255,8 @@ namespace limg_hip
           zeroC = dirC.a.x == 0.0f && dirC.b.x == 0.0f && dirC.a.y == 0.0f;
           if (!zeroC) invC = FAST ? __builtin_amdgcn_rcpf(dp4<CH, FAST>(dirC, dirC)) : 1.0f / dp4<CH, FAST>(dirC, dirC);
           float mnC = zeroC ? 0.0f : FLT_MAX, mxC = zeroC ? 0.0f : -FLT_MAX;
-#pragma unroll 1
-          for (int r = 0; r < 8; r++)
+          for_rows(my, pitch, [&](const int, const uint32_t (&q)[8])
           {
-            const uint4 u = *reinterpret_cast<const uint4 *>(my + r * pitch), w = *reinterpret_cast<const uint4 *>(my + r * pitch + 4);
-            const uint32_t q[8] = { u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w };
 #pragma unroll
             for (int i = 0; i < 8; i++)
             {
@@ -243,7 +272,7 @@ namespace limg_hip
                 mnC = vmin(mnC, fC); mxC = vmax(mxC, fC);
               }
             }
-          }
+          });
           mm[2] = mnB; mm[3] = mxB; mm[4] = mnC; mm[5] = mxC;
         }
       }

@@ -67,6 +67,7 @@ namespace limg_hip
     // cross-GPU single dither chain (split path only): the scan writes this image strip's dither-call total; the F step adds the strip's first call index
     unsigned long long *chainCallsOut;
     const unsigned long long *chainBase;
+    int32_t fitPrio;    // k_fit_tpb: wave priority (s_setprio 0..3); raised when it runs next to a persistent kernel (batched encode as a pipeline)
     int32_t prefit;     // host dispatch only: p.records already hold the fit (k_fit_tpb ran first)
     int32_t floatFast;  // host dispatch only: FAST float stage (limg_hip_options.float_mode = 1)
     int32_t vecIn;      // rows of pIn may be read 16 bytes per lane (sizeX % 4 == 0 and pIn 16-byte aligned); otherwise dword loads

@@ -108,7 +108,7 @@ def test_batch_stats_cover_the_whole_list(gpu, oracle):
                 n = int((np.minimum(sh[:, :, f], 8) == s).sum()) * 64
                 want[3 + 9 * f + s] += n
                 want[f] += (8 - s) * n
-    for kw in (dict(), dict(test_batch_chunk=3), dict(batch_sub_images=2), dict(test_batch_chunk=4, batch_sub_images=3)):
+    for kw in (dict(), dict(batch_sub_images=-1), dict(test_batch_chunk=3), dict(batch_sub_images=2), dict(test_batch_chunk=4, batch_sub_images=3)):
         gpu.set_options(collect_stats=True, **kw)
         try:
             gpu.encode3d_batch_device(imgs, True, outs)

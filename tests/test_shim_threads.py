@@ -116,7 +116,7 @@ def test_shim_from_four_threads(program, oracle, stats):
     exe, d = program
     imgs = []
     for i, (w, h, alpha, pool, rounds) in enumerate(JOBS):
-        img = oracle.photo_noise(w, h, 300 + i) if i % 2 == 0 else oracle.random_gradient(w, h, 300 + i, True)
+        img = oracle.photo_noise(w, h, 300 + i) if i != 3 else oracle.random_gradient(w, h, 300 + i, True)  # (four distinguishable statistics blocks)
         img.tofile(str(d / ("in%d.bin" % i)))
         imgs.append(img)
     args = [str(x) for j in JOBS for x in j]
