@@ -39,11 +39,38 @@ VALU_FULL_RATE_PER_S = 960e9
 VALU_HALF_RATE_PER_S = 578e9
 
 
+PMC_ROUND = "r04"   # the round whose kernels this file benches: a counter entry measured on another round's build is refused (lines that quoted round-2 counters for round-3 kernels)
+
+
 def pmc_entry(key):
+    """The counter-derived figures of one workload, or None when there are none -- or when the entry was not measured on this round's build (its `source` names the
+    profile run, tools/prof.sh <tag>, and tags carry the round)."""
     try:
-        return json.load(open(PMC_FILE)).get(key)
+        e = json.load(open(PMC_FILE)).get(key)
     except Exception:
         return None
+    if e is None or ("_%s" % PMC_ROUND) not in str(e.get("source", "")):
+        return None
+    return e
+
+
+def pmc_stale_source(key):
+    """Why pmc_entry(key) is None although the file has the key: the stale entry's source, for the line's `pmc_refused` field."""
+    try:
+        e = json.load(open(PMC_FILE)).get(key)
+    except Exception:
+        return None
+    return None if e is None or ("_%s" % PMC_ROUND) in str(e.get("source", "")) else e.get("source")
+
+
+def instruction_floor(pmc, algo_bytes):
+    """The fraction of the HBM roofline this instruction count could reach if the kernels issued at the chip's measured rate for their instruction class
+    (profiles/r02_valu_ceiling.md): algorithmic bytes / (VALU instructions per launch / ceiling) / peak.  The distance between `frac` and this number is what
+    scheduling can still recover; the distance between this number and 1 only fewer instructions can."""
+    if not pmc or not pmc.get("valu_instr_per_launch"):
+        return None
+    t = pmc["valu_instr_per_launch"] / VALU_HALF_RATE_PER_S
+    return round(algo_bytes / t / 1e9 / HBM_PEAK_GBPS, 4)
 
 
 def workload_key(args, W, H):
@@ -320,6 +347,7 @@ def run_sharded(args, g, dist, rank, world):
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": None if not pmc or pmc.get("fetch_kib") is None else int((2 * pmc["fetch_kib"] + pmc["write_kib"]) * 1024),
                          "valu_busy": None if not pmc else pmc.get("valu_busy"), "pmc_source": None if not pmc else pmc.get("source"), "pmc_key": pmc_key,
+                         "pmc_refused_stale_source": pmc_stale_source(pmc_key), "instruction_floor": instruction_floor(pmc, ALGO_BYTES_PER_PX * px_per_launch),
                          "valu_instr_per_block": None if not pmc or not pmc.get("valu_instr_per_launch") else round(pmc["valu_instr_per_launch"] / (px_per_launch / 64.0), 1),
                          "algorithmic_bytes_per_launch": int(ALGO_BYTES_PER_PX * px_per_launch), "launch_pairs_per_step": launches_per_step,
                          "kernels_ms": ({"k_fit_tpb of the first sub-batch (alone)": round(float(kavg[0]), 4), "the pipeline: k_encode_persistent of every sub-batch, k_fit_tpb of the next one beside it": round(float(kavg[1]), 4)}
@@ -750,7 +778,8 @@ def main():
                                         {"k_fit_search": round(float(kavg[0]), 4), "k_strip_scan": round(float(kavg[1]), 4), "k_dither_store": round(float(kavg[2]), 4)}
                                         if args.split else ({"k_encode_persistent": round(float(kavg[0]), 4)} if args.legacy_float_stage else
                                                             {"k_fit_tpb": round(float(kavg[0]), 4), "k_encode_persistent": round(float(kavg[1]), 4)})),
-                         "valu": valu, "pmc_key": workload_key(args, W, H),
+                         "valu": valu, "pmc_key": workload_key(args, W, H), "pmc_refused_stale_source": pmc_stale_source(workload_key(args, W, H)),
+                         "instruction_floor": instruction_floor(pmc, bytes_per_px * px),
                          "note": ("image with partial edge blocks: achieved = 39 B/px * pixels / the sum of the three intervals, host stage included (HIP events on the launch stream)" if ragged else
                                   "whole encode = 3 launches; achieved = 39 B/px * pixels / sum of the three average kernel durations (HIP events)" if args.split else
                                   "whole encode = k_fit_tpb (float stage, one lane per block) + one persistent launch; achieved = 39 B/px * pixels / the sum of their average durations "

@@ -86,6 +86,7 @@ struct limg_hip_context
   size_t noiseCount = 0;                         // entries generated so far
   uint64_t noiseNext = kDitherSeed;              // chain value after the last generated entry
   DevBuf noiseDyn;                               // data-dependent chains (images with partial blocks)
+  DevBuf noiseStates;                            // ... their per-call chain values + pixel counts as the host uploads them (k_noise_expand -> noiseDyn)
   DevBuf noiseCk;                                // the chain checkpoints (limg_noise_checkpoints.h) on the device: the GPU fills the noise table from them
   DevBuf park;                                   // persistent kernel: 2 x 8 KiB per workgroup
   DevBuf batchTable;                             // batched encode: one ImageIO per image
@@ -108,7 +109,10 @@ struct limg_hip_context
   HostBuf hFlags;
   HostBuf hRec, hBits, hDesc, hOut, hNoise, hNoiseBase;
   hipStream_t workStream = nullptr; // the merged-block encoder's worker thread launches on its own stream
-  hipEvent_t workEvent[2] = { nullptr, nullptr };
+  std::vector<hipStream_t> workStreams; // ... its fit + search batches round-robin on these
+  hipStream_t storeStream = nullptr; // ... and the noise expansion + store kernels of a batch on a second one
+  DevBuf bCalls;                     // per dither call of the merged-block encoder: chain value, noise offset, pixel count (host walk -> k_noise_expand_calls)
+  std::vector<hipEvent_t> workEvents;        // one per batch of the merged-block encoder's worker that is in flight on the GPU
   hipStream_t copyStream = nullptr;      // copies of the similarity-bit bands, behind the kernels that produce them
   std::vector<hipEvent_t> bandEvents;
   std::vector<HostRegion> lastRegions;
@@ -600,13 +604,16 @@ namespace
     {
       // Partial edge blocks: the chain walk depends on each block's pixel count (a call over N pixels is N / 8 AES rounds + N % 8 PCG steps: G_N), so it is
       // evaluated in raster order on the host from the per-block call counts (blocking).  What crosses PCIe: the shift words down, then -- through pinned
-      // staging -- the strips' first call indices and 64 noise bytes per call up.
-      const size_t stageBytes = ((blocks * 4 + 15) & ~(size_t)15) + 16 + ((strips * 4 + 15) & ~(size_t)15);
-      if ((r = c->hStage.ensure(stageBytes + (blocks * 3 + 1) * 64)) != limg_hip_success) return r;
+      // staging -- the strips' first call indices and, per dither call, the chain value it starts from and its pixel count (9 bytes; k_noise_expand turns them
+      // into the call's 64 noise bytes on the device; rounds 1-3 uploaded the 64 bytes).
+      const size_t maxCalls = blocks * 3;
+      const size_t offPrev = (blocks * 4 + 15) & ~(size_t)15, offBase = offPrev + 16, offStates = (offBase + strips * 4 + 15) & ~(size_t)15, offPixels = offStates + maxCalls * 8;
+      if ((r = c->hStage.ensure(offPixels + maxCalls + 16)) != limg_hip_success) return r;
       uint32_t *hShifts = (uint32_t *)c->hStage.p;
-      unsigned long long *hPrev = (unsigned long long *)((uint8_t *)c->hStage.p + ((blocks * 4 + 15) & ~(size_t)15));
-      uint32_t *hBase = (uint32_t *)(hPrev + 2);
-      uint8_t *hNoise = (uint8_t *)c->hStage.p + stageBytes;
+      unsigned long long *hPrev = (unsigned long long *)((uint8_t *)c->hStage.p + offPrev);
+      uint32_t *hBase = (uint32_t *)((uint8_t *)c->hStage.p + offBase);
+      unsigned long long *hStates = (unsigned long long *)((uint8_t *)c->hStage.p + offStates);
+      uint8_t *hPixels = (uint8_t *)c->hStage.p + offPixels;
       HIP_TRY(hipMemcpyAsync(hShifts, p.shifts, blocks * 4, hipMemcpyDeviceToHost, stream));
       if (x.dPrevDesc) HIP_TRY(hipMemcpyAsync(hPrev, x.dPrevDesc, 8, hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
@@ -619,6 +626,7 @@ namespace
           return limg_hip_error_Generic;
         }
       }
+      const bool pcg = c->opt.dither_pcg != 0;
       uint64_t h = h0;
       size_t call = 0;
       for (uint32_t by = 0; by < p.blocksY; by++)
@@ -630,12 +638,22 @@ namespace
           if (bx % kStripBlocks == 0) hBase[(size_t)by * p.stripsX + bx / kStripBlocks] = (uint32_t)call;
           const unsigned rx = (unsigned)((sizeX - (size_t)bx * kBlock) < kBlock ? (sizeX - (size_t)bx * kBlock) : kBlock);
           const uint32_t calls = hShifts[(size_t)by * p.blocksX + bx] >> 24;
-          for (uint32_t k = 0; k < calls && call < blocks * 3; k++, call++) h = chain_call(h, rx * ry, hNoise + call * 64, false, c->opt.dither_pcg != 0);
+          for (uint32_t k = 0; k < calls && call < maxCalls; k++, call++)
+          {
+            hStates[call] = h; hPixels[call] = (uint8_t)(rx * ry);
+            h = chain_call(h, rx * ry, nullptr, false, pcg);
+          }
         }
       }
       const size_t totalCalls = call;
       if ((r = c->noiseDyn.ensure((totalCalls + 1) * 64)) != limg_hip_success) return r;
-      HIP_TRY(hipMemcpyAsync(c->noiseDyn.p, hNoise, (totalCalls + 1) * 64, hipMemcpyHostToDevice, stream));
+      if ((r = c->noiseStates.ensure(totalCalls * 9 + 16)) != limg_hip_success) return r;
+      if (totalCalls)
+      {
+        HIP_TRY(hipMemcpyAsync(c->noiseStates.p, hStates, totalCalls * 8, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync((uint8_t *)c->noiseStates.p + totalCalls * 8, hPixels, totalCalls, hipMemcpyHostToDevice, stream));
+        launch_noise_expand((uint8_t *)c->noiseDyn.p, (const unsigned long long *)c->noiseStates.p, (const uint8_t *)c->noiseStates.p + totalCalls * 8, totalCalls, pcg, stream);
+      }
       HIP_TRY(hipMemcpyAsync(p.stripBase, hBase, strips * 4, hipMemcpyHostToDevice, stream));
       // (the staging buffer is the context's: the next encode that uses it synchronises with this stream before it writes -- see the D2H above)
       p.noise = (const uint8_t *)c->noiseDyn.p;
@@ -732,7 +750,7 @@ extern "C"
     limg_hip_context *c = *ppCtx;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = { &c->invN, &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->noiseCk, &c->stats, &c->lookback, &c->devStatus, &c->accTable, &c->commWords, &c->park, &c->batchTable, &c->in, &c->planes, &c->cmp,
+    DevBuf *bufs[] = { &c->noiseStates, &c->invN, &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->noiseCk, &c->stats, &c->lookback, &c->devStatus, &c->accTable, &c->commWords, &c->park, &c->batchTable, &c->in, &c->planes, &c->cmp,
                        &c->streamFac, &c->streamTiles, &c->streamStatus, &c->streamBuf,
                        &c->bFlags, &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bV, &c->bFac, &c->bNoise, &c->bNoiseBase };
     for (DevBuf *b : bufs) b->release();
@@ -743,7 +761,10 @@ extern "C"
     for (hipEvent_t e : c->pipeEvents) (void)hipEventDestroy(e);
     if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
     if (c->workStream) (void)hipStreamDestroy(c->workStream);
-    for (hipEvent_t e : c->workEvent) if (e) (void)hipEventDestroy(e);
+    if (c->storeStream) (void)hipStreamDestroy(c->storeStream);
+    for (hipStream_t st : c->workStreams) (void)hipStreamDestroy(st);
+    c->bCalls.release();
+    for (hipEvent_t e : c->workEvents) (void)hipEventDestroy(e);
     if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
     for (hipEvent_t e : c->bandEvents) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
@@ -896,7 +917,7 @@ extern "C"
   size_t limg_hip_context_device_bytes(const limg_hip_context *c)
   {
     if (!c) return 0;
-    const DevBuf *bufs[] = { &c->records, &c->shifts, &c->invN, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->noiseCk, &c->lookback, &c->park, &c->batchTable, &c->stats,
+    const DevBuf *bufs[] = { &c->bCalls, &c->noiseStates, &c->records, &c->shifts, &c->invN, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->noiseCk, &c->lookback, &c->park, &c->batchTable, &c->stats,
                              &c->accTable, &c->devStatus, &c->commWords, &c->in, &c->planes, &c->cmp, &c->streamFac, &c->streamTiles, &c->streamStatus, &c->streamBuf,
                              &c->bFlags, &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bV, &c->bFac, &c->bNoise, &c->bNoiseBase };
     size_t sum = 0;
@@ -1389,7 +1410,9 @@ extern "C"
     if ((r = c->hDesc.ensure(blocks * sizeof(RegionDesc))) != limg_hip_success) return r;
     if ((r = c->hOut.ensure(blocks * sizeof(RegionOut))) != limg_hip_success) return r;
     if ((r = c->hNoiseBase.ensure(blocks * 8 + 8)) != limg_hip_success) return r;
-    if ((r = c->hNoise.ensure(3 * px + 64)) != limg_hip_success) return r;
+    const size_t maxCalls = 3 * blocks; // per dither call: the chain value it starts from (8 B), where its noise bytes go (8 B), its pixel count (4 B)
+    if ((r = c->hNoise.ensure(maxCalls * 20 + 64)) != limg_hip_success) return r;
+    if ((r = c->bCalls.ensure(maxCalls * 20 + 64)) != limg_hip_success) return r;
     if ((r = c->bRegions.ensure(blocks * sizeof(RegionDesc))) != limg_hip_success) return r;
     if ((r = c->bOut.ensure(blocks * sizeof(RegionOut))) != limg_hip_success) return r;
     if ((r = c->bNoiseBase.ensure(blocks * 8 + 8)) != limg_hip_success) return r;
@@ -1401,7 +1424,10 @@ extern "C"
     RegionDesc *desc = (RegionDesc *)c->hDesc.p;
     RegionOut *hOut = (RegionOut *)c->hOut.p;
     unsigned long long *noiseBase = (unsigned long long *)c->hNoiseBase.p;
-    uint8_t *noise = (uint8_t *)c->hNoise.p;
+    unsigned long long *callState = (unsigned long long *)c->hNoise.p, *callOff = callState + maxCalls;
+    uint32_t *callPx = (uint32_t *)(callOff + maxCalls);
+    unsigned long long *dCallState = (unsigned long long *)c->bCalls.p, *dCallOff = dCallState + maxCalls;
+    uint32_t *dCallPx = (uint32_t *)(dCallOff + maxCalls);
     std::vector<uint32_t> npx(blocks);
     bp.scratchPx = (uint32_t *)c->bPx.p; bp.scratchV = (float *)c->bV.p; bp.scratchFac = (uint8_t *)c->bFac.p; bp.scratchCap = (uint32_t)capMax;
     bp.noise = (const uint8_t *)c->bNoise.p;
@@ -1410,20 +1436,39 @@ extern "C"
     limg_hip_result workerResult = limg_hip_success;
     double busy[3] = { 0, 0, 0 }; // worker: fit + search (incl. copies), chain walk, store launch
     const bool pcg = c->opt.dither_pcg != 0;
-    hipStream_t ws = c->workStream;
+    // One batch = everything the merge has published when the worker looks; one stream for the fit + search kernels.  Measured on one box (profiles/r04_blocked_pipeline.md):
+    // batches capped at 8 K ... 64 K rectangles, two or four streams round-robin, a high-priority stream -- all within +-2 ms of this, most of them worse: the GPU
+    // (similarity kernels 13 ms + fit / search kernels 13 ms per 8192^2 image) is as busy as the two host threads, so reordering its queue buys nothing.
+    constexpr size_t kBatchRegions = (size_t)1 << 30;
+    constexpr size_t kWorkStreams = 1;
+    while (c->workStreams.size() < kWorkStreams)
+    {
+      hipStream_t st;
+      HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      c->workStreams.push_back(st);
+    }
+    if (!c->storeStream) HIP_TRY(hipStreamCreateWithFlags(&c->storeStream, hipStreamNonBlocking));
+    hipStream_t ss = c->storeStream; // noise expansion + store kernels of a batch: beside the next batch's fit + search kernel, not behind it
 
-    if (!c->workEvent[0])
-      for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&c->workEvent[i], hipEventDisableTiming));
+    constexpr size_t kInFlight = 32; // batches whose fit + search kernel has been enqueued and whose chain has not been walked yet
+    while (c->workEvents.size() < kInFlight)
+    {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      c->workEvents.push_back(e);
+    }
 
     double dbgEnqueue = 0, dbgWait = 0; int dbgBatches = 0;
     std::thread worker([&]() {
       if (hipSetDevice(c->device) != hipSuccess) { workerResult = limg_hip_error_Generic; }
-      // Software pipeline of depth two: the fit + search kernel of batch k + 1 is enqueued before the chain of batch k is walked, so the GPU
-      // round trip (upload, kernel, shift words back) hides behind the AES chain, which is this thread's real work.
-      struct Batch { size_t r0 = 0, r1 = 0; bool live = false; } pending;
-      size_t issued = 0;
-      int slot = 0;
+      // The GPU runs AHEAD of this thread: whatever the merge has published goes to the device at once (rectangle table up, fit + search kernel, records and
+      // shift words back, one event per batch, up to kInFlight batches), and the chain -- this thread's real work, serial by construction -- is walked batch by batch
+      // in creation order as the results arrive.  (Rounds 2-3 kept one batch in flight: every batch's GPU round trip was waited for, 11-20 ms per image.)
+      struct Batch { size_t r0 = 0, r1 = 0; size_t ev = 0; };
+      std::vector<Batch> queue; // FIFO: [head, queue.size())
+      size_t head = 0, issued = 0, evNext = 0;
       uint64_t chain = kDitherSeed, noiseOff = 0;
+      size_t callCount = 0;
       bool fin = false;
       auto params_of = [&](const Batch &b) {
         BlockedParams q = bp;
@@ -1434,59 +1479,87 @@ extern "C"
       };
       for (;;)
       {
-        // 1. take whatever the merge has published since the last look (wait for it only if there is nothing else to do)
-        Batch next;
-        if (!fin)
-        {
-          std::unique_lock<std::mutex> lk(pipe.m);
-          if (!pending.live) pipe.cv.wait(lk, [&] { return pipe.ready > issued || pipe.finished; });
-          if (pipe.ready > issued) { next.r0 = issued; next.r1 = pipe.ready; next.live = true; issued = pipe.ready; }
-          else fin = pipe.finished;
-        }
+        // 1. everything the merge has published since the last look goes to the GPU (wait for the merge only if there is nothing to walk)
         const clk::time_point w0 = clk::now();
-        if (next.live) dbgBatches++;
-        if (next.live && workerResult == limg_hip_success)
+        if (!fin && queue.size() - head < kInFlight)
         {
-          const size_t n = next.r1 - next.r0;
-          const BlockedParams q = params_of(next);
-          bool ok = hipMemcpyAsync((RegionDesc *)c->bRegions.p + next.r0, desc + next.r0, n * sizeof(RegionDesc), hipMemcpyHostToDevice, ws) == hipSuccess;
-          if (ok) { launch_blocked_fit_search(q, ws); ok = hipGetLastError() == hipSuccess; }
-          ok = ok && hipMemcpyAsync(hOut + next.r0, (RegionOut *)c->bOut.p + next.r0, n * sizeof(RegionOut), hipMemcpyDeviceToHost, ws) == hipSuccess;
-          ok = ok && hipEventRecord(c->workEvent[slot], ws) == hipSuccess;
-          if (!ok) workerResult = limg_hip_error_Generic;
+          size_t r0 = 0, r1 = 0;
+          {
+            std::unique_lock<std::mutex> lk(pipe.m);
+            if (head == queue.size()) pipe.cv.wait(lk, [&] { return pipe.ready > issued || pipe.finished; });
+            // (at most kBatchRegions at a time: several smaller batches in flight let the walk of one overlap the kernels of the next ones; one batch of everything
+            //  published so far would be waited for as a whole)
+            if (pipe.ready > issued) { r0 = issued; r1 = pipe.ready - issued > kBatchRegions ? issued + kBatchRegions : pipe.ready; issued = r1; }
+            else fin = pipe.finished;
+          }
+          if (r1 > r0)
+          {
+            dbgBatches++;
+            Batch nb; nb.r0 = r0; nb.r1 = r1; nb.ev = evNext; evNext = (evNext + 1) % kInFlight;
+            if (workerResult == limg_hip_success)
+            {
+              const size_t n = r1 - r0;
+              const BlockedParams q = params_of(nb);
+              hipStream_t bs = c->workStreams[nb.ev % kWorkStreams];
+              bool ok = hipMemcpyAsync((RegionDesc *)c->bRegions.p + r0, desc + r0, n * sizeof(RegionDesc), hipMemcpyHostToDevice, bs) == hipSuccess;
+              if (ok) { launch_blocked_fit_search(q, bs); ok = hipGetLastError() == hipSuccess; }
+              ok = ok && hipMemcpyAsync(hOut + r0, (RegionOut *)c->bOut.p + r0, n * sizeof(RegionOut), hipMemcpyDeviceToHost, bs) == hipSuccess;
+              ok = ok && hipEventRecord(c->workEvents[nb.ev], bs) == hipSuccess;
+              if (!ok) workerResult = limg_hip_error_Generic;
+            }
+            queue.push_back(nb);
+          }
         }
         const clk::time_point w0b = clk::now();
         dbgEnqueue += ms(w0, w0b);
-        // 2. finish the batch enqueued one round earlier: its shift words are (about to be) back
-        if (pending.live && workerResult == limg_hip_success)
+        // 2. the oldest batch in flight: its shift words are (about to be) back
+        if (head < queue.size())
         {
-          bool ok = hipEventSynchronize(c->workEvent[slot ^ 1]) == hipSuccess;
-          const clk::time_point w1 = clk::now();
-          dbgWait += ms(w0b, w1);
-          // the dither chain (src/limg_internal.h:711, src/limg.cpp:1541-1551): one chain through all rectangles in creation order; a call over N
-          // pixels advances it by floor(N / 8) AES rounds + N % 8 PCG steps, so it is walked here, producing the byte every pixel adds
-          const uint64_t noiseStart = noiseOff;
-          if (ok)
-            for (size_t i = pending.r0; i < pending.r1; i++)
+          const Batch pending = queue[head++];
+          if (workerResult == limg_hip_success)
+          {
+            bool ok = hipEventSynchronize(c->workEvents[pending.ev]) == hipSuccess;
+            const clk::time_point w1 = clk::now();
+            dbgWait += ms(w0b, w1);
+            // the dither chain (src/limg_internal.h:711, src/limg.cpp:1541-1551): one chain through all rectangles in creation order; a call over N
+            // pixels advances it by floor(N / 8) AES rounds + N % 8 PCG steps, so it is walked here -- for the chain VALUES only: every call's start value, pixel
+            // count and place in the noise buffer go up (20 bytes per call) and k_noise_expand_calls produces the byte every pixel adds on the device.  (Rounds
+            // 1-3 wrote the bytes here and uploaded them: 200 MB per 8192^2 image through this thread's store buffers and over PCIe.)
+            const size_t call0 = callCount;
+            if (ok)
+              for (size_t i = pending.r0; i < pending.r1; i++)
+              {
+                noiseBase[i] = noiseOff;
+                const uint32_t calls = hOut[i].shiftWord >> 24;
+                for (uint32_t k = 0; k < calls && callCount < maxCalls; k++, noiseOff += npx[i], callCount++)
+                {
+                  callState[callCount] = chain; callOff[callCount] = noiseOff; callPx[callCount] = npx[i];
+                  chain = chain_call_n(chain, npx[i], nullptr, pcg);
+                }
+              }
+            const clk::time_point w2 = clk::now();
+            const BlockedParams q = params_of(pending);
+            const size_t nc = callCount - call0;
+            ok = ok && hipStreamWaitEvent(ss, c->workEvents[pending.ev], 0) == hipSuccess; // this batch's records and shift words are in bOut
+            if (ok && nc)
             {
-              noiseBase[i] = noiseOff;
-              const uint32_t calls = hOut[i].shiftWord >> 24;
-              for (uint32_t k = 0; k < calls; k++, noiseOff += npx[i]) chain = chain_call_n(chain, npx[i], noise + noiseOff, pcg);
+              ok = hipMemcpyAsync(dCallState + call0, callState + call0, nc * 8, hipMemcpyHostToDevice, ss) == hipSuccess &&
+                   hipMemcpyAsync(dCallOff + call0, callOff + call0, nc * 8, hipMemcpyHostToDevice, ss) == hipSuccess &&
+                   hipMemcpyAsync(dCallPx + call0, callPx + call0, nc * 4, hipMemcpyHostToDevice, ss) == hipSuccess;
+              if (ok) { launch_noise_expand_calls((uint8_t *)c->bNoise.p, dCallState + call0, dCallOff + call0, dCallPx + call0, nc, pcg, ss); ok = hipGetLastError() == hipSuccess; }
             }
-          const clk::time_point w2 = clk::now();
-          const BlockedParams q = params_of(pending);
-          if (ok && noiseOff > noiseStart) ok = hipMemcpyAsync((uint8_t *)c->bNoise.p + noiseStart, noise + noiseStart, noiseOff - noiseStart, hipMemcpyHostToDevice, ws) == hipSuccess;
-          ok = ok && hipMemcpyAsync((unsigned long long *)c->bNoiseBase.p + pending.r0, noiseBase + pending.r0, (pending.r1 - pending.r0) * 8, hipMemcpyHostToDevice, ws) == hipSuccess;
-          if (ok) { launch_blocked_store(q, ws); ok = hipGetLastError() == hipSuccess; }
-          const clk::time_point w3 = clk::now();
-          busy[0] += ms(w0, w1); busy[1] += ms(w1, w2); busy[2] += ms(w2, w3);
-          if (!ok) workerResult = limg_hip_error_Generic;
+            ok = ok && hipMemcpyAsync((unsigned long long *)c->bNoiseBase.p + pending.r0, noiseBase + pending.r0, (pending.r1 - pending.r0) * 8, hipMemcpyHostToDevice, ss) == hipSuccess;
+            if (ok) { launch_blocked_store(q, ss); ok = hipGetLastError() == hipSuccess; }
+            const clk::time_point w3 = clk::now();
+            busy[0] += ms(w0, w1); busy[1] += ms(w1, w2); busy[2] += ms(w2, w3);
+            if (!ok) workerResult = limg_hip_error_Generic;
+          }
         }
-        pending = next;
-        slot ^= 1;
-        if (!pending.live && fin) break;
+        if (fin && head == queue.size()) break;
       }
-      if (hipStreamSynchronize(ws) != hipSuccess && workerResult == limg_hip_success) workerResult = limg_hip_error_Generic;
+      for (hipStream_t st : c->workStreams)
+        if (hipStreamSynchronize(st) != hipSuccess && workerResult == limg_hip_success) workerResult = limg_hip_error_Generic;
+      if (hipStreamSynchronize(ss) != hipSuccess && workerResult == limg_hip_success) workerResult = limg_hip_error_Generic;
     });
 
     // producer: the merge; its progress callback lays the finished rectangles out (pixel counts, scratch slices) and hands them over

@@ -180,6 +180,8 @@ namespace limg_hip
       std::vector<uint8_t> used;
       const std::function<void(uint32_t)> *needRow = nullptr; // the similarity bits arrive band by band: called before a seed row's bits are first read
       mutable uint32_t rowsSeen = 0;
+      mutable uint32_t pfRow = 0xFFFFFFFFu, pfCol = 0, pfAhead = 0; // look-ahead of `find` that requests the similarity rows of the seeds to come
+      mutable bool pfTiny = false;
       const uint8_t *flags = nullptr; // per seed, from the GPU: bit 0 = a rectangle of >= 3 x 3 is possible at all, bit 1 = any rectangle is (necessary conditions)
 
       // One expansion (src/limg.cpp:1288-1384) from the seed at (ox, oy).  A strip joins when every block of it is unused
@@ -217,6 +219,61 @@ namespace limg_hip
           }
         }
       }
+      // The same expansion for the common case -- right / down only, everything inside the precomputed window -- on ROW MASKS: bit dx of avail(dy) says
+      // "block (sx + dx, sy + dy) is unused and matches the seed" (13 columns: offsets 0 .. kMatchHi).  A column joins when its bit is set in the AND of the rows
+      // taken so far, a row when its mask covers the columns taken so far: a few operations per step instead of a loop over the strip's blocks, and a row is only
+      // looked at when the rectangle gets there (most expansions end after one or two steps).  Returns false when the rectangle reaches the window's edge or the
+      // generic form is needed: the caller then runs `expand` from scratch (same result by construction: both evaluate the same predicate on the same blocks).
+      bool expand_fast(const uint32_t sx, const uint32_t sy, uint32_t &rx, uint32_t &ry, const uint32_t minSide) const
+      {
+        if (!bits) return false;
+        if (needRow && sy >= rowsSeen) { (*needRow)(sy); rowsSeen = sy + 1; }
+        const unsigned long long *row = bits + ((size_t)sy * bx + sx) * kMatchWords;
+        const uint32_t wmax = bx - sx < (uint32_t)kMatchHi + 1u ? bx - sx : (uint32_t)kMatchHi + 1u; // columns of the window that exist
+        const uint32_t hmax = by - sy < (uint32_t)kMatchHi + 1u ? by - sy : (uint32_t)kMatchHi + 1u;
+        auto avail = [&](const uint32_t dy) -> uint32_t
+        {
+          const unsigned cell = (dy + kMatchLo) * kMatchSide + kMatchLo; // first of the row's 13 cells; 323 at most, so word + 1 exists whenever the run crosses a word
+          const unsigned w = cell >> 6, sh = cell & 63;
+          unsigned long long m = row[w] >> sh;
+          if (sh > 64 - (kMatchHi + 1)) m |= row[w + 1] << (64 - sh);
+          const uint8_t *u = &used[(size_t)(sy + dy) * bx + sx];
+          uint32_t free_ = 0;
+#if defined(__x86_64__)
+          // 16 flag bytes at once (`used` carries 16 bytes of padding behind its last row); columns past the image's right edge belong to the next row: masked off
+          free_ = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i *>(u)), _mm_setzero_si128())) & ((1u << wmax) - 1u);
+#else
+          for (uint32_t dx = 0; dx < wmax; dx++) free_ |= (u[dx] ? 0u : 1u) << dx;
+#endif
+          return (uint32_t)m & free_ & ((1u << (kMatchHi + 1)) - 1u);
+        };
+        uint32_t colAnd = avail(0) | 1u; // (the seed itself: unused by construction, its own cell is never set)
+        rx = 1; ry = 1;
+        bool down = true, right = true;
+        while (down || right)
+        {
+          if (right)
+          {
+            if (sx + rx + 1 < bx)
+            {
+              if (rx >= wmax || rx > (uint32_t)kMatchHi) return false; // the next column lies outside the window
+              if ((colAnd >> rx) & 1u) rx++; else { right = false; if (rx < minSide) return true; }
+            }
+            else { right = false; if (rx < minSide) return true; }
+          }
+          if (down)
+          {
+            if (sy + ry + 1 < by)
+            {
+              if (ry >= hmax || ry > (uint32_t)kMatchHi) return false;
+              const uint32_t a = avail(ry), need = (1u << rx) - 1u;
+              if ((a & need) == need) { colAnd &= a; ry++; } else { down = false; if (ry < minSide) return true; }
+            }
+            else { down = false; if (ry < minSide) return true; }
+          }
+        }
+        return true;
+      }
       // src/limg.cpp:1386-1496
       bool find(bool acceptTiny, uint32_t &staticX, uint32_t &staticY, HostRegion &out) const
       {
@@ -227,12 +284,30 @@ namespace limg_hip
           if (flags && needRow && oy >= rowsSeen) { (*needRow)(oy); rowsSeen = oy + 1; }
           const uint8_t *frow = flags ? flags + (size_t)oy * bx : nullptr;
           const uint8_t need = acceptTiny ? 2 : 1;
+          // The similarity bits of an 8192^2 image are 50 MB, and a seed's 48-byte row is first touched when its expansion starts: a DRAM round trip per seed.  The
+          // seeds to come are known (unused, flagged), so their rows are requested a few candidates ahead (`pf`: the column the look-ahead has reached in this row).
+          // (the look-ahead's position survives from one call to the next -- `find` returns at every rectangle it finds)
+          if (pfRow != oy || pfTiny != acceptTiny) { pfRow = oy; pfTiny = acceptTiny; pfCol = ox; pfAhead = 0; }
+          auto prefetch_ahead = [&]()
+          {
+            if (!bits || !frow) return;
+            if (needRow && oy >= rowsSeen) return; // (this band's bits are not on the host yet: nothing to request)
+            for (; pfCol < bx && pfAhead < 6; pfCol++)
+              if (!urow[pfCol] && (frow[pfCol] & need))
+              {
+                const char *q = reinterpret_cast<const char *>(bits + ((size_t)oy * bx + pfCol) * kMatchWords);
+                __builtin_prefetch(q); __builtin_prefetch(q + 47);
+                pfAhead++;
+              }
+          };
           for (; ox < bx; ox++)
           {
             if (urow[ox]) continue;
             if (frow && !(frow[ox] & need)) continue; // cannot become a rectangle of the wanted kind whatever is in use: same outcome as growing and discarding
+            if (pfCol <= ox) { pfCol = ox + 1; pfAhead = 0; } else if (pfAhead > 0) pfAhead--;
+            prefetch_ahead();
             uint32_t x = ox, y = oy, rx = 1, ry = 1;
-            expand(x, y, rx, ry, false, acceptTiny ? 0u : 3u);
+            if (!expand_fast(ox, oy, rx, ry, acceptTiny ? 0u : 3u)) { rx = 1; ry = 1; expand(x, y, rx, ry, false, acceptTiny ? 0u : 3u); }
             if (rx == 1 && ry == 1) continue;
             if (!acceptTiny)
             {
@@ -269,7 +344,7 @@ namespace limg_hip
   {
     Merge m;
     m.rec = pass1; m.bits = matchBits; m.bx = blocksX; m.by = blocksY; m.ch = channels; m.needRow = needSeedRow; m.flags = matchBits ? seedFlags : nullptr;
-    m.used.assign((size_t)blocksX * blocksY, 0);
+    m.used.assign((size_t)blocksX * blocksY + 16, 0); // (+ 16: expand_fast reads 16 flag bytes at a time)
     out.clear();
     out.reserve((size_t)blocksX * blocksY);
     size_t told = 0;

@@ -75,6 +75,127 @@ namespace limg_hip
     }
   }
 
+  namespace
+  {
+    // Images with partial edge blocks: the chain is data dependent (a call over N pixels is N / 8 AES rounds + N % 8 PCG steps, src/limg.cpp:824-879), so the host walks
+    // it -- but only the chain VALUES: what it uploads per dither call is the value the call starts from (8 bytes) and its pixel count (1 byte), and this kernel
+    // expands them into the 64 noise bytes per call the F step indexes.  One lane per call.  pcg: the reference's PCG dither (every pixel a PCG step, :799-822).
+    __global__ __launch_bounds__(256) void k_noise_expand(uint8_t *noise, const unsigned long long *states, const uint8_t *pixels, uint32_t calls, int pcg)
+    {
+      __shared__ uint32_t td[4][256];
+      for (uint32_t x = threadIdx.x; x < 256; x += 256)
+      {
+        const uint32_t s = d_inv_sbox[x], s2 = xtime(s), s4 = xtime(s2), s8 = xtime(s4);
+        const uint32_t m9 = s8 ^ s, m11 = s8 ^ s2 ^ s, m13 = s8 ^ s4 ^ s, m14 = s8 ^ s4 ^ s2;
+        td[0][x] = m14 | (m9 << 8) | (m13 << 16) | (m11 << 24);
+        td[1][x] = m11 | (m14 << 8) | (m9 << 16) | (m13 << 24);
+        td[2][x] = m13 | (m11 << 8) | (m14 << 16) | (m9 << 24);
+        td[3][x] = m9 | (m13 << 8) | (m11 << 16) | (m14 << 24);
+      }
+      __syncthreads();
+      const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+      if (k >= calls) return;
+      const uint32_t key[4] = { 0xAB705E1Du, 0x824A73EAu, 0x06CB4CADu, 0x2A76E980u };
+      unsigned long long h = states[k];
+      const uint32_t n = pixels[k], rounds = (!pcg && n >= 8u) ? n / 8u : 0u;
+      uint32_t bytes[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) bytes[i] = 0u;
+      uint32_t st[4] = { (uint32_t)h, (uint32_t)(h >> 32), ~(uint32_t)h, ~(uint32_t)(h >> 32) };
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+      {
+        if ((uint32_t)j < rounds)
+        {
+          uint32_t o[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++)
+            o[c] = td[0][st[c] & 0xFFu] ^ td[1][(st[(c + 3) & 3] >> 8) & 0xFFu] ^ td[2][(st[(c + 2) & 3] >> 16) & 0xFFu] ^ td[3][st[(c + 1) & 3] >> 24] ^ key[c];
+#pragma unroll
+          for (int c = 0; c < 4; c++) st[c] = o[c];
+          bytes[2 * j] = __builtin_amdgcn_perm(st[1], st[0], 0x06040200u);
+          bytes[2 * j + 1] = __builtin_amdgcn_perm(st[3], st[2], 0x06040200u);
+        }
+      }
+      if (rounds) h = (unsigned long long)st[0] | ((unsigned long long)st[1] << 32);
+      uint4 *out = reinterpret_cast<uint4 *>(noise + (size_t)k * 64);
+#pragma unroll
+      for (int q = 0; q < 4; q++) out[q] = make_uint4(bytes[4 * q], bytes[4 * q + 1], bytes[4 * q + 2], bytes[4 * q + 3]);
+      // the pixels the AES rounds do not cover: PCG steps on the chain value (src/limg.cpp:866-876); rare (blocks whose pixel count is not a multiple of 8), so byte stores
+      for (uint32_t i = rounds * 8u; i < n; i++)
+      {
+        h = h * 6364136223846793005ULL + 1ULL;
+        const uint32_t xs = (uint32_t)(((h >> 18) ^ h) >> 27), rot = (uint32_t)(h >> 59);
+        noise[(size_t)k * 64 + i] = (uint8_t)((xs >> rot) | (xs << ((0u - rot) & 31u)));
+      }
+    }
+  }
+
+  namespace
+  {
+    // The merged-block encoder's dither calls run over whole rectangles (N = 64 rx ry pixels minus what the image's edges cut off): N / 8 AES rounds in a row, then N % 8
+    // PCG steps (src/limg.cpp:824-879 with rangeSize = N; :1541-1551).  One lane per call again -- the rounds of a call are a serial chain -- writing the call's N noise
+    // bytes (one per pixel) at its offset in the noise buffer.  The host walks the same chain, but only for the values the calls start from.
+    __global__ __launch_bounds__(256) void k_noise_expand_calls(uint8_t *noise, const unsigned long long *states, const unsigned long long *offsets, const uint32_t *pixels,
+                                                               uint32_t calls, int pcg)
+    {
+      __shared__ uint32_t td[4][256];
+      {
+        const uint32_t x = threadIdx.x;
+        const uint32_t s = d_inv_sbox[x], s2 = xtime(s), s4 = xtime(s2), s8 = xtime(s4);
+        const uint32_t m9 = s8 ^ s, m11 = s8 ^ s2 ^ s, m13 = s8 ^ s4 ^ s, m14 = s8 ^ s4 ^ s2;
+        td[0][x] = m14 | (m9 << 8) | (m13 << 16) | (m11 << 24);
+        td[1][x] = m11 | (m14 << 8) | (m9 << 16) | (m13 << 24);
+        td[2][x] = m13 | (m11 << 8) | (m14 << 16) | (m9 << 24);
+        td[3][x] = m9 | (m13 << 8) | (m11 << 16) | (m14 << 24);
+      }
+      __syncthreads();
+      const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+      if (k >= calls) return;
+      const uint32_t key[4] = { 0xAB705E1Du, 0x824A73EAu, 0x06CB4CADu, 0x2A76E980u };
+      unsigned long long h = states[k];
+      const uint32_t n = pixels[k], rounds = (!pcg && n >= 8u) ? n / 8u : 0u;
+      uint8_t *out = noise + offsets[k];
+      uint32_t st[4] = { (uint32_t)h, (uint32_t)(h >> 32), ~(uint32_t)h, ~(uint32_t)(h >> 32) };
+      const bool aligned = (reinterpret_cast<uintptr_t>(out) & 7u) == 0;
+      for (uint32_t j = 0; j < rounds; j++)
+      {
+        uint32_t o[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+          o[c] = td[0][st[c] & 0xFFu] ^ td[1][(st[(c + 3) & 3] >> 8) & 0xFFu] ^ td[2][(st[(c + 2) & 3] >> 16) & 0xFFu] ^ td[3][st[(c + 1) & 3] >> 24] ^ key[c];
+#pragma unroll
+        for (int c = 0; c < 4; c++) st[c] = o[c];
+        const uint32_t lo = __builtin_amdgcn_perm(st[1], st[0], 0x06040200u), hi = __builtin_amdgcn_perm(st[3], st[2], 0x06040200u);
+        if (aligned) *reinterpret_cast<uint2 *>(out + 8 * (size_t)j) = make_uint2(lo, hi);
+        else
+        {
+#pragma unroll
+          for (int b = 0; b < 4; b++) { out[8 * (size_t)j + b] = (uint8_t)(lo >> (8 * b)); out[8 * (size_t)j + 4 + b] = (uint8_t)(hi >> (8 * b)); }
+        }
+      }
+      if (rounds) h = (unsigned long long)st[0] | ((unsigned long long)st[1] << 32);
+      for (uint32_t i = rounds * 8u; i < n; i++)
+      {
+        h = h * 6364136223846793005ULL + 1ULL;
+        const uint32_t xs = (uint32_t)(((h >> 18) ^ h) >> 27), rot = (uint32_t)(h >> 59);
+        out[i] = (uint8_t)((xs >> rot) | (xs << ((0u - rot) & 31u)));
+      }
+    }
+  }
+
+  void launch_noise_expand_calls(uint8_t *noise, const unsigned long long *dStates, const unsigned long long *dOffsets, const uint32_t *dPixels, size_t calls, bool pcg, hipStream_t s)
+  {
+    if (calls == 0) return;
+    hipLaunchKernelGGL(k_noise_expand_calls, dim3((uint32_t)((calls + 255u) / 256u)), dim3(256), 0, s, noise, dStates, dOffsets, dPixels, (uint32_t)calls, pcg ? 1 : 0);
+  }
+
+  void launch_noise_expand(uint8_t *noise, const unsigned long long *dStates, const uint8_t *dPixels, size_t calls, bool pcg, hipStream_t s)
+  {
+    if (calls == 0) return;
+    hipLaunchKernelGGL(k_noise_expand, dim3((uint32_t)((calls + 255u) / 256u)), dim3(256), 0, s, noise, dStates, dPixels, (uint32_t)calls, pcg ? 1 : 0);
+  }
+
   const uint64_t *noise_checkpoints_host(size_t *pCount, size_t *pEvery)
   {
     static const uint64_t table[LIMG_NOISE_CHECKPOINT_COUNT] = LIMG_NOISE_CHECKPOINTS_INIT;

@@ -92,6 +92,26 @@ def test_batch_as_pipeline_of_sub_batches(gpu, oracle, sub, alpha, pool, fast, e
         gpu.set_options()
 
 
+@pytest.mark.parametrize("n", [17, 35])
+def test_batch_default_rule_pipelines_long_lists(gpu, oracle, n):
+    """Default options: a list of 16 ... 31 images goes in sub-batches of 4, of 32 and more in sub-batches of 8 (limg_hip_options.batch_sub_images = 0); every image
+    still gets the planes of its single encode."""
+    import torch
+    W, H = 256, 24
+    host = [oracle.photo_noise(W, H, 200 + i) if i % 3 else oracle.random_gradient(W, H, 200 + i, True) for i in range(n)]
+    imgs = [torch.from_numpy(h.view(np.int32)).cuda() for h in host]
+    outs = [gpu.alloc_planes_device(W, H) for _ in imgs]
+    gpu.set_options()
+    gpu.encode3d_batch_device(imgs, True, outs)
+    torch.cuda.synchronize()
+    gpu.check()
+    for i, (h, pl) in enumerate(zip(host, outs)):
+        want = oracle.encode3d(h, True)
+        got = _host(pl)
+        bad = [(k, int((got[k] != want[k]).sum())) for k in PLANES if not np.array_equal(got[k], want[k])]
+        assert not bad, (n, i, bad)
+
+
 def test_batch_stats_cover_the_whole_list(gpu, oracle):
     """limg_hip_last_stats after a batched encode: all images of the list together, also when the list took several launch pairs (chunks) or a pipeline of
     sub-batches (only the last chunk was counted)."""
