@@ -299,6 +299,9 @@ namespace limg_hip
         count += (uint32_t)__builtin_popcountll(open);
       }
       wave_lds_fence();
+#ifdef LIMG_MATCH_SKIP2 // timing experiment only (wrong results; tools/r04/run9.sh): how much of the kernel is the expensive evaluation?
+      count = 0;
+#endif
       for (uint32_t k = 0; k < count; k += 128)
       {
         const uint32_t i0 = k + lane, i1 = k + 64 + lane;
