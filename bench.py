@@ -333,6 +333,14 @@ def run_sharded(args, g, dist, rank, world):
         px_per_launch = (units[0][0].numel() if units else 0) * (len(units) if batched else 1)
         pmc_key = "config%d_%s%s%s" % (args.config, "batched" if batched else "single", "" if args.contexts == 1 else "_ctx%d" % args.contexts, "" if not sub_eff else "_sub%d" % sub_eff)
         pmc = pmc_entry(pmc_key)
+        if pmc and batched and sub_eff:
+            # the counters are means per DISPATCH; a pipelined list is ceil(n / sub) dispatches of each kernel per step: scale to the whole list
+            n_sub = (n_units + sub_eff - 1) // sub_eff
+            pmc = dict(pmc)
+            for k in ("fetch_kib", "write_kib", "valu_instr_per_launch", "salu_instr_per_launch", "lds_instr_per_launch"):
+                if pmc.get(k) is not None:
+                    pmc[k] = pmc[k] * n_sub
+            pmc["source"] = "%s (per-dispatch means x %d sub-batches)" % (pmc.get("source"), n_sub)
         achieved = ALGO_BYTES_PER_PX * px_per_launch / (ksum * 1e-3) / 1e9 if ksum > 0 else 0.0
         line = {
             "metric": "encode Mpixels/s, RGBA (limg_encode3d_test-equivalent: all 11 planes stored), BASELINE configs[%d]" % (args.config - 1),

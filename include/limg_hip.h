@@ -311,7 +311,7 @@ limg_hip_result limg_hip_encode3d_single_chain_device(limg_hip_context *pCtx, co
 /* Abort rule of the two collective entries (the reference's analogue, row strips on one thread pool, cannot half-fail: src/limg.cpp:2114-2136): a rank never leaves its
  * peers inside a collective.  limg_hip_gather_stream decides "fits / does not fit" from all-gathered numbers, so every rank returns limg_hip_error_OutOfBounds alike
  * before anything is posted.  limg_hip_encode3d_single_chain_device: a rank whose own E step failed (bad arguments, allocation, launch) still joins the 8-byte
- * all-gather, with the poison value ~0, and returns its error; on every other rank the call returns limg_hip_success (it is asynchronous), the F step stores
+ * all-gather, with the poison value ~0, and returns its error; on every other rank the call -- it is asynchronous -- returns limg_hip_success, the F step stores
  * NOTHING, and the next limg_hip_check_device_status of that context returns limg_hip_error_Generic ("a rank of the communicator aborted ..."), once. */
 /* The two halves of the above without the exchange, for callers that move the counts themselves (and for single-GPU tests of the chain arithmetic):
  * phase 1 = E step + scan, writes this strip's dither-call total to *pCallsDevice; phase 2 = F step, its first dither call is *pChainBaseDevice.

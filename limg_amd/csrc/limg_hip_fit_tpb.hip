@@ -27,7 +27,10 @@ namespace limg_hip
     // = 12 per CU) set the occupancy.  Otherwise the 64 blocks' pixels are staged in LDS first (dword loads), 17 KiB per wave, two waves per workgroup
     // (2 x 17 + 8 KiB => 3 workgroups = 6 waves per CU).  Occupancy is not what the kernel lacks: forced down to 61 VGPRs (8 waves per SIMD) it runs at the same
     // speed -- it is issue-bound on its instruction count.
-    template <bool DIRECT> constexpr int tpb_waves() { return DIRECT ? 4 : 2; } // waves per workgroup: they share one copy of the table
+#ifndef LIMG_TPB_WG_WAVES
+#define LIMG_TPB_WG_WAVES 4
+#endif
+    template <bool DIRECT> constexpr int tpb_waves() { return DIRECT ? LIMG_TPB_WG_WAVES : 2; } // waves per workgroup: they share one copy of the table
 
     // The eight rows of a lane's block, two per iteration, the NEXT two already requested: a pass is a chain of (load 32 bytes, 8 pixels of arithmetic) per row, and
     // with few waves on a SIMD -- a 4096^2 image is one round of 4 waves per SIMD, the sub-batch pipeline leaves this kernel one -- nothing else covers the load's
