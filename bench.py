@@ -331,7 +331,9 @@ def run_sharded(args, g, dist, rank, world):
         kavg = kernels.mean(axis=0) if len(kernels) else np.zeros(3)
         ksum = float(kavg.sum())  # k_fit_tpb + k_encode_persistent of one unit (single chain: the E/scan, exchange and F intervals)
         px_per_launch = (units[0][0].numel() if units else 0) * (len(units) if batched else 1)
-        pmc_key = "config%d_%s%s%s" % (args.config, "batched" if batched else "single", "" if args.contexts == 1 else "_ctx%d" % args.contexts, "" if not sub_eff else "_sub%d" % sub_eff)
+        pmc_key = "config%d_%s%s%s%s" % (args.config, ("batched_n%d" % n_units) if batched else ("single_chain" if single_chain else "single"),
+                                         "" if args.contexts == 1 else "_ctx%d" % args.contexts, "" if not (batched and sub_eff) else "_sub%d" % sub_eff,
+                                         "" if (args.size == 8192 and args.workload == "photo_noise") else "_%s%d" % (args.workload, args.size))
         pmc = pmc_entry(pmc_key)
         if pmc and batched and sub_eff:
             # the counters are means per DISPATCH; a pipelined list is ceil(n / sub) dispatches of each kernel per step: scale to the whole list
