@@ -374,6 +374,8 @@ def run_blocked(args, g, dist, rank, world, W, H):
     (greedy merge over GPU similarity bits, dither chain walk); input and the 13 output planes stay in HBM."""
     import torch
     import numpy as np
+    if args.forced_shift >= 0:  # (kernel-time experiments: the per-rectangle search bypassed)
+        g.set_options(forced_shift=(args.forced_shift,) * 3)
     img = g.synth_device(args.workload, W, H, seed=1 + rank)
     planes = g.alloc_blocked_planes_device(W, H)
     for _ in range(max(args.warmup, 1)):
