@@ -1,3 +1,4 @@
+# NOTE: the LIMG_BLK_EXP hooks this script builds with were removed from limg_hip_blocked.hip together with the experiment (profiles/r04_blocked_pipeline.md); kept as the record of how the split was measured.
 set -o pipefail
 O=$PWD/gpurun_out/r04_13; mkdir -p $O
 R=$PWD
