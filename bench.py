@@ -830,13 +830,20 @@ def collective_evidence(g, dist, rank, world):
     if dist.get_backend() != "nccl":
         ev["note"] = "gloo rehearsal: no RCCL communicator"
         return ev
-    g.comm_init_from_torch(dist)
-    info = g.comm_info()
+    try:
+        g.comm_init_from_torch(dist)
+        info = g.comm_info()
+        g.comm_destroy()
+    except Exception as e:  # the evidence must never sink the measurement: an error here is reported on the line, the timed numbers stand
+        info = {"ranks": -1, "rank": rank, "rccl_version": -1}
+        ev["error"] = repr(e)
     t = torch.tensor([info["ranks"], info["rank"], info["rccl_version"]], dtype=torch.int64, device="cuda")
     allv = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(allv, t)
-    g.comm_destroy()
     views = [[int(v) for v in a.tolist()] for a in allv]
+    if any(v[0] < 0 for v in views):
+        ev["comm_views"] = views  # (a rank could not create or query the library's communicator: reported, not fatal)
+        return ev
     if any(v[0] != world for v in views) or sorted(v[1] for v in views) != list(range(world)):
         raise SystemExit("bench.py: RCCL communicator does not span the %d ranks asked for: %r" % (world, views))
     ev.update({"rccl_version": info["rccl_version"], "comm_ranks": info["ranks"], "comm_user_ranks": [v[1] for v in views]})

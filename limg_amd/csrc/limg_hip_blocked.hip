@@ -401,9 +401,28 @@ namespace limg_hip
           {
             const float *src = sv + (size_t)lane * cap;
             uint32_t i = 0;
+            // sixteen terms per iteration, the next sixteen already requested: the adds are one dependent chain (that IS the reference's order), and with the loads
+            // issued where they are used an iteration cost ~160 cycles per four terms -- five times what the chain itself needs.  A batch's kernel ends with its
+            // largest rectangle (10 816 terms per walk for 13 x 13 blocks), and the worker thread waits for exactly that (profiles/r04_blocked_pipeline.md).
+            if (n >= 32)
+            {
+              float4 a0 = *reinterpret_cast<const float4 *>(src), a1 = *reinterpret_cast<const float4 *>(src + 4), a2 = *reinterpret_cast<const float4 *>(src + 8),
+                     a3 = *reinterpret_cast<const float4 *>(src + 12); // R.scratch and cap are multiples of 4
+              for (; i + 32 <= n; i += 16)
+              {
+                const float4 b0 = *reinterpret_cast<const float4 *>(src + i + 16), b1 = *reinterpret_cast<const float4 *>(src + i + 20),
+                             b2 = *reinterpret_cast<const float4 *>(src + i + 24), b3 = *reinterpret_cast<const float4 *>(src + i + 28);
+                s = s + a0.x; s = s + a0.y; s = s + a0.z; s = s + a0.w; s = s + a1.x; s = s + a1.y; s = s + a1.z; s = s + a1.w;
+                s = s + a2.x; s = s + a2.y; s = s + a2.z; s = s + a2.w; s = s + a3.x; s = s + a3.y; s = s + a3.z; s = s + a3.w;
+                a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+              }
+              s = s + a0.x; s = s + a0.y; s = s + a0.z; s = s + a0.w; s = s + a1.x; s = s + a1.y; s = s + a1.z; s = s + a1.w;
+              s = s + a2.x; s = s + a2.y; s = s + a2.z; s = s + a2.w; s = s + a3.x; s = s + a3.y; s = s + a3.z; s = s + a3.w;
+              i += 16;
+            }
             for (; i + 4 <= n; i += 4)
             {
-              const float4 v = *reinterpret_cast<const float4 *>(src + i); // R.scratch and cap are multiples of 4
+              const float4 v = *reinterpret_cast<const float4 *>(src + i);
               s = s + v.x; s = s + v.y; s = s + v.z; s = s + v.w;
             }
             for (; i < n; i++) s = s + src[i];
