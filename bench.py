@@ -73,6 +73,15 @@ def instruction_floor(pmc, algo_bytes):
     return round(algo_bytes / t / 1e9 / HBM_PEAK_GBPS, 4)
 
 
+def parse_size(text):
+    """`--size`: N (an N x N image) or WxH."""
+    text = str(text)
+    if "x" in text:
+        w, h = (int(v) for v in text.split("x"))
+        return w, h
+    return int(text), int(text)
+
+
 def workload_key(args, W, H):
     mode = "split" if args.split else "fused"
     return "%dx%d_%s_ef%d_%s%s%s%s" % (W, H, args.workload, args.error_factor, mode, "" if args.forced_shift < 0 else "_shift%d" % args.forced_shift,
@@ -593,14 +602,13 @@ def main():
     ap.add_argument("--share-gpus", action="store_true", help="rehearsal only: allow more ranks than GPUs (ranks share cards, gloo instead of RCCL)")
     ap.add_argument("--sub-images", type=int, default=0, help="--config 4: limg_hip_options.batch_sub_images -- the list as a pipeline of sub-batches of this many images "
                                                                  "(float stage of sub-batch k + 1 next to the persistent kernel of sub-batch k); 0 = the library's rule, -1 = off")
+    ap.add_argument("--graph", action="store_true", help="capture one encode into a HIP graph after the warm-up and time replays (launch-bound small images); kernel intervals "
+                                                      "are not available inside a graph: roofline.achieved then divides by the wall time per replay")
     ap.add_argument("--pipeline-knobs", type=lambda v: int(v, 0), default=0, help="A/B: limg_hip_options.test_pipeline")
     ap.add_argument("--wg-per-cu", type=int, default=0, help="A/B: limg_hip_options.test_wg_per_cu (workgroups per CU of the persistent kernel, 1..6)")
     ap.add_argument("--whole-image-ragged", action="store_true", help="A/B: height-ragged images through the whole-image ragged path (host walk over every dither call)")
     args = ap.parse_args()
-    if "x" in str(args.size):
-        args.width, args.height = (int(v) for v in str(args.size).split("x"))
-    else:
-        args.width = args.height = int(args.size)
+    args.width, args.height = parse_size(args.size)
     args.size = args.width  # (the square-size uses below: configs 4 / 5, cpu_baseline)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -691,13 +699,28 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    graph = None
+    if args.graph:
+        if ragged:
+            raise SystemExit("--graph: images with partial edge blocks take a host step inside the call (not capturable)")
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        for _ in range(args.warmup):
+            graph.replay()
+        torch.cuda.synchronize()
     g.profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        if graph is not None:
+            graph.replay()
+        else:
+            step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernels = g.profile_end(args.steps)
+    if graph is not None:  # one "interval" = the whole replay
+        kernels = np.array([[elapsed * 1e3 / args.steps, 0.0, 0.0]], dtype=np.float32)
     if dist is not None:
         dist.barrier()
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
@@ -788,7 +811,8 @@ def main():
                                         {"k_fit_search (lane == pixel float stage)": round(float(kavg[0]), 4), "shift words D2H + host chain walk over every dither call + noise H2D": round(float(kavg[1]), 4),
                                          "k_dither_store": round(float(kavg[2]), 4)} if ragged else
                                         {"k_fit_search": round(float(kavg[0]), 4), "k_strip_scan": round(float(kavg[1]), 4), "k_dither_store": round(float(kavg[2]), 4)}
-                                        if args.split else ({"k_encode_persistent": round(float(kavg[0]), 4)} if args.legacy_float_stage else
+                                        if args.split else {"HIP graph replay of one encode (k_fit_tpb + k_encode_persistent), wall": round(float(kavg[0]), 4)} if args.graph else
+                                        ({"k_encode_persistent": round(float(kavg[0]), 4)} if args.legacy_float_stage else
                                                             {"k_fit_tpb": round(float(kavg[0]), 4), "k_encode_persistent": round(float(kavg[1]), 4)})),
                          "valu": valu, "pmc_key": workload_key(args, W, H), "pmc_refused_stale_source": pmc_stale_source(workload_key(args, W, H)),
                          "instruction_floor": instruction_floor(pmc, bytes_per_px * px),
