@@ -21,6 +21,8 @@ namespace limg_hip
   uint64_t chain_call(uint64_t h, unsigned n, uint8_t *noise64, bool forceSoft, bool pcg);
   uint64_t fill_noise_table(uint64_t h, uint8_t *noise, size_t count, bool pcg);
   uint64_t chain_checkpoints(uint64_t h, size_t calls, size_t every, uint64_t *pOut, bool pcg);
+  size_t chain_walk_blocks(uint64_t h0, uint32_t blocksX, uint32_t blocksY, uint32_t stripsX, size_t sizeX, size_t sizeY, uint32_t chainCount, uint32_t chainRows, const uint32_t *shifts,
+                           uint32_t *stripBase, unsigned long long *states, uint8_t *pixels, size_t maxCalls, bool pcg);
 }
 
 using namespace limg_hip;
@@ -627,24 +629,7 @@ namespace
         }
       }
       const bool pcg = c->opt.dither_pcg != 0;
-      uint64_t h = h0;
-      size_t call = 0;
-      for (uint32_t by = 0; by < p.blocksY; by++)
-      {
-        if (by != 0 && chain_of_row(pt, by) != chain_of_row(pt, by - 1)) h = kDitherSeed;
-        const unsigned ry = (unsigned)((sizeY - (size_t)by * kBlock) < kBlock ? (sizeY - (size_t)by * kBlock) : kBlock);
-        for (uint32_t bx = 0; bx < p.blocksX; bx++)
-        {
-          if (bx % kStripBlocks == 0) hBase[(size_t)by * p.stripsX + bx / kStripBlocks] = (uint32_t)call;
-          const unsigned rx = (unsigned)((sizeX - (size_t)bx * kBlock) < kBlock ? (sizeX - (size_t)bx * kBlock) : kBlock);
-          const uint32_t calls = hShifts[(size_t)by * p.blocksX + bx] >> 24;
-          for (uint32_t k = 0; k < calls && call < maxCalls; k++, call++)
-          {
-            hStates[call] = h; hPixels[call] = (uint8_t)(rx * ry);
-            h = chain_call(h, rx * ry, nullptr, false, pcg);
-          }
-        }
-      }
+      const size_t call = chain_walk_blocks(h0, p.blocksX, p.blocksY, p.stripsX, sizeX, sizeY, pt.chainCount, pt.chainRows, hShifts, hBase, hStates, hPixels, maxCalls, pcg);
       const size_t totalCalls = call;
       if ((r = c->noiseDyn.ensure((totalCalls + 1) * 64)) != limg_hip_success) return r;
       if ((r = c->noiseStates.ensure(totalCalls * 9 + 16)) != limg_hip_success) return r;
@@ -1527,16 +1512,8 @@ extern "C"
             // 1-3 wrote the bytes here and uploaded them: 200 MB per 8192^2 image through this thread's store buffers and over PCIe.)
             const size_t call0 = callCount;
             if (ok)
-              for (size_t i = pending.r0; i < pending.r1; i++)
-              {
-                noiseBase[i] = noiseOff;
-                const uint32_t calls = hOut[i].shiftWord >> 24;
-                for (uint32_t k = 0; k < calls && callCount < maxCalls; k++, noiseOff += npx[i], callCount++)
-                {
-                  callState[callCount] = chain; callOff[callCount] = noiseOff; callPx[callCount] = npx[i];
-                  chain = chain_call_n(chain, npx[i], nullptr, pcg);
-                }
-              }
+              chain = chain_walk_batch(chain, pending.r1 - pending.r0, reinterpret_cast<const uint8_t *>(&hOut[pending.r0].shiftWord), sizeof(RegionOut), npx.data() + pending.r0,
+                                       noiseBase + pending.r0, callState, callOff, callPx, noiseOff, callCount, maxCalls, pcg);
             const clk::time_point w2 = clk::now();
             const BlockedParams q = params_of(pending);
             const size_t nc = callCount - call0;

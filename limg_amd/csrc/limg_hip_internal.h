@@ -166,6 +166,8 @@ namespace limg_hip
                      const std::function<void(size_t)> *progress = nullptr, const std::function<void(uint32_t)> *needSeedRow = nullptr, const uint8_t *seedFlags = nullptr);
   bool blocked_matches_host(int channels, const limg_hip_block_record &seed, const limg_hip_block_record &cand);
   uint64_t chain_call_n(uint64_t h, size_t n, uint8_t *noise, bool pcg);
+  uint64_t chain_walk_batch(uint64_t h, size_t count, const uint8_t *shiftWords, size_t stride, const uint32_t *npx, unsigned long long *noiseBase, unsigned long long *callState,
+                            unsigned long long *callOff, uint32_t *callPx, uint64_t &noiseOff, size_t &callCount, size_t maxCalls, bool pcg); // limg_hip_noise.cpp
 
   void launch_stream_pack(const StreamParams &p, hipStream_t s);
   void launch_stream_decode(const DecodeParams &p, hipStream_t s);

@@ -169,6 +169,119 @@ namespace limg_hip
     return h;
   }
 
+  // The merged-block encoder's chain walk for one batch of rectangles, in creation order (src/limg.cpp:1541-1551 calls limg_encode_dither once per dithered
+  // factor of a rectangle, :824-879): per dither call the value it starts from, where its noise bytes go and its pixel count are recorded (the device re-runs the
+  // rounds: k_noise_expand_calls) and the chain moves on by G_N.  One function so that the AESDEC rounds sit inline in the loop: the walk is a single dependent chain
+  // (~4 cycles per round), and a call per dither call -- set-up of {h, ~h}, dispatch on the CPU's features, the PCG tail's loop -- cost a third of it on rectangles
+  // of a few blocks.  shiftWords: the rectangles' result words, `stride` bytes apart, dither calls in bits 24..31.
+#if defined(__x86_64__)
+  __attribute__((target("aes,sse4.1"))) static uint64_t walk_batch_aesni(uint64_t h, size_t count, const uint8_t *shiftWords, size_t stride, const uint32_t *npx,
+                                                                        unsigned long long *noiseBase, unsigned long long *callState, unsigned long long *callOff,
+                                                                        uint32_t *callPx, uint64_t &noiseOff, size_t &callCount, size_t maxCalls)
+  {
+    const __m128i key = _mm_set_epi64x(0x2A76E98006CB4CADLL, (long long)0x824A73EAAB705E1DULL);
+    for (size_t i = 0; i < count; i++)
+    {
+      noiseBase[i] = noiseOff;
+      uint32_t word;
+      memcpy(&word, shiftWords + i * stride, 4);
+      const uint32_t calls = word >> 24, n = npx[i], rounds = n >= 8 ? n / 8 : 0, tail = n - rounds * 8;
+      for (uint32_t k = 0; k < calls && callCount < maxCalls; k++, noiseOff += n, callCount++)
+      {
+        callState[callCount] = h; callOff[callCount] = noiseOff; callPx[callCount] = n;
+        if (rounds)
+        {
+          __m128i st = _mm_set_epi64x((long long)~h, (long long)h);
+          for (uint32_t j = 0; j < rounds; j++) st = _mm_aesdec_si128(st, key);
+          h = (uint64_t)_mm_cvtsi128_si64(st);
+        }
+        for (uint32_t j = 0; j < tail; j++) (void)pcg_step(h);
+      }
+    }
+    return h;
+  }
+#endif
+
+  // The 8x8 path's chain walk over an image with partial edge blocks (limg_hip_api.hip: the whole image, or the last block row of an image whose width is whole
+  // blocks), raster order, chains restarting at the strip partition's boundaries (src/limg.cpp:2114-2134): same recording as above, per dither call the value it starts
+  // from and its pixel count; per work strip (32 blocks) the index of its first call.  Template on the AES-NI use so that the rounds are inline in the hot variant.
+  namespace
+  {
+    template <bool NI>
+#if defined(__x86_64__)
+    __attribute__((target("aes,sse4.1")))
+#endif
+    size_t walk_blocks_impl(uint64_t h0, uint32_t blocksX, uint32_t blocksY, uint32_t stripsX, size_t sizeX, size_t sizeY, uint32_t chainCount, uint32_t chainRows,
+                            const uint32_t *shifts, uint32_t *stripBase, unsigned long long *states, uint8_t *pixels, size_t maxCalls, bool pcg)
+    {
+#if defined(__x86_64__)
+      const __m128i key = _mm_set_epi64x(0x2A76E98006CB4CADLL, (long long)0x824A73EAAB705E1DULL);
+#endif
+      auto chain_of = [&](uint32_t row) -> uint32_t { if (chainCount <= 1 || chainRows == 0) return 0u; const uint32_t c = row / chainRows; return c < chainCount - 1 ? c : chainCount - 1; };
+      uint64_t h = h0;
+      size_t call = 0;
+      for (uint32_t by = 0; by < blocksY; by++)
+      {
+        if (by != 0 && chain_of(by) != chain_of(by - 1)) h = 0xCA7F00D15BADF00DULL; // src/limg.cpp:1893
+        const unsigned ry = (unsigned)((sizeY - (size_t)by * 8) < 8 ? (sizeY - (size_t)by * 8) : 8);
+        for (uint32_t bx = 0; bx < blocksX; bx++)
+        {
+          if (bx % 32u == 0) stripBase[(size_t)by * stripsX + bx / 32u] = (uint32_t)call;
+          const unsigned rx = (unsigned)((sizeX - (size_t)bx * 8) < 8 ? (sizeX - (size_t)bx * 8) : 8);
+          const uint32_t n = rx * ry, calls = shifts[(size_t)by * blocksX + bx] >> 24, rounds = (!pcg && n >= 8) ? n / 8 : 0, tail = n - rounds * 8;
+          for (uint32_t k = 0; k < calls && call < maxCalls; k++, call++)
+          {
+            states[call] = h; pixels[call] = (uint8_t)n;
+            if (NI)
+            {
+#if defined(__x86_64__)
+              if (rounds)
+              {
+                __m128i st = _mm_set_epi64x((long long)~h, (long long)h);
+                for (uint32_t j = 0; j < rounds; j++) st = _mm_aesdec_si128(st, key);
+                h = (uint64_t)_mm_cvtsi128_si64(st);
+              }
+              for (uint32_t j = 0; j < tail; j++) (void)pcg_step(h);
+#endif
+            }
+            else h = chain_call(h, n, nullptr, false, pcg);
+          }
+        }
+      }
+      return call;
+    }
+  }
+
+  size_t chain_walk_blocks(uint64_t h0, uint32_t blocksX, uint32_t blocksY, uint32_t stripsX, size_t sizeX, size_t sizeY, uint32_t chainCount, uint32_t chainRows, const uint32_t *shifts,
+                           uint32_t *stripBase, unsigned long long *states, uint8_t *pixels, size_t maxCalls, bool pcg)
+  {
+#if defined(__x86_64__)
+    if (!pcg && have_aesni()) return walk_blocks_impl<true>(h0, blocksX, blocksY, stripsX, sizeX, sizeY, chainCount, chainRows, shifts, stripBase, states, pixels, maxCalls, pcg);
+#endif
+    return walk_blocks_impl<false>(h0, blocksX, blocksY, stripsX, sizeX, sizeY, chainCount, chainRows, shifts, stripBase, states, pixels, maxCalls, pcg);
+  }
+
+  uint64_t chain_walk_batch(uint64_t h, size_t count, const uint8_t *shiftWords, size_t stride, const uint32_t *npx, unsigned long long *noiseBase, unsigned long long *callState,
+                            unsigned long long *callOff, uint32_t *callPx, uint64_t &noiseOff, size_t &callCount, size_t maxCalls, bool pcg)
+  {
+#if defined(__x86_64__)
+    if (!pcg && have_aesni()) return walk_batch_aesni(h, count, shiftWords, stride, npx, noiseBase, callState, callOff, callPx, noiseOff, callCount, maxCalls);
+#endif
+    for (size_t i = 0; i < count; i++)
+    {
+      noiseBase[i] = noiseOff;
+      uint32_t word;
+      memcpy(&word, shiftWords + i * stride, 4);
+      const uint32_t calls = word >> 24;
+      for (uint32_t k = 0; k < calls && callCount < maxCalls; k++, noiseOff += npx[i], callCount++)
+      {
+        callState[callCount] = h; callOff[callCount] = noiseOff; callPx[callCount] = npx[i];
+        h = chain_call(h, npx[i], nullptr, false, pcg);
+      }
+    }
+    return h;
+  }
+
   // Chain values of a chain of full-block calls: pOut[i] = the value call number i * every starts from (pOut[0] = h), for i * every < calls.  Returns the value
   // after `calls` calls.  (Generator and checker of limg_noise_checkpoints.h.)
   uint64_t chain_checkpoints(uint64_t h, size_t calls, size_t every, uint64_t *pOut, bool pcg)
