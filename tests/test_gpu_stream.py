@@ -29,6 +29,11 @@ def _cases(oracle):
     yield "pn_ef0", oracle.photo_noise(64, 24, 11), True, {"error_factor": 0}
     yield "pn_pool", oracle.photo_noise(128, 256, 13), True, {"pool_threads": 2}
     yield "tiles", oracle.photo_noise(8 * 300, 16, 17), True, {}   # 600 blocks: more than two 256-block tiles, tile edge inside a block row
+    # width in whole blocks, last block row partial: in the `fused` mode the rows above the last run through the persistent kernel in compact mode and the last row
+    # through the split path (limg_hip_api.hip encode_height_ragged), both writing one set of records / shift words for the packer
+    yield "pn_height_ragged", oracle.photo_noise(256, 61, 19), True, {}
+    yield "rga_height_ragged_pool", oracle.random_gradient(512, 100, 19, False), True, {"pool_threads": 1}
+    yield "pn_height_ragged_rgb", oracle.photo_noise(1024, 301, 23), False, {}
 
 
 def test_stream_bytes_and_roundtrip(gpu, oracle):
