@@ -479,6 +479,7 @@ namespace
       p.ticket = (uint32_t *)c->lookback.p;
       p.desc = (unsigned long long *)((uint8_t *)c->lookback.p + 16);
       p.zeroLookback = p.prefit ? 1 : 0;
+      p.ticketStart = 0; // (set per launch below, where the workgroup count is known)
       if (!p.prefit) HIP_TRY(hipMemsetAsync(c->lookback.p, 0, 16 + strips * 8, stream));
       if (!c->devStatus.p)
       {
@@ -526,6 +527,8 @@ namespace
         uint8_t *lb = (uint8_t *)c->lookback.p + k * 16 + i0 * imgStrips * 8; // sub-batch k: its ticket, then the descriptors of its strips
         q.ticket = (uint32_t *)lb; q.desc = (unsigned long long *)(lb + 16);
         q.fitPrio = k == 0 ? 0 : fitPrio;
+        const size_t wgs = (size_t)(c->persistentWorkgroups / 5 * (k + 1 < nSub ? wgOverlap : wg_per_cu(6))), stripsK = n * imgStrips;
+        q.ticketStart = (uint32_t)(stripsK < wgs ? stripsK : wgs); // = the grid launch_encode_persistent gives this sub-batch
         return q;
       };
       hipStream_t fs = c->fitStream;
@@ -553,6 +556,11 @@ namespace
       return stats();
     }
 
+    if (fused && p.prefit)
+    { // the ticket starts at the persistent launch's workgroup count (k_fit_tpb writes it): workgroup i takes strip i without an atomic
+      const size_t wgs = (size_t)(c->persistentWorkgroups / 5 * wg_per_cu(6));
+      p.ticketStart = (uint32_t)(strips < wgs ? strips : wgs);
+    }
     if (p.prefit && chainPhase != 2)
     {
       mark_if(1);

@@ -59,6 +59,7 @@ namespace limg_hip
     unsigned long long *desc;
     uint32_t *ticket;   // [0] = next strip id
     int32_t zeroLookback; // k_fit_tpb clears `ticket` (16 bytes) and the descriptors of the strips its waves cover (the persistent launch follows it on the stream)
+    uint32_t ticketStart; // ... and starts the ticket at this value: the persistent launch's workgroup count -- workgroup i takes strip i without asking (one atomic round trip less per workgroup); 0: every ticket is drawn
     uint32_t *timeout;  // sticky: set when a look-back spin gave up; lives outside the per-launch words, cleared only by limg_hip_check_device_status
     uint8_t *park;      // persistent kernel: per workgroup two 8 KiB slots holding a strip's parked results between its E and F steps
     int32_t compactOut; // persistent kernel: also write records / shift words to the raster-order arrays

@@ -32,6 +32,8 @@
 //     chains at once instead of a 64-step dependent chain per block;
 //   * correctly rounded division (hipcc default), once per batch and lane-parallel; round-to-nearest-even conversions.
 #include "limg_hip_device.h"
+#include <stdio.h>
+#include <stdlib.h>
 #include "limg_search_table.h"
 
 #include <type_traits>
@@ -969,6 +971,22 @@ namespace limg_hip
       const uint32_t stripW = min(p.sizeX - x0, (uint32_t)(kStripBlocks * kBlock)); // pixels
       const uint32_t ry = min(p.sizeY - y0, (uint32_t)kBlock);
 
+      // PREFIT: the records of the wave's 8 blocks as k_fit_tpb left them (16 dwords per block: avg, then the 24 int16; 16 lanes per block) are REQUESTED here, next to
+      // the strip's pixels, and used behind the barrier below: one memory round trip per strip instead of two.  Round 4, same-box A/B (tools/r04/run19.sh): persistent
+      // kernel 1.079-1.085 -> 1.054-1.059 ms on 8192^2 photo-noise, config 4 15.01-15.13 -> 14.46-14.65 ms.  (The same idea for the F step -- the strip's own look-back
+      // descriptor and the first window requested before the parked data -- costs 4 spilled registers and was measured 0.5-1 % slower: not kept.)
+      uint32_t recVal[2] = { 0u, 0u };
+      if (PREFIT)
+      {
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+        {
+          const int b = r * 4 + (lane >> 4), w = lane & 15;
+          const uint32_t bx = strip * kStripBlocks + wave * kBlocksPerWave + b;
+          if (bx < p.blocksX) recVal[r] = w >= 4 ? reinterpret_cast<const uint32_t *>(p.records + (size_t)byS * p.blocksX + bx)[w] // (the averages in words 0..3 are not needed here)
+                                                 : reinterpret_cast<const uint32_t *>(p.invN)[((size_t)byS * p.blocksX + bx) * 4 + w];      // 1 / |n|^2 of A, B, C from k_fit_tpb
+        }
+      }
       // ---- stage: the strip's pixel rows into LDS (the rsqrt table is loaded by the caller) ----------------------------
       if (p.vecIn)
       {
@@ -1008,15 +1026,13 @@ namespace limg_hip
 
       if (PREFIT)
       {
-        // records of the wave's 8 blocks as k_fit_tpb left them (16 dwords per block: avg, then the 24 int16); 16 lanes per block
+        // the records requested above: into the phase-E view, the park slot, and the range flags
 #pragma unroll
         for (int r = 0; r < 2; r++)
         {
           const int b = r * 4 + (lane >> 4), w = lane & 15;
           const uint32_t sb = wave * kBlocksPerWave + b, bx = strip * kStripBlocks + sb;
-          uint32_t val = 0;
-          if (bx < p.blocksX) val = w >= 4 ? reinterpret_cast<const uint32_t *>(p.records + (size_t)byS * p.blocksX + bx)[w] // (the averages in words 0..3 are not needed here)
-                                           : reinterpret_cast<const uint32_t *>(p.invN)[((size_t)byS * p.blocksX + bx) * 4 + w];      // 1 / |n|^2 of A, B, C from k_fit_tpb
+          const uint32_t val = recVal[r];
           if (w < 3) reinterpret_cast<BlkE *>(&blk[b])->invN[w] = __uint_as_float(val); // its place in the phase-E view (nothing else of the float-stage fields is live with PREFIT)
           if (w >= 4)
           {
@@ -1702,12 +1718,17 @@ namespace limg_hip
       // by slot, so slot k (= blockIdx.x / 256) starts k * 3.4 us late: measured -0.5 % on the kernel, and harmless where the placement differs.
       for (uint32_t i = 0; i < (blockIdx.x >> 8); i++) __builtin_amdgcn_s_sleep(127);
       __builtin_amdgcn_s_setprio(LIMG_PRIO_E);
+      bool first = kargs->ticketStart != 0u; // the ticket counter starts at the grid size: workgroup i's first strip is strip i, no atomic needed
       for (;;)
       {
         __syncthreads(); // the previous step's LDS use is over (and the rsqrt table is in place)
-        if (tid == 0) s_ticket = atomicAdd(p.ticket, 1u);
-        __syncthreads();
-        const uint32_t t = (uint32_t)sgpr((int)s_ticket);
+        if (!first)
+        {
+          if (tid == 0) s_ticket = atomicAdd(p.ticket, 1u);
+          __syncthreads();
+        }
+        const uint32_t t = first ? blockIdx.x : (uint32_t)sgpr((int)s_ticket);
+        first = false;
         int tid_e = tid;
         asm volatile("" : "+v"(tid_e));
         KernArgs *pe = kargs;
@@ -1774,6 +1795,11 @@ namespace limg_hip
   {
     const uint32_t strips = p.imageStrips * p.batchCount;
     const dim3 grid(strips < (uint32_t)workgroups ? strips : (uint32_t)workgroups), block(kThreads);
+    if (p.ticketStart != 0u && p.ticketStart != grid.x)
+    { // internal invariant (the host computes both from the same numbers): a ticket that does not start at the grid size would skip or repeat strips
+      fprintf(stderr, "limg_hip: ticket start %u != persistent grid %u\n", p.ticketStart, grid.x);
+      abort();
+    }
     LIMG_DISPATCH(k_encode_persistent, grid, block, s, p);
   }
 
