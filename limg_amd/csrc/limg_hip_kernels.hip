@@ -396,7 +396,9 @@ namespace limg_hip
     // the 7 block-uniform planes, straight from registers: 16 bytes per lane = four rows of 256 contiguous bytes (8 blocks x 8 px) per store instruction where
     // the rows allow it (p.vecPlanes: width a multiple of 4, 16-byte aligned planes), 4 bytes per lane = one row per instruction otherwise
     template <class P, class IO>
-    __device__ __forceinline__ void phase_f_store_const(const P &p, const IO &io, const StripLds &L, uint32_t x0, uint32_t y0, uint32_t ry, int lane, int wave)
+    // halves: bit 0 = the strip's rows 0..3, bit 1 = rows 4..7 (the F step issues them at two different points, each beside a memory round trip of its own; the
+    // one-row-per-instruction form stores everything with bit 0)
+    __device__ __forceinline__ void phase_f_store_const(const P &p, const IO &io, const StripLds &L, uint32_t x0, uint32_t y0, uint32_t ry, int lane, int wave, const uint32_t halves = 3u)
     {
       const uint32_t wx0 = x0 + wave * 64;
       if (wx0 >= p.sizeX) return;
@@ -411,7 +413,7 @@ namespace limg_hip
           for (uint32_t half = 0; half < 2; half++)
           {
             const uint32_t row = half * 4 + rsub;
-            if (row < ry)
+            if (row < ry && ((halves >> half) & 1u))
             {
               size_t g = (size_t)(y0 + row) * p.sizeX + wx0 + col;
               asm volatile("" : "+v"(g)); // one offset for the seven planes (left to itself the compiler adds its three loop-invariant parts to every plane's base separately)
@@ -421,6 +423,7 @@ namespace limg_hip
           }
         return;
       }
+      if (!(halves & 1u)) return;
       uint32_t cst[7];
 #pragma unroll
       for (int k = 0; k < 7; k++) cst[k] = L.cst[(k * kStripBlocks + wave * kBlocksPerWave + (lane >> 3)) * 4];
@@ -508,8 +511,11 @@ namespace limg_hip
       __builtin_amdgcn_sched_barrier(0);
     }
 
-    template <int CH, class P, class IO>
-    __device__ __forceinline__ void phase_f_rows(const P &p, const IO &io, const StripLds &L, const uint32_t strip, const uint32_t x0, const uint32_t y0, const int lane, const int wave)
+    // `between`: work that does not depend on the noise bytes (the seven uniform planes' stores: 28 of the 35 output bytes per pixel), run right after the noise
+    // loads are issued -- their round trip to HBM (the table is 200 MB: no cache holds it) then runs beside those stores instead of in front of the decode
+    template <int CH, class P, class IO, class BETWEEN>
+    __device__ __forceinline__ void phase_f_rows(const P &p, const IO &io, const StripLds &L, const uint32_t strip, const uint32_t x0, const uint32_t y0, const int lane, const int wave,
+                                                 BETWEEN &&between)
     {
       const uint32_t j = (uint32_t)lane & 7u, r = (uint32_t)lane >> 3;
       const uint32_t sb = (uint32_t)wave * kBlocksPerWave + j, bx = strip * kStripBlocks + sb;
@@ -530,6 +536,7 @@ namespace limg_hip
           call++;
         }
       }
+      between();
       const uint8_t *facRow = L.fac + r * kFacRow + sb * kBlock;
       const int *nm = L.nm + sb * 24;
 #ifdef LIMG_X_NOGEN
@@ -1630,7 +1637,11 @@ namespace limg_hip
       __syncthreads();
       phase_f_prepare<CH>(L, lane, wave, p.recordLimit);
       wave_lds_fence();
-      if (p.fullPlanes) phase_f_store_const(p, io, L, x0, y0, ry, lane, wave); // base-independent: 28 of the 35 output bytes per pixel
+      // strips of whole blocks (always in the persistent kernel; in the split path unless the image has partial edge blocks): the uniform planes' stores run inside
+      // phase_f_rows, behind its noise loads; otherwise here
+      const bool rowsPath = PERSIST || (p.sizeX % kBlock == 0 && ry == (uint32_t)kBlock);
+      // the uniform planes (base-independent: 28 of the 35 output bytes per pixel): rows 0..3 here, beside wave 0's look-back; rows 4..7 behind the noise loads
+      if (p.fullPlanes) phase_f_store_const(p, io, L, x0, y0, ry, lane, wave, rowsPath ? 1u : 3u);
       if (wave == 0)
       {
         uint32_t base;
@@ -1661,8 +1672,7 @@ namespace limg_hip
         phase_f_first_calls(L, base, lane);
       }
       __syncthreads();
-      // strips of whole blocks (always in the persistent kernel; in the split path unless the image has partial edge blocks)
-      if (PERSIST || (p.sizeX % kBlock == 0 && ry == (uint32_t)kBlock)) phase_f_rows<CH>(p, io, L, strip, x0, y0, lane, wave);
+      if (rowsPath) phase_f_rows<CH>(p, io, L, strip, x0, y0, lane, wave, [&]() { if (p.fullPlanes) phase_f_store_const(p, io, L, x0, y0, ry, lane, wave, 2u); });
       else phase_f_pixels<CH>(p, io, L, strip, x0, y0, ry, lane, wave, tid);
     }
 
