@@ -372,6 +372,28 @@ static void thresholds(uint32_t ef, size_t *maxPixel, size_t *maxBlock)
   *maxBlock = (size_t)0x4 * (ef / 2) * 7;
 }
 
+/* statistics helper (tools/trial_early_exit.py): the per-pixel error of one trial for EVERY pixel, i.e. trial_core without its early return */
+void limg_oracle_block_trial_pixel_errors(const uint32_t *px, size_t n, int channels, const limg_oracle_record *rec, const uint8_t *A, const uint8_t *B, const uint8_t *C,
+                                          const uint8_t shift[3], uint32_t *pErr)
+{
+  recon_consts k;
+  recon_setup(rec, channels, shift, 0, &k);
+  for (size_t i = 0; i < n; i++)
+  {
+    const uint32_t dA = (uint32_t)(A[i] >> shift[0]) * k.mul[0];
+    const uint32_t dB = (uint32_t)(B[i] >> shift[1]) * k.mul[1];
+    const uint32_t dC = (uint32_t)(C[i] >> shift[2]) * k.mul[2];
+    uint32_t dsq[3];
+    for (int c = 0; c < 3; c++)
+    {
+      const int32_t d = (int32_t)((px[i] >> (8 * c)) & 0xFF) - recon_channel(&k, c, dA, dB, dC);
+      dsq[c] = (uint32_t)(d * d);
+    }
+    const int low_red = (int32_t)dsq[0] < 0x4000;
+    pErr[i] = dsq[0] * (low_red ? 2u : 3u) + dsq[2] * (low_red ? 3u : 2u) + dsq[1] * 4u;
+  }
+}
+
 int limg_oracle_block_trial(const uint32_t *px, size_t n, int channels, const limg_oracle_record *rec, const uint8_t *A, const uint8_t *B, const uint8_t *C,
                             const uint8_t shift[3], uint32_t error_factor, uint64_t *pBlockError)
 {
