@@ -219,6 +219,10 @@ limg_hip_result limg_hip_blocked_regions(limg_hip_context *pCtx, limg_hip_region
  * overlapped with [1] on a worker thread, summed over its batches -- [2] per-rectangle fit + search (GPU, incl. copies), [3] dither chain walk (host),
  * [4] noise upload + dither/decode/store launch; [5] wall-clock total. */
 limg_hip_result limg_hip_blocked_timing(limg_hip_context *pCtx, double *pMs6);
+/* GPU time of the last merged-block encode's launches, from HIP events on the streams they run on: [0] pass 1 (the 8x8 path's float stage), [1] the similarity
+ * kernels (16 bands, back to back), and summed over the worker's batches [2] the per-rectangle fit + search kernel, [3] chain-value upload + noise expansion +
+ * dither/decode/store kernel.  (What the GPU side costs with no host in the way: bench.py's kernel-only rate of the merged-block encoder.) */
+limg_hip_result limg_hip_blocked_kernel_timing(limg_hip_context *pCtx, double *pMs4);
 /* Host-only (no GPU touched): the block-similarity predicate `limg_encode_3d_matches` (src/limg.cpp:1137-1268) as the host merge evaluates it
  * for candidates outside the precomputed window; records in `limg_hip_block_record` layout. */
 int limg_hip_host_blocked_matches(int channels, const limg_hip_block_record *pSeed, const limg_hip_block_record *pCandidate);

@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     "limg_hip_host_noise_table", "limg_hip_noise_table_device", "limg_hip_host_chain_call", "limg_hip_host_chain_checkpoints", "limg_hip_host_partition", "limg_hip_check_device_status",
     "limg_hip_stream_bound", "limg_hip_encode_stream_device", "limg_hip_decode_stream_device", "limg_hip_encode_stream", "limg_hip_decode_stream",
     "limg_hip_stream_info",
-    "limg_hip_blocked_encode3d", "limg_hip_blocked_encode3d_device", "limg_hip_blocked_regions", "limg_hip_blocked_timing", "limg_hip_host_blocked_matches",
+    "limg_hip_blocked_encode3d", "limg_hip_blocked_encode3d_device", "limg_hip_blocked_regions", "limg_hip_blocked_timing", "limg_hip_blocked_kernel_timing", "limg_hip_host_blocked_matches",
     "limg_hip_host_blocked_merge", "limg_hip_host_blocked_match_words", "limg_hip_host_blocked_match_bits",
     "limg_hip_comm_unique_id", "limg_hip_comm_init", "limg_hip_comm_destroy", "limg_hip_comm_info", "limg_hip_gather_stream", "limg_hip_encode3d_single_chain_device",
     "limg_hip_encode3d_chain_device", "limg_hip_host_gather_offsets", "limg_hip_host_chain_bases",
@@ -134,6 +134,8 @@ def load_library(path=None):
     L.limg_hip_blocked_regions.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.limg_hip_blocked_timing.restype = C.c_int
     L.limg_hip_blocked_timing.argtypes = [C.c_void_p, C.c_void_p]
+    L.limg_hip_blocked_kernel_timing.restype = C.c_int
+    L.limg_hip_blocked_kernel_timing.argtypes = [C.c_void_p, C.c_void_p]
     L.limg_hip_host_blocked_matches.restype = C.c_int
     L.limg_hip_host_blocked_matches.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
     L.limg_hip_host_blocked_merge.restype = C.c_int
@@ -411,6 +413,13 @@ class LimgHip:
         ms = np.zeros(6, dtype=np.float64)
         _check(self.lib.limg_hip_blocked_timing(self.ctx, _np_ptr(ms)), "limg_hip_blocked_timing")
         return dict(zip(("pass1_match_gpu", "merge_host", "fit_search_gpu", "chain_host", "store_gpu", "total"), ms.tolist()))
+
+    def blocked_kernel_timing(self):
+        """GPU milliseconds (HIP events) of the last merged-block encode's launches: pass 1, similarity kernels, and -- summed over the worker's batches -- the
+        per-rectangle fit + search kernel and the expansion + store kernels."""
+        ms = np.zeros(4, dtype=np.float64)
+        _check(self.lib.limg_hip_blocked_kernel_timing(self.ctx, _np_ptr(ms)), "limg_hip_blocked_kernel_timing")
+        return dict(zip(("pass1_kernel", "match_kernels", "fit_search_kernel", "expand_store_kernels"), ms.tolist()))
 
     # ---- compact stream ("limg_encode" / "limg_decode") ----------------------------------------------------------------------------
     def stream_bound(self, w, h):

@@ -119,6 +119,10 @@ struct limg_hip_context
   std::vector<hipEvent_t> bandEvents;
   std::vector<HostRegion> lastRegions;
   double blockedMs[6] = { 0, 0, 0, 0, 0, 0 };
+  double blockedKernelMs[4] = { 0, 0, 0, 0 }; // the last merged-block encode, HIP events: pass 1 (k_fit_tpb) / the k_blocked_match launches / the k_blocked_fit_search launches /
+                                             // the noise-expansion + store launches (the last two summed over the worker's batches)
+  std::vector<hipEvent_t> workTimers;        // [4 i .. 4 i + 3]: begin / end of batch slot i's fit + search kernel, begin / end of its expansion + store kernels;
+                                             // [4 kInFlight ..]: begin of pass 1, end of pass 1 = begin of the similarity kernels, their end
   // multi-GPU (RCCL over xGMI): one communicator per context, created by limg_hip_comm_init
   ncclComm_t comm = nullptr;
   int commRank = 0, commWorld = 1;
@@ -678,9 +682,11 @@ namespace
     // the last block row
     limg_hip_encode3d_info low = *dInfo;
     {
-      void **pp = reinterpret_cast<void **>(&low);
-      for (int i = 0; i < 8; i++) if (pp[i]) pp[i] = (uint32_t *)pp[i] + topY * sizeX;
-      for (int i = 8; i < 11; i++) pp[i] = (uint8_t *)pp[i] + topY * sizeX;
+      const size_t skip = topY * sizeX; // pixels above the last block row, in every plane
+      uint32_t **words[] = { &low.pDecoded, &low.pShiftABCX, &low.pColAMin, &low.pColAMax, &low.pColBMin, &low.pColBMax, &low.pColCMin, &low.pColCMax };
+      uint8_t **bytes[] = { &low.pFactorsA, &low.pFactorsB, &low.pFactorsC };
+      for (uint32_t **p : words) if (*p) *p += skip;
+      for (uint8_t **p : bytes) if (*p) *p += skip;
     }
     EncodeExtra xb;
     xb.streamRaw = x.streamRaw; xb.inner = true; xb.marks = 0; xb.scratchRow0 = blocksY - 1; xb.scratchRows = blocksY;
@@ -758,6 +764,7 @@ extern "C"
     for (hipStream_t st : c->workStreams) (void)hipStreamDestroy(st);
     c->bCalls.release();
     for (hipEvent_t e : c->workEvents) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->workTimers) (void)hipEventDestroy(e);
     if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
     for (hipEvent_t e : c->bandEvents) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
@@ -1321,9 +1328,19 @@ extern "C"
     const size_t blocks = (size_t)blocksX * blocksY;
     limg_hip_result r;
 
+    constexpr size_t kInFlight = 32; // batches of the worker (below) whose fit + search kernel has been enqueued and whose chain has not been walked yet
+    while (c->workTimers.size() < 4 * kInFlight + 3)
+    {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreate(&e));
+      c->workTimers.push_back(e);
+    }
+    hipEvent_t *frontTimers = c->workTimers.data() + 4 * kInFlight;
+
     // pass 1 (src/limg.cpp:1088-1119): every block's own fit = the 8x8 path's E step, records only
     EncodeExtra x1;
     x1.fitOnly = true;
+    HIP_TRY(hipEventRecord(frontTimers[0], s));
     if ((r = encode_device(c, pIn, sizeX, sizeY, hasAlpha, nullptr, nullptr, errorFactor, 0, fastBitCrushing, s, x1)) != limg_hip_success) return r;
 
     BlockedParams bp;
@@ -1361,6 +1378,7 @@ extern "C"
     }
     hipStream_t cs = c->copyStream;
     hipEvent_t evPass1 = c->bandEvents[2 * kBands];
+    HIP_TRY(hipEventRecord(frontTimers[1], s));
     HIP_TRY(hipEventRecord(evPass1, s));
     HIP_TRY(hipStreamWaitEvent(cs, evPass1, 0));
     HIP_TRY(hipMemcpyAsync(hRec, c->records.p, blocks * sizeof(limg_hip_block_record), hipMemcpyDeviceToHost, cs));
@@ -1378,6 +1396,7 @@ extern "C"
       HIP_TRY(hipMemcpyAsync(hFlags + bp.seedBase, (uint8_t *)c->bFlags.p + bp.seedBase, bp.seedCount, hipMemcpyDeviceToHost, cs));
       HIP_TRY(hipEventRecord(c->bandEvents[2 * b + 1], cs));
     }
+    HIP_TRY(hipEventRecord(frontTimers[2], s)); // (`s` holds nothing but the similarity kernels between the two timers: the copies run on `cs`)
     HIP_TRY(hipEventSynchronize(evPass1));
     const clk::time_point t1 = clk::now();
     uint32_t bandsReady = 0;
@@ -1443,13 +1462,15 @@ extern "C"
     if (!c->storeStream) HIP_TRY(hipStreamCreateWithFlags(&c->storeStream, hipStreamNonBlocking));
     hipStream_t ss = c->storeStream; // noise expansion + store kernels of a batch: beside the next batch's fit + search kernel, not behind it
 
-    constexpr size_t kInFlight = 32; // batches whose fit + search kernel has been enqueued and whose chain has not been walked yet
     while (c->workEvents.size() < kInFlight)
     {
       hipEvent_t e;
       HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       c->workEvents.push_back(e);
     }
+
+    double kernelMs[2] = { 0, 0 };
+    std::vector<uint8_t> storeTimed(kInFlight, 0); // slot i's store timers hold a finished-or-enqueued interval that has not been added up yet
 
     double dbgEnqueue = 0, dbgWait = 0; int dbgBatches = 0;
     std::thread worker([&]() {
@@ -1489,13 +1510,21 @@ extern "C"
           {
             dbgBatches++;
             Batch nb; nb.r0 = r0; nb.r1 = r1; nb.ev = evNext; evNext = (evNext + 1) % kInFlight;
+            if (storeTimed[nb.ev])
+            { // the slot comes round again: its previous batch's store kernels were enqueued kInFlight batches ago
+              float t = 0;
+              if (hipEventSynchronize(c->workTimers[4 * nb.ev + 3]) == hipSuccess && hipEventElapsedTime(&t, c->workTimers[4 * nb.ev + 2], c->workTimers[4 * nb.ev + 3]) == hipSuccess) kernelMs[1] += t;
+              storeTimed[nb.ev] = 0;
+            }
             if (workerResult == limg_hip_success)
             {
               const size_t n = r1 - r0;
               const BlockedParams q = params_of(nb);
               hipStream_t bs = c->workStreams[nb.ev % kWorkStreams];
               bool ok = hipMemcpyAsync((RegionDesc *)c->bRegions.p + r0, desc + r0, n * sizeof(RegionDesc), hipMemcpyHostToDevice, bs) == hipSuccess;
+              ok = ok && hipEventRecord(c->workTimers[4 * nb.ev], bs) == hipSuccess;
               if (ok) { launch_blocked_fit_search(q, bs); ok = hipGetLastError() == hipSuccess; }
+              ok = ok && hipEventRecord(c->workTimers[4 * nb.ev + 1], bs) == hipSuccess;
               ok = ok && hipMemcpyAsync(hOut + r0, (RegionOut *)c->bOut.p + r0, n * sizeof(RegionOut), hipMemcpyDeviceToHost, bs) == hipSuccess;
               ok = ok && hipEventRecord(c->workEvents[nb.ev], bs) == hipSuccess;
               if (!ok) workerResult = limg_hip_error_Generic;
@@ -1512,6 +1541,10 @@ extern "C"
           if (workerResult == limg_hip_success)
           {
             bool ok = hipEventSynchronize(c->workEvents[pending.ev]) == hipSuccess;
+            {
+              float t = 0;
+              if (ok && hipEventElapsedTime(&t, c->workTimers[4 * pending.ev], c->workTimers[4 * pending.ev + 1]) == hipSuccess) kernelMs[0] += t;
+            }
             const clk::time_point w1 = clk::now();
             dbgWait += ms(w0b, w1);
             // the dither chain (src/limg_internal.h:711, src/limg.cpp:1541-1551): one chain through all rectangles in creation order; a call over N
@@ -1526,6 +1559,7 @@ extern "C"
             const BlockedParams q = params_of(pending);
             const size_t nc = callCount - call0;
             ok = ok && hipStreamWaitEvent(ss, c->workEvents[pending.ev], 0) == hipSuccess; // this batch's records and shift words are in bOut
+            ok = ok && hipEventRecord(c->workTimers[4 * pending.ev + 2], ss) == hipSuccess;
             if (ok && nc)
             {
               ok = hipMemcpyAsync(dCallState + call0, callState + call0, nc * 8, hipMemcpyHostToDevice, ss) == hipSuccess &&
@@ -1535,6 +1569,7 @@ extern "C"
             }
             ok = ok && hipMemcpyAsync((unsigned long long *)c->bNoiseBase.p + pending.r0, noiseBase + pending.r0, (pending.r1 - pending.r0) * 8, hipMemcpyHostToDevice, ss) == hipSuccess;
             if (ok) { launch_blocked_store(q, ss); ok = hipGetLastError() == hipSuccess; }
+            if (ok && hipEventRecord(c->workTimers[4 * pending.ev + 3], ss) == hipSuccess) storeTimed[pending.ev] = 1;
             const clk::time_point w3 = clk::now();
             busy[0] += ms(w0, w1); busy[1] += ms(w1, w2); busy[2] += ms(w2, w3);
             if (!ok) workerResult = limg_hip_error_Generic;
@@ -1545,6 +1580,12 @@ extern "C"
       for (hipStream_t st : c->workStreams)
         if (hipStreamSynchronize(st) != hipSuccess && workerResult == limg_hip_success) workerResult = limg_hip_error_Generic;
       if (hipStreamSynchronize(ss) != hipSuccess && workerResult == limg_hip_success) workerResult = limg_hip_error_Generic;
+      for (size_t i = 0; i < kInFlight; i++)
+        if (storeTimed[i])
+        {
+          float t = 0;
+          if (hipEventElapsedTime(&t, c->workTimers[4 * i + 2], c->workTimers[4 * i + 3]) == hipSuccess) kernelMs[1] += t;
+        }
     });
 
     // producer: the merge; its progress callback lays the finished rectangles out (pixel counts, scratch slices) and hands them over
@@ -1575,6 +1616,12 @@ extern "C"
     pipe.cv.notify_one();
     worker.join();
     const clk::time_point t5 = clk::now();
+    {
+      float a = 0, b = 0; // (both intervals ended before the merge's last band arrived)
+      const bool ok = hipEventElapsedTime(&a, frontTimers[0], frontTimers[1]) == hipSuccess && hipEventElapsedTime(&b, frontTimers[1], frontTimers[2]) == hipSuccess;
+      c->blockedKernelMs[0] = ok ? a : 0; c->blockedKernelMs[1] = ok ? b : 0;
+    }
+    c->blockedKernelMs[2] = kernelMs[0]; c->blockedKernelMs[3] = kernelMs[1];
     c->blockedMs[0] = ms(t0, t1); c->blockedMs[1] = ms(t1, t2); c->blockedMs[2] = busy[0]; c->blockedMs[3] = busy[1]; c->blockedMs[4] = busy[2]; c->blockedMs[5] = ms(t0, t5);
     if (getenv("LIMG_HIP_DEBUG_TIMING")) fprintf(stderr, "merge waited %.2f ms for similarity-bit bands; ", bandWaitMs);
     if (getenv("LIMG_HIP_DEBUG_TIMING")) fprintf(stderr, "worker: %d batches, enqueue %.2f ms, event wait %.2f ms, chain %.2f ms, store enqueue %.2f ms\n", dbgBatches, dbgEnqueue, dbgWait, busy[1], busy[2]);
@@ -1609,6 +1656,13 @@ extern "C"
   {
     if (!c || !pMs6) return limg_hip_error_ArgumentNull;
     memcpy(pMs6, c->blockedMs, sizeof(c->blockedMs));
+    return limg_hip_success;
+  }
+
+  limg_hip_result limg_hip_blocked_kernel_timing(limg_hip_context *c, double *pMs4)
+  {
+    if (!c || !pMs4) return limg_hip_error_ArgumentNull;
+    memcpy(pMs4, c->blockedKernelMs, sizeof(c->blockedKernelMs));
     return limg_hip_success;
   }
 
