@@ -108,6 +108,8 @@ def test_device_entry_full_size(gpu, oracle):
             assert np.array_equal(got, want[k]), (kind, k)
         t = gpu.blocked_timing()
         assert t["total"] > 0 and len(gpu.blocked_regions()) == len(want["regions"])
+        k = gpu.blocked_kernel_timing()  # HIP-event times of this very encode's launches: all four ran, and none can have taken longer than the call
+        assert all(0 < v < t["total"] for v in k.values()), (k, t)
 
 
 def test_giant_rectangle(gpu, oracle):
