@@ -51,7 +51,9 @@ def main():
         legacy = bool(rng.random() < 0.25)  # float stage with lane == pixel inside the E step instead of k_fit_tpb
         recipe = dict(w=w, h=h, gen=gen, seed=seed, alpha=alpha, ef=ef, fast=fast, pcg=pcg, pool=pool, split=split, legacy=legacy)
         kw = dict(error_factor=ef, fast=fast)
-        g.set_options(force_split=split, dither_pcg=pcg, legacy_float_stage=legacy)
+        whole = bool(rng.random() < 0.3)  # images with a partial last block row: the whole-image host walk instead of fast path + last row
+        recipe["whole_image_ragged"] = whole
+        g.set_options(force_split=split, dither_pcg=pcg, legacy_float_stage=legacy, test_whole_image_ragged=whole)
         mode = ["fixed", "stream", "blocked", "batch"][int(rng.integers(0, 4))]
         if mode == "fixed":
             want = orc.encode3d(img, alpha, pool_threads=pool, dither_mode=int(pcg), **kw)
@@ -67,11 +69,13 @@ def main():
         elif mode == "batch":
             # limg_hip_encode3d_batch_device: 2..4 images of this shape (this one + variations of it) in one launch pair, each against its own single-image oracle encode
             import torch
-            cnt = int(rng.integers(2, 5))
+            cnt = int(rng.integers(2, 7))
+            sub = int([0, 0, 1, 2, 3][int(rng.integers(0, 5))])  # the list as a pipeline of sub-batches of this many images (0: the library's rule)
+            recipe["batch"] = (cnt, sub)
             host = [img] + [np.ascontiguousarray(np.roll(img, int(rng.integers(1, 64)), axis=1) ^ np.uint32(int(rng.integers(0, 1 << 24)))) for _ in range(cnt - 1)]
             dev = [torch.from_numpy(x.view(np.int32)).cuda() for x in host]
             outs = [g.alloc_planes_device(w, h) for _ in host]
-            g.set_options(force_split=split, dither_pcg=pcg, legacy_float_stage=legacy, test_batch_chunk=int(rng.integers(0, 4)))
+            g.set_options(force_split=split, dither_pcg=pcg, legacy_float_stage=legacy, test_batch_chunk=int(rng.integers(0, 4)), batch_sub_images=sub)
             g.encode3d_batch_device(dev, alpha, outs, pool_threads=pool, **kw)
             torch.cuda.synchronize()
             bad = []
