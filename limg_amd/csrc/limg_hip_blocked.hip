@@ -108,7 +108,11 @@ namespace limg_hip
       for (int z = 0; z < 3; z++)
 #pragma unroll 1
         for (int y = 0; y < 3; y++)
+#ifdef LIMG_MATCH_ROLL_X
+#pragma unroll 1
+#else
 #pragma unroll
+#endif
           for (int x = 0; x < 3; x++)
           {
             const float xf = x * 0.5f, yf = y * 0.5f, zf = z * 0.5f;
@@ -220,7 +224,11 @@ namespace limg_hip
       for (int z = 0; z < 3; z++)
 #pragma unroll 1
         for (int y = 0; y < 3; y++)
+#ifdef LIMG_MATCH_ROLL_X
+#pragma unroll 1
+#else
 #pragma unroll
+#endif
           for (int x = 0; x < 3; x++)
           {
             const float xf = x * 0.5f, yf = y * 0.5f, zf = z * 0.5f;
@@ -272,7 +280,12 @@ namespace limg_hip
     // One wave per seed.  Step 1: every cell of the window through the early exits (cheap), lane = cell; the undecided cells are compacted into
     // a list in LDS.  Step 2: the expensive loop over the list only, two candidates per lane.
     template <int CH>
-    __global__ __launch_bounds__(256) void k_blocked_match(const BlockedParams p)
+    // Three workgroups per CU (168 VGPRs, three dwords of scratch) instead of the two the compiler takes by itself (218): 14.7-15.0 -> 13.8-14.0 ms per 8192^2 image and
+    // 3.23 -> 3.49 Gpixel/s over four contexts (tools/r04/run27.sh, same box); four (128 VGPRs, 344 B of scratch, or 192 B with the x loop rolled) is slower: 17.7 ms.
+#ifndef LIMG_MATCH_WGS
+#define LIMG_MATCH_WGS 3
+#endif
+    __global__ __launch_bounds__(256, LIMG_MATCH_WGS) void k_blocked_match(const BlockedParams p)
     {
       __shared__ unsigned short sList[4][kMatchWords * 64];
       __shared__ unsigned long long sWords[4][kMatchWords];
