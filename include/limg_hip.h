@@ -84,6 +84,8 @@ typedef struct limg_hip_options
                                   ragged path (host chain walk over every dither call) instead of fast path + last row; same planes either way */
   int32_t test_pipeline;       /* A/B hook of the sub-batch pipeline, 0 = defaults (see limg_hip_api.hip) */
   int32_t test_fail_chain_phase1; /* test hook, non-0: limg_hip_encode3d_single_chain_device behaves as if this rank's E step had failed (abort rule below) */
+  int32_t test_blocked_no_bound; /* test / A-B hook, non-0: the merged-block encoder's similarity kernel evaluates the 27-colour loop for every pair its early exits leave
+                                  open, without the certain-match bound in front of it (limg_hip_blocked.hip).  Same bits either way */
 } limg_hip_options;
 
 typedef struct limg_hip_context limg_hip_context;
@@ -219,6 +221,9 @@ limg_hip_result limg_hip_blocked_regions(limg_hip_context *pCtx, limg_hip_region
  * overlapped with [1] on a worker thread, summed over its batches -- [2] per-rectangle fit + search (GPU, incl. copies), [3] dither chain walk (host),
  * [4] noise upload + dither/decode/store launch; [5] wall-clock total. */
 limg_hip_result limg_hip_blocked_timing(limg_hip_context *pCtx, double *pMs6);
+/* The similarity bits of the context's last merged-block encode (limg_hip_host_blocked_match_words() words per block, the layout of limg_hip_host_blocked_match_bits):
+ * copies up to `capacityWords`, always reports the count.  For tests: the GPU kernel's bits against the host evaluation of the same records. */
+limg_hip_result limg_hip_blocked_match_bits(limg_hip_context *pCtx, uint64_t *pBits, size_t capacityWords, size_t *pWords);
 /* GPU time of the last merged-block encode's launches, from HIP events on the streams they run on: [0] pass 1 (the 8x8 path's float stage), [1] the similarity
  * kernels (16 bands, back to back), and summed over the worker's batches [2] the per-rectangle fit + search kernel, [3] chain-value upload + noise expansion +
  * dither/decode/store kernel.  (What the GPU side costs with no host in the way: bench.py's kernel-only rate of the merged-block encoder.) */

@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     "limg_hip_host_noise_table", "limg_hip_noise_table_device", "limg_hip_host_chain_call", "limg_hip_host_chain_checkpoints", "limg_hip_host_partition", "limg_hip_check_device_status",
     "limg_hip_stream_bound", "limg_hip_encode_stream_device", "limg_hip_decode_stream_device", "limg_hip_encode_stream", "limg_hip_decode_stream",
     "limg_hip_stream_info",
-    "limg_hip_blocked_encode3d", "limg_hip_blocked_encode3d_device", "limg_hip_blocked_regions", "limg_hip_blocked_timing", "limg_hip_blocked_kernel_timing", "limg_hip_host_blocked_matches",
+    "limg_hip_blocked_encode3d", "limg_hip_blocked_encode3d_device", "limg_hip_blocked_regions", "limg_hip_blocked_timing", "limg_hip_blocked_kernel_timing", "limg_hip_blocked_match_bits", "limg_hip_host_blocked_matches",
     "limg_hip_host_blocked_merge", "limg_hip_host_blocked_match_words", "limg_hip_host_blocked_match_bits",
     "limg_hip_comm_unique_id", "limg_hip_comm_init", "limg_hip_comm_destroy", "limg_hip_comm_info", "limg_hip_gather_stream", "limg_hip_encode3d_single_chain_device",
     "limg_hip_encode3d_chain_device", "limg_hip_host_gather_offsets", "limg_hip_host_chain_bases",
@@ -62,7 +62,8 @@ class CompactOut(C.Structure):
 class Options(C.Structure):
     _fields_ = [("forced_shift", C.c_int32 * 3), ("force_split_kernels", C.c_int32), ("dither_pcg", C.c_int32), ("test_record_limit", C.c_int32), ("float_mode", C.c_int32), ("legacy_float_stage", C.c_int32),
                 ("collect_stats", C.c_int32), ("host_noise_table", C.c_int32), ("test_batch_chunk", C.c_int32), ("batch_sub_images", C.c_int32), ("test_wg_per_cu", C.c_int32),
-                ("test_whole_image_ragged", C.c_int32), ("test_pipeline", C.c_int32), ("test_fail_chain_phase1", C.c_int32)]
+                ("test_whole_image_ragged", C.c_int32), ("test_pipeline", C.c_int32), ("test_fail_chain_phase1", C.c_int32),
+                ("test_blocked_no_bound", C.c_int32)]
 
 
 def load_library(path=None):
@@ -134,6 +135,8 @@ def load_library(path=None):
     L.limg_hip_blocked_regions.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.limg_hip_blocked_timing.restype = C.c_int
     L.limg_hip_blocked_timing.argtypes = [C.c_void_p, C.c_void_p]
+    L.limg_hip_blocked_match_bits.restype = C.c_int
+    L.limg_hip_blocked_match_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.limg_hip_blocked_kernel_timing.restype = C.c_int
     L.limg_hip_blocked_kernel_timing.argtypes = [C.c_void_p, C.c_void_p]
     L.limg_hip_host_blocked_matches.restype = C.c_int
@@ -259,7 +262,7 @@ class LimgHip:
             pass
 
     def set_options(self, forced_shift=None, force_split=False, dither_pcg=False, test_record_limit=0, float_fast=False, legacy_float_stage=False, test_batch_chunk=0, host_noise_table=False, collect_stats=False,
-                    batch_sub_images=0, test_wg_per_cu=0, test_whole_image_ragged=False, test_fail_chain_phase1=False, test_pipeline=0):
+                    batch_sub_images=0, test_wg_per_cu=0, test_whole_image_ragged=False, test_fail_chain_phase1=False, test_pipeline=0, test_blocked_no_bound=False):
         o = Options()
         self.lib.limg_hip_default_options(C.byref(o))
         if forced_shift is not None:
@@ -278,6 +281,7 @@ class LimgHip:
         o.test_whole_image_ragged = int(test_whole_image_ragged)
         o.test_fail_chain_phase1 = int(test_fail_chain_phase1)
         o.test_pipeline = int(test_pipeline)
+        o.test_blocked_no_bound = int(test_blocked_no_bound)
         _check(self.lib.limg_hip_set_options(self.ctx, C.byref(o)), "limg_hip_set_options")
 
     def get_options(self):
@@ -413,6 +417,14 @@ class LimgHip:
         ms = np.zeros(6, dtype=np.float64)
         _check(self.lib.limg_hip_blocked_timing(self.ctx, _np_ptr(ms)), "limg_hip_blocked_timing")
         return dict(zip(("pass1_match_gpu", "merge_host", "fit_search_gpu", "chain_host", "store_gpu", "total"), ms.tolist()))
+
+    def blocked_match_bits(self):
+        """The similarity bits (uint64 words, host_blocked_merge's layout) the last merged-block encode's merge worked from."""
+        n = C.c_size_t(0)
+        _check(self.lib.limg_hip_blocked_match_bits(self.ctx, None, 0, C.byref(n)), "limg_hip_blocked_match_bits")
+        out = np.zeros(n.value, dtype=np.uint64)
+        _check(self.lib.limg_hip_blocked_match_bits(self.ctx, _np_ptr(out), out.size, C.byref(n)), "limg_hip_blocked_match_bits")
+        return out
 
     def blocked_kernel_timing(self):
         """GPU milliseconds (HIP events) of the last merged-block encode's launches: pass 1, similarity kernels, and -- summed over the worker's batches -- the

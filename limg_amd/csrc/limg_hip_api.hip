@@ -106,7 +106,7 @@ struct limg_hip_context
   DevBuf devStatus;                              // sticky look-back timeout word: never touched by the per-launch memset, cleared by limg_hip_check_device_status
   DevBuf in, planes;                             // staging for the host-pointer entry points
   DevBuf cmp;                                    // 8-byte accumulator of limg_hip_compare
-  DevBuf bFlags;
+  DevBuf bFlags, bBound;
   DevBuf bMatch, bRegions, bOut, bPx, bV, bFac, bNoise, bNoiseBase; // merged-block encoder: similarity bits, region table / results, scratch, noise
   HostBuf hFlags;
   HostBuf hRec, hBits, hDesc, hOut, hNoise, hNoiseBase;
@@ -118,6 +118,7 @@ struct limg_hip_context
   hipStream_t copyStream = nullptr;      // copies of the similarity-bit bands, behind the kernels that produce them
   std::vector<hipEvent_t> bandEvents;
   std::vector<HostRegion> lastRegions;
+  size_t lastBlocks = 0;                     // blocks of the last merged-block encode (what hBits / lastRegions describe)
   double blockedMs[6] = { 0, 0, 0, 0, 0, 0 };
   double blockedKernelMs[4] = { 0, 0, 0, 0 }; // the last merged-block encode, HIP events: pass 1 (k_fit_tpb) / the k_blocked_match launches / the k_blocked_fit_search launches /
                                              // the noise-expansion + store launches (the last two summed over the worker's batches)
@@ -751,7 +752,7 @@ extern "C"
     (void)hipDeviceSynchronize();
     DevBuf *bufs[] = { &c->noiseStates, &c->invN, &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->noiseCk, &c->stats, &c->lookback, &c->devStatus, &c->accTable, &c->commWords, &c->park, &c->batchTable, &c->in, &c->planes, &c->cmp,
                        &c->streamFac, &c->streamTiles, &c->streamStatus, &c->streamBuf,
-                       &c->bFlags, &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bV, &c->bFac, &c->bNoise, &c->bNoiseBase };
+                       &c->bFlags, &c->bBound, &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bV, &c->bFac, &c->bNoise, &c->bNoiseBase };
     for (DevBuf *b : bufs) b->release();
     HostBuf *hbufs[] = { &c->hFlags, &c->hRec, &c->hBits, &c->hDesc, &c->hOut, &c->hNoise, &c->hNoiseBase };
     for (HostBuf *b : hbufs) b->release();
@@ -919,7 +920,7 @@ extern "C"
     if (!c) return 0;
     const DevBuf *bufs[] = { &c->bCalls, &c->noiseStates, &c->records, &c->shifts, &c->invN, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->noiseCk, &c->lookback, &c->park, &c->batchTable, &c->stats,
                              &c->accTable, &c->devStatus, &c->commWords, &c->in, &c->planes, &c->cmp, &c->streamFac, &c->streamTiles, &c->streamStatus, &c->streamBuf,
-                             &c->bFlags, &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bV, &c->bFac, &c->bNoise, &c->bNoiseBase };
+                             &c->bFlags, &c->bBound, &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bV, &c->bFac, &c->bNoise, &c->bNoiseBase };
     size_t sum = 0;
     for (const DevBuf *b : bufs) sum += b->cap;
     return sum;
@@ -1359,6 +1360,11 @@ extern "C"
     if ((r = c->bFlags.ensure(blocks)) != limg_hip_success) return r;
     if ((r = c->hFlags.ensure(blocks)) != limg_hip_success) return r;
     bp.matchFlags = (uint8_t *)c->bFlags.p;
+    if (c->opt.test_blocked_no_bound == 0)
+    {
+      if ((r = c->bBound.ensure(blocks * 16)) != limg_hip_success) return r;
+      bp.matchBound = (float *)c->bBound.p;
+    }
     uint8_t *hFlags = (uint8_t *)c->hFlags.p;
     bp.info = *pInfo;
     // The similarity bits are produced and copied band by band (block rows) so that the merge, which consumes seeds in raster order, can start
@@ -1383,6 +1389,8 @@ extern "C"
     HIP_TRY(hipStreamWaitEvent(cs, evPass1, 0));
     HIP_TRY(hipMemcpyAsync(hRec, c->records.p, blocks * sizeof(limg_hip_block_record), hipMemcpyDeviceToHost, cs));
     HIP_TRY(hipEventRecord(evPass1, cs)); // reused: now "records are on the host"
+    c->lastBlocks = blocks;
+    launch_blocked_bounds(bp, s);
     for (uint32_t b = 0; b < nBands; b++)
     {
       const uint32_t row0 = b * bandRows, rows = min(bandRows, blocksY - row0);
@@ -1656,6 +1664,16 @@ extern "C"
   {
     if (!c || !pMs6) return limg_hip_error_ArgumentNull;
     memcpy(pMs6, c->blockedMs, sizeof(c->blockedMs));
+    return limg_hip_success;
+  }
+
+  limg_hip_result limg_hip_blocked_match_bits(limg_hip_context *c, uint64_t *pBits, size_t capacityWords, size_t *pWords)
+  { // the similarity bits the last merged-block encode's merge worked from (they stay in the context's pinned staging buffer until the next encode)
+    if (!c || !pWords) return limg_hip_error_ArgumentNull;
+    std::lock_guard<std::recursive_mutex> hostLock(c->hostEntry);
+    const size_t words = c->lastBlocks * kMatchWords;
+    *pWords = words;
+    if (pBits && c->hBits.p) memcpy(pBits, c->hBits.p, (words < capacityWords ? words : capacityWords) * 8);
     return limg_hip_success;
   }
 

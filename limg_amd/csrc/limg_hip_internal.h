@@ -144,6 +144,7 @@ namespace limg_hip
     unsigned long long *matchBits; // [blocks][kMatchWords]
     uint32_t seedBase, seedCount;  // k_blocked_match: the seeds of this launch (a band of block rows)
     uint8_t *matchFlags;           // per seed: bit 0 = its 3x3 neighbourhood (right / down) matches entirely, bit 1 = its right or its lower neighbour matches
+    float *matchBound;             // per block, 4 floats (k_blocked_bounds): the coefficients of an upper bound of the predicate's 27-colour average; nullptr = not used
     const RegionDesc *regions; // of this launch (a batch of consecutive rectangles)
     uint32_t nRegions;
     uint32_t regionBase;       // index of regions[0] in creation order (block index = regionBase + r + 1)
@@ -157,6 +158,7 @@ namespace limg_hip
     limg_hip_blocked_encode3d_info info;
   };
 
+  void launch_blocked_bounds(const BlockedParams &p, hipStream_t s);
   void launch_blocked_match(const BlockedParams &p, hipStream_t s);
   void launch_blocked_fit_search(const BlockedParams &p, hipStream_t s);
   void launch_blocked_store(const BlockedParams &p, hipStream_t s);

@@ -112,6 +112,47 @@ def test_device_entry_full_size(gpu, oracle):
         assert all(0 < v < t["total"] for v in k.values()), (k, t)
 
 
+def test_similarity_bits_equal_host_evaluation_with_and_without_the_bound(gpu, oracle):
+    """k_blocked_match's bits, with its certain-match bound (the default) and with the 27-colour loop for every open pair (test_blocked_no_bound), against the host's
+    evaluation of the full predicate over the same records (limg_hip_host_blocked_match_bits, pinned to the oracle / reference by tests/test_host.py) -- on content
+    where the bound decides everything (noise), next to nothing (gradients), and on flat / tiny / odd-sized images."""
+    import limg_amd
+    lib = limg_amd.load_library()
+    words = lib.limg_hip_host_blocked_match_words()
+    rng = np.random.default_rng(11)
+    cases = [("pn", True, 512, 384), ("rg", True, 512, 384), ("rga", True, 300, 203), ("pn", False, 264, 131), ("rg", False, 200, 160), ("rand", True, 256, 256), ("flat", True, 128, 96),
+             ("mix", True, 384, 256), ("pn", True, 8, 8), ("rg", True, 24, 136)]
+    decided = {}
+    for kind, alpha, w, h in cases:
+        if kind == "pn":
+            img = oracle.photo_noise(w, h, 9)
+        elif kind in ("rg", "rga"):
+            img = oracle.random_gradient(w, h, 9, kind == "rg")
+        elif kind == "rand":
+            img = rng.integers(0, 1 << 32, (h, w), dtype=np.uint64).astype(np.uint32)
+        elif kind == "flat":
+            img = np.full((h, w), 0xFF4080C0, dtype=np.uint32)
+        else:  # noise with low-contrast patches and gradients in between: states of very different sizes side by side
+            img = oracle.photo_noise(w, h, 3)
+            img[64:192, 32:200] = oracle.random_gradient(168, 128, 4, True)
+            img[200:240, 250:380] = (img[200:240, 250:380] & np.uint32(0xFF030303)) | np.uint32(0x00808080)
+        ch = 4 if alpha else 3
+        bits = {}
+        for no_bound in (False, True):
+            gpu.set_options(test_blocked_no_bound=no_bound)
+            try:
+                gpu.blocked_encode3d(img, alpha)
+                bits[no_bound] = gpu.blocked_match_bits()
+            finally:
+                gpu.set_options()
+        fits = oracle.blocked_encode3d(img, alpha, planes=False)["pass1"]
+        by, bx = fits.shape
+        want = np.zeros(by * bx * words, dtype=np.uint64)
+        limg_amd._check(lib.limg_hip_host_blocked_match_bits(limg_amd._np_ptr(np.ascontiguousarray(fits)), bx, by, ch, limg_amd._np_ptr(want)), "limg_hip_host_blocked_match_bits")
+        assert np.array_equal(bits[True], want), (kind, alpha, "27-colour loop")
+        assert np.array_equal(bits[False], want), (kind, alpha, "with the bound")
+
+
 def test_giant_rectangle(gpu, oracle):
     """A flat 512x512 image with a few odd blocks: one rectangle of ~250k pixels handled by a single wave (chunk loops, 64-bit block errors, long
     pixel-order sums, host evaluation of far-apart pairs)."""
