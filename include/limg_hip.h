@@ -85,7 +85,7 @@ typedef struct limg_hip_options
   int32_t test_pipeline;       /* A/B hook of the sub-batch pipeline, 0 = defaults (see limg_hip_api.hip) */
   int32_t test_fail_chain_phase1; /* test hook, non-0: limg_hip_encode3d_single_chain_device behaves as if this rank's E step had failed (abort rule below) */
   int32_t test_blocked_no_bound; /* test / A-B hook, non-0: the merged-block encoder's similarity kernel evaluates the 27-colour loop for every pair its early exits leave
-                                  open, without the certain-match bound in front of it (limg_hip_blocked.hip).  Same bits either way */
+                                  open, without the certain-match / certain-failure bounds in front of it (limg_hip_blocked.hip).  Same bits either way */
 } limg_hip_options;
 
 typedef struct limg_hip_context limg_hip_context;

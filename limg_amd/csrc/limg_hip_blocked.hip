@@ -277,16 +277,24 @@ namespace limg_hip
       idx = ok ? (size_t)cy * p.blocksX + cx : 0;
     }
 
-    // A cheap CERTAIN match for the cells the two early exits leave open.  The predicate's last test is avgF = (sum over 27 colours of termA + termB) / 27 < 3, every
-    // term of the form |f0| / len0 + |0.5 - f1| * 2 / len1 + |0.5 - f2| * 2 / len2 with f = the factors of a colour c in a block's state (m_factors).  By the triangle and
-    // Cauchy-Schwarz inequalities alone (no orthogonality assumed, so they hold for the rounded float operations up to a factor (1 + 2^-23)^k, k < 200):
-    //   D := |c| + |dirA_min|;  |f0| <= D / |nA|;  |f1| <= (2 D + |ofB|) / |nB|;  |f2| <= (4 D + |ofB| + |ofC|) / |nC|   (a factor whose normal is all zero is exactly 0)
-    // i.e. term <= alpha + beta * D with per-block constants alpha, beta.  For termA the state is the seed's and |c| <= |(|nA| + |nB| + |nC|) of the candidate| =: R (the 27
-    // colours are nA x + nB y + nC z, x, y, z in {0, 0.5, 1}); for termB the state is the candidate's and c the seed's average.  So
-    //   avgF <= alpha_a + beta_a (R_b + M_a) + alpha_b + beta_b (|avg_a| + M_b) =: U,   M = |dirA_min|,
+    // A cheap CERTAIN outcome for most of the cells the two early exits leave open.  The predicate's last test is avgF = (sum over 27 colours of termA + termB) / 27 < 3,
+    // every term of the form |f0| / len0 + |0.5 - f1| * 2 / len1 + |0.5 - f2| * 2 / len2 with f = the factors of a colour c in a block's state (m_factors).
+    //
+    // Certain match.  By the triangle and Cauchy-Schwarz inequalities alone (no orthogonality assumed, so they hold for the rounded float operations up to a factor
+    // (1 + 2^-23)^k, k < 200):   D := |c| + |dirA_min|;  |f0| <= D / |nA|;  |f1| <= (2 D + |ofB|) / |nB|;  |f2| <= (4 D + |ofB| + |ofC|) / |nC|   (a factor whose normal is
+    // all zero is exactly 0), i.e. term <= alpha + beta * D with per-block constants alpha, beta.  For termA the state is the seed's and |c| <= S_b := |nA| + |nB| + |nC| of the
+    // candidate (the 27 colours are nA x + nB y + nC z, x, y, z in {0, 0.5, 1}); for termB the state is the candidate's and c the seed's average.  So
+    //   avgF <= alpha_a + beta_a (S_b + M_a) + alpha_b + beta_b (|avg_a| + M_b) =: U,   M = |dirA_min|,
     // and U * 1.01 < 2.5 proves avgF < 3 whatever the 27-colour loop would have rounded to.  On noisy content (large normals, tiny terms) this decides EVERY open cell --
-    // the 27-colour evaluation, 5/6 of this kernel's time there, is not run at all; on smooth gradients it decides 3-4 % (cost: one 16-byte load and 8 operations per cell).
-    // k_blocked_bounds: per block { alpha, beta, M, R }.
+    // the 27-colour evaluation, 5/6 of this kernel's time there, is not run at all; on smooth gradients it decides 3 %.
+    //
+    // Certain failure, from the same constants.  The factors are affine in the colour, so a term moves by at most beta * |c - c'| between two colours (same inequalities
+    // on differences), and the first of the 27 colours is the zero vector whatever the candidate.  With T0 := the seed's term at colour 0 (once per seed, by the loop's own
+    // operations): term(c) >= T0 - beta_a |c|, and the 27 colours' norms add up to at most 27 * 0.5 * S_b (x, y and z each average 0.5), so
+    //   (sum of the 27 termA) / 27 >= T0 - 0.5 beta_a S_b - (rounding: < 2e-5 U_a);   termB >= 0, and a float sum of non-negative terms is monotone:
+    //   T0 - 1.01 * 0.5 beta_a S_b - 0.01 U_a > 3.01  proves avgF > 3.
+    // On smooth gradients (small normals: a seed's zero-colour term is ~8) this decides 53 % of the open pairs, on noisy content none.
+    // Cost: k_blocked_bounds (one lane per block: { alpha, beta, M, S }), then one 16-byte load and a dozen operations per open cell.
     template <int CH>
     __global__ __launch_bounds__(256) void k_blocked_bounds(const BlockedParams p)
     {
@@ -296,21 +304,21 @@ namespace limg_hip
       MState s;
       m_init<CH>(r, s);
       const float w[4] = { 2, 4, 3, 3 };
-      float len[3] = { 3, 3, 3 }, qA = 0, qB = 0, qC = 0, qM = 0, qOB = 0, qOC = 0, qR = 0;
+      float len[3] = { 3, 3, 3 }, qA = 0, qB = 0, qC = 0, qM = 0, qOB = 0, qOC = 0;
 #pragma unroll
       for (int k = 0; k < CH; k++)
       {
         len[0] += (s.nA[k] * s.nA[k]) * w[k]; len[1] += (s.nB[k] * s.nB[k]) * w[k]; len[2] += (s.nC[k] * s.nC[k]) * w[k];
         qA += s.nA[k] * s.nA[k]; qB += s.nB[k] * s.nB[k]; qC += s.nC[k] * s.nC[k];
-        const float m = (float)r.dirA_min[k], ob = (float)r.dirB_offset[k], oc = (float)r.dirC_offset[k], rr = fabsf(s.nA[k]) + fabsf(s.nB[k]) + fabsf(s.nC[k]);
-        qM += m * m; qOB += ob * ob; qOC += oc * oc; qR += rr * rr;
+        const float m = (float)r.dirA_min[k], ob = (float)r.dirB_offset[k], oc = (float)r.dirC_offset[k];
+        qM += m * m; qOB += ob * ob; qOC += oc * oc;
       }
       const float NA = sqrtf(qA), NB = sqrtf(qB), NC = sqrtf(qC), OB = sqrtf(qOB), OC = sqrtf(qOC);
       float alpha = 0.5f * 2.0f / len[1] + 0.5f * 2.0f / len[2], beta = 0;
       if (qA > 0) beta += 1.0f / (NA * len[0]);
       if (qB > 0) { alpha += (OB / NB) * 2.0f / len[1]; beta += 4.0f / (NB * len[1]); }
       if (qC > 0) { alpha += ((OB + OC) / NC) * 2.0f / len[2]; beta += 8.0f / (NC * len[2]); }
-      reinterpret_cast<float4 *>(p.matchBound)[i] = make_float4(alpha, beta, sqrtf(qM), sqrtf(qR));
+      reinterpret_cast<float4 *>(p.matchBound)[i] = make_float4(alpha, beta, sqrtf(qM), (NA + NB + NC) * 1.0001f);
     }
 
     // One wave per seed.  Step 1: every cell of the window through the early exits (cheap), lane = cell; the undecided cells are compacted into
@@ -333,7 +341,7 @@ namespace limg_hip
       const limg_hip_block_record a = p.pass1[seed];
       MState sa;
       m_init<CH>(a, sa);
-      float boundA = 0, boundB = 0, boundM = 0, boundAvg = 0; // the seed's share of the certain-match bound (k_blocked_bounds)
+      float boundA = 0, boundB = 0, boundM = 0, boundAvg = 0, boundT0 = 0; // the seed's share of the certain-match / certain-failure bounds (k_blocked_bounds)
       if (p.matchBound)
       {
         const float4 ba = reinterpret_cast<const float4 *>(p.matchBound)[seed];
@@ -341,6 +349,13 @@ namespace limg_hip
 #pragma unroll
         for (int k = 0; k < CH; k++) q += a.avg[k] * a.avg[k];
         boundA = ba.x; boundB = ba.y; boundM = ba.z; boundAvg = sqrtf(q);
+        // the seed's term at the zero colour (x = y = z = 0 of the 27-colour loop), with the loop's operations
+        const float w[4] = { 2, 4, 3, 3 }, zero[4] = { 0, 0, 0, 0 };
+        float len[3] = { 3, 3, 3 }, f0[3];
+#pragma unroll
+        for (int k = 0; k < CH; k++) { len[0] += (sa.nA[k] * sa.nA[k]) * w[k]; len[1] += (sa.nB[k] * sa.nB[k]) * w[k]; len[2] += (sa.nC[k] * sa.nC[k]) * w[k]; }
+        m_factors<CH>(zero, a, sa, f0);
+        boundT0 = fabsf(f0[0]) * (1.0f / len[0]) + fabsf(0.5f - f0[1]) * ((1.0f / len[1]) * 2.f) + fabsf(0.5f - f0[2]) * ((1.0f / len[2]) * 2.f);
       }
       uint32_t count = 0;
       for (int c = 0; c < kMatchWords; c++)
@@ -354,8 +369,9 @@ namespace limg_hip
         if (e == 0 && p.matchBound)
         {
           const float4 bb = reinterpret_cast<const float4 *>(p.matchBound)[idx];
-          const float U = (boundA + boundB * (bb.w + boundM)) + (bb.x + bb.y * (boundAvg + bb.z));
-          if (U * 1.01f < 2.5f) e = 1; // (a NaN or an infinity fails the comparison: the 27-colour loop decides)
+          const float UA = boundA + boundB * (bb.w + boundM), U = UA + (bb.x + bb.y * (boundAvg + bb.z));
+          if (U * 1.01f < 2.5f) e = 1; // (a NaN or an infinity fails both comparisons: the 27-colour loop decides)
+          else if (boundT0 - 1.01f * (0.5f * boundB * bb.w) - 0.01f * UA > 3.01f) e = 2;
         }
         const unsigned long long yes = __builtin_amdgcn_ballot_w64(e == 1), open = __builtin_amdgcn_ballot_w64(e == 0);
         if (lane == 0) sWords[wave][c] = yes;

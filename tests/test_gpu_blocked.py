@@ -113,7 +113,7 @@ def test_device_entry_full_size(gpu, oracle):
 
 
 def test_similarity_bits_equal_host_evaluation_with_and_without_the_bound(gpu, oracle):
-    """k_blocked_match's bits, with its certain-match bound (the default) and with the 27-colour loop for every open pair (test_blocked_no_bound), against the host's
+    """k_blocked_match's bits, with its certain-match / certain-failure bounds (the default) and with the 27-colour loop for every open pair (test_blocked_no_bound), against the host's
     evaluation of the full predicate over the same records (limg_hip_host_blocked_match_bits, pinned to the oracle / reference by tests/test_host.py) -- on content
     where the bound decides everything (noise), next to nothing (gradients), and on flat / tiny / odd-sized images."""
     import limg_amd
@@ -121,13 +121,20 @@ def test_similarity_bits_equal_host_evaluation_with_and_without_the_bound(gpu, o
     words = lib.limg_hip_host_blocked_match_words()
     rng = np.random.default_rng(11)
     cases = [("pn", True, 512, 384), ("rg", True, 512, 384), ("rga", True, 300, 203), ("pn", False, 264, 131), ("rg", False, 200, 160), ("rand", True, 256, 256), ("flat", True, 128, 96),
-             ("mix", True, 384, 256), ("pn", True, 8, 8), ("rg", True, 24, 136)]
+             ("mix", True, 384, 256), ("pn", True, 8, 8), ("rg", True, 24, 136), ("rg2", True, 640, 512), ("rga2", False, 512, 320), ("smooth", True, 384, 384)]
     decided = {}
     for kind, alpha, w, h in cases:
         if kind == "pn":
             img = oracle.photo_noise(w, h, 9)
         elif kind in ("rg", "rga"):
             img = oracle.random_gradient(w, h, 9, kind == "rg")
+        elif kind in ("rg2", "rga2"):
+            img = oracle.random_gradient(w, h, 31, kind == "rg2")
+        elif kind == "smooth":  # slow ramps + a little noise: small normals next to zero normals (where the failure bound has the most to decide)
+            yy, xx = np.mgrid[0:h, 0:w]
+            n = rng.integers(0, 3, (h, w, 3))
+            r8 = ((xx // 3 + n[..., 0]) & 255).astype(np.uint32); g8 = ((yy // 2 + n[..., 1]) & 255).astype(np.uint32); b8 = (((xx + yy) // 5 + n[..., 2]) & 255).astype(np.uint32)
+            img = (np.uint32(0xFF000000) | (b8 << 16) | (g8 << 8) | r8).astype(np.uint32)
         elif kind == "rand":
             img = rng.integers(0, 1 << 32, (h, w), dtype=np.uint64).astype(np.uint32)
         elif kind == "flat":
