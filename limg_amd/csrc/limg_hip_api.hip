@@ -1383,12 +1383,16 @@ extern "C"
       c->bandEvents.push_back(e);
     }
     hipStream_t cs = c->copyStream;
+    // The records go to the host as well, but the merge reads them only for pairs outside the similarity window (a few dozen per image): their copy (64 MB for 8192^2,
+    // 1.3 ms of PCIe) is queued BEHIND the first two bands' bits, and the merge waits for it when it first needs a record -- not before it starts.
     hipEvent_t evPass1 = c->bandEvents[2 * kBands];
     HIP_TRY(hipEventRecord(frontTimers[1], s));
-    HIP_TRY(hipEventRecord(evPass1, s));
-    HIP_TRY(hipStreamWaitEvent(cs, evPass1, 0));
-    HIP_TRY(hipMemcpyAsync(hRec, c->records.p, blocks * sizeof(limg_hip_block_record), hipMemcpyDeviceToHost, cs));
-    HIP_TRY(hipEventRecord(evPass1, cs)); // reused: now "records are on the host"
+    auto copy_records = [&]() -> limg_hip_result
+    {
+      HIP_TRY(hipMemcpyAsync(hRec, c->records.p, blocks * sizeof(limg_hip_block_record), hipMemcpyDeviceToHost, cs)); // (`cs` has waited for a band's kernel: pass 1 is long done)
+      HIP_TRY(hipEventRecord(evPass1, cs)); // "records are on the host"
+      return limg_hip_success;
+    };
     c->lastBlocks = blocks;
     launch_blocked_bounds(bp, s);
     for (uint32_t b = 0; b < nBands; b++)
@@ -1403,13 +1407,19 @@ extern "C"
                              hipMemcpyDeviceToHost, cs));
       HIP_TRY(hipMemcpyAsync(hFlags + bp.seedBase, (uint8_t *)c->bFlags.p + bp.seedBase, bp.seedCount, hipMemcpyDeviceToHost, cs));
       HIP_TRY(hipEventRecord(c->bandEvents[2 * b + 1], cs));
+      if (b == 1 || (b == 0 && nBands == 1))
+        if ((r = copy_records()) != limg_hip_success) return r;
     }
     HIP_TRY(hipEventRecord(frontTimers[2], s)); // (`s` holds nothing but the similarity kernels between the two timers: the copies run on `cs`)
-    HIP_TRY(hipEventSynchronize(evPass1));
+    HIP_TRY(hipEventSynchronize(c->bandEvents[1])); // the first band's bits: the merge can start
     const clk::time_point t1 = clk::now();
     uint32_t bandsReady = 0;
-    bool bandError = false;
+    bool bandError = false, recordsHere = false;
     double bandWaitMs = 0;
+    const std::function<void()> needRecords = [&]() {
+      if (!recordsHere && hipEventSynchronize(evPass1) != hipSuccess) bandError = true;
+      recordsHere = true;
+    };
     const std::function<void(uint32_t)> needSeedRow = [&](uint32_t row) {
       while (bandsReady < nBands && row >= bandsReady * bandRows)
       {
@@ -1616,9 +1626,10 @@ extern "C"
       pipe.cv.notify_one();
     };
     bool mergeFailed = false;
-    try { blocked_merge(hRec, hBits, blocksX, blocksY, channels, c->lastRegions, &progress, &needSeedRow, hFlags); }
+    try { blocked_merge(hRec, hBits, blocksX, blocksY, channels, c->lastRegions, &progress, &needSeedRow, hFlags, &needRecords); }
     catch (...) { mergeFailed = true; } // out of host memory: the worker must still be released and joined
     needSeedRow(blocksY - 1); // every band's copy is complete before the staging buffers can be reused
+    needRecords();
     const clk::time_point t2 = clk::now();
     { std::lock_guard<std::mutex> lk(pipe.m); pipe.finished = true; }
     pipe.cv.notify_one();

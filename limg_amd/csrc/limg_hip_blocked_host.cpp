@@ -180,6 +180,8 @@ namespace limg_hip
       std::vector<uint8_t> used;
       const std::function<void(uint32_t)> *needRow = nullptr; // the similarity bits arrive band by band: called before a seed row's bits are first read
       mutable uint32_t rowsSeen = 0;
+      const std::function<void()> *needRecords = nullptr;     // the records themselves are only read for pairs outside the window (rare): called before the first such read
+      mutable bool recordsSeen = false;
       mutable uint32_t pfRow = 0xFFFFFFFFu, pfCol = 0, pfAhead = 0; // look-ahead of `find` that requests the similarity rows of the seeds to come
       mutable bool pfTiny = false;
       const uint8_t *flags = nullptr; // per seed, from the GPU: bit 0 = a rectangle of >= 3 x 3 is possible at all, bit 1 = any rectangle is (necessary conditions)
@@ -203,6 +205,7 @@ namespace limg_hip
             const unsigned cell = uy * kMatchSide + ux;
             return (row[cell >> 6] >> (cell & 63)) & 1ull;
           }
+          if (needRecords && !recordsSeen) { (*needRecords)(); recordsSeen = true; }
           return blocked_matches_host(ch, rec[seed], rec[ci]);
         };
         auto column = [&](uint32_t x, uint32_t y0, uint32_t n) { for (uint32_t i = 0; i < n; i++) if (!ok(x, y0 + i)) return false; return true; };
@@ -340,9 +343,12 @@ namespace limg_hip
   // src/limg.cpp:1813-1881: large rectangles, then small ones, then the remaining single blocks.  `progress` (optional) is told how many rectangles
   // of `out` are final every few thousand, so that a consumer can work on them while the scan goes on; `out` never reallocates (reserved up front).
   void blocked_merge(const limg_hip_block_record *pass1, const unsigned long long *matchBits, uint32_t blocksX, uint32_t blocksY, int channels, std::vector<HostRegion> &out,
-                     const std::function<void(size_t)> *progress, const std::function<void(uint32_t)> *needSeedRow, const uint8_t *seedFlags)
+                     const std::function<void(size_t)> *progress, const std::function<void(uint32_t)> *needSeedRow, const uint8_t *seedFlags,
+                     const std::function<void()> *needRecords)
   {
     Merge m;
+    m.needRecords = matchBits ? needRecords : nullptr;
+    if (!matchBits && needRecords) (*needRecords)(); // (no window: every pair is evaluated from the records)
     m.rec = pass1; m.bits = matchBits; m.bx = blocksX; m.by = blocksY; m.ch = channels; m.needRow = needSeedRow; m.flags = matchBits ? seedFlags : nullptr;
     m.used.assign((size_t)blocksX * blocksY + 16, 0); // (+ 16: expand_fast reads 16 flag bytes at a time)
     out.clear();

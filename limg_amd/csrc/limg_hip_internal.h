@@ -166,7 +166,8 @@ namespace limg_hip
   // host side of the merged-block encoder (limg_hip_blocked_host.cpp): the greedy raster merge and the dither chain walk
   struct HostRegion { uint32_t ox, oy, rx, ry, keep; };
   void blocked_merge(const limg_hip_block_record *pass1, const unsigned long long *matchBits, uint32_t blocksX, uint32_t blocksY, int channels, std::vector<HostRegion> &out,
-                     const std::function<void(size_t)> *progress = nullptr, const std::function<void(uint32_t)> *needSeedRow = nullptr, const uint8_t *seedFlags = nullptr);
+                     const std::function<void(size_t)> *progress = nullptr, const std::function<void(uint32_t)> *needSeedRow = nullptr, const uint8_t *seedFlags = nullptr,
+                     const std::function<void()> *needRecords = nullptr);
   bool blocked_matches_host(int channels, const limg_hip_block_record &seed, const limg_hip_block_record &cand);
   uint64_t chain_call_n(uint64_t h, size_t n, uint8_t *noise, bool pcg);
   uint64_t chain_walk_batch(uint64_t h, size_t count, const uint8_t *shiftWords, size_t stride, const uint32_t *npx, unsigned long long *noiseBase, unsigned long long *callState,
