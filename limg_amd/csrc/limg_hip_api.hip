@@ -1496,7 +1496,8 @@ extern "C"
       // The GPU runs AHEAD of this thread: whatever the merge has published goes to the device at once (rectangle table up, fit + search kernel, records and
       // shift words back, one event per batch, up to kInFlight batches), and the chain -- this thread's real work, serial by construction -- is walked batch by batch
       // in creation order as the results arrive.  (Rounds 2-3 kept one batch in flight: every batch's GPU round trip was waited for, 11-20 ms per image.)
-      struct Batch { size_t r0 = 0, r1 = 0; size_t ev = 0; };
+      struct Batch { size_t r0 = 0, r1 = 0; size_t ev = 0; double tq = 0; };
+      const bool dbgTimeline = getenv("LIMG_HIP_DEBUG_TIMELINE") != nullptr;
       std::vector<Batch> queue; // FIFO: [head, queue.size())
       size_t head = 0, issued = 0, evNext = 0;
       uint64_t chain = kDitherSeed, noiseOff = 0;
@@ -1509,47 +1510,47 @@ extern "C"
         q.noiseBase = (const unsigned long long *)c->bNoiseBase.p + b.r0;
         return q;
       };
+      // Everything the merge has published since the last look goes to the GPU.  mayWait: nothing is left to walk, so wait for the merge.  Called at the top of
+      // every round AND between the pieces of a batch's chain walk: a batch's walk takes milliseconds, and what the merge publishes meanwhile should be on the GPU
+      // (kernel latency: the life of its largest rectangle, 0.6-2 ms) before this thread comes looking for it -- not be enqueued when the walk is over.
+      auto enqueue_published = [&](bool mayWait)
+      {
+        if (fin || queue.size() - head >= kInFlight) return;
+        size_t r0 = 0, r1 = 0;
+        {
+          std::unique_lock<std::mutex> lk(pipe.m);
+          if (mayWait) pipe.cv.wait(lk, [&] { return pipe.ready > issued || pipe.finished; });
+          if (pipe.ready > issued) { r0 = issued; r1 = pipe.ready - issued > kBatchRegions ? issued + kBatchRegions : pipe.ready; issued = r1; }
+          else fin = pipe.finished;
+        }
+        if (r1 <= r0) return;
+        dbgBatches++;
+        Batch nb; nb.r0 = r0; nb.r1 = r1; nb.ev = evNext; evNext = (evNext + 1) % kInFlight; nb.tq = ms(t0, clk::now());
+        if (storeTimed[nb.ev])
+        { // the slot comes round again: its previous batch's store kernels were enqueued kInFlight batches ago
+          float t = 0;
+          if (hipEventSynchronize(c->workTimers[4 * nb.ev + 3]) == hipSuccess && hipEventElapsedTime(&t, c->workTimers[4 * nb.ev + 2], c->workTimers[4 * nb.ev + 3]) == hipSuccess) kernelMs[1] += t;
+          storeTimed[nb.ev] = 0;
+        }
+        if (workerResult == limg_hip_success)
+        {
+          const size_t n = r1 - r0;
+          const BlockedParams q = params_of(nb);
+          hipStream_t bs = c->workStreams[nb.ev % kWorkStreams];
+          bool ok = hipMemcpyAsync((RegionDesc *)c->bRegions.p + r0, desc + r0, n * sizeof(RegionDesc), hipMemcpyHostToDevice, bs) == hipSuccess;
+          ok = ok && hipEventRecord(c->workTimers[4 * nb.ev], bs) == hipSuccess;
+          if (ok) { launch_blocked_fit_search(q, bs); ok = hipGetLastError() == hipSuccess; }
+          ok = ok && hipEventRecord(c->workTimers[4 * nb.ev + 1], bs) == hipSuccess;
+          ok = ok && hipMemcpyAsync(hOut + r0, (RegionOut *)c->bOut.p + r0, n * sizeof(RegionOut), hipMemcpyDeviceToHost, bs) == hipSuccess;
+          ok = ok && hipEventRecord(c->workEvents[nb.ev], bs) == hipSuccess;
+          if (!ok) workerResult = limg_hip_error_Generic;
+        }
+        queue.push_back(nb);
+      };
       for (;;)
       {
-        // 1. everything the merge has published since the last look goes to the GPU (wait for the merge only if there is nothing to walk)
         const clk::time_point w0 = clk::now();
-        if (!fin && queue.size() - head < kInFlight)
-        {
-          size_t r0 = 0, r1 = 0;
-          {
-            std::unique_lock<std::mutex> lk(pipe.m);
-            if (head == queue.size()) pipe.cv.wait(lk, [&] { return pipe.ready > issued || pipe.finished; });
-            // (at most kBatchRegions at a time: several smaller batches in flight let the walk of one overlap the kernels of the next ones; one batch of everything
-            //  published so far would be waited for as a whole)
-            if (pipe.ready > issued) { r0 = issued; r1 = pipe.ready - issued > kBatchRegions ? issued + kBatchRegions : pipe.ready; issued = r1; }
-            else fin = pipe.finished;
-          }
-          if (r1 > r0)
-          {
-            dbgBatches++;
-            Batch nb; nb.r0 = r0; nb.r1 = r1; nb.ev = evNext; evNext = (evNext + 1) % kInFlight;
-            if (storeTimed[nb.ev])
-            { // the slot comes round again: its previous batch's store kernels were enqueued kInFlight batches ago
-              float t = 0;
-              if (hipEventSynchronize(c->workTimers[4 * nb.ev + 3]) == hipSuccess && hipEventElapsedTime(&t, c->workTimers[4 * nb.ev + 2], c->workTimers[4 * nb.ev + 3]) == hipSuccess) kernelMs[1] += t;
-              storeTimed[nb.ev] = 0;
-            }
-            if (workerResult == limg_hip_success)
-            {
-              const size_t n = r1 - r0;
-              const BlockedParams q = params_of(nb);
-              hipStream_t bs = c->workStreams[nb.ev % kWorkStreams];
-              bool ok = hipMemcpyAsync((RegionDesc *)c->bRegions.p + r0, desc + r0, n * sizeof(RegionDesc), hipMemcpyHostToDevice, bs) == hipSuccess;
-              ok = ok && hipEventRecord(c->workTimers[4 * nb.ev], bs) == hipSuccess;
-              if (ok) { launch_blocked_fit_search(q, bs); ok = hipGetLastError() == hipSuccess; }
-              ok = ok && hipEventRecord(c->workTimers[4 * nb.ev + 1], bs) == hipSuccess;
-              ok = ok && hipMemcpyAsync(hOut + r0, (RegionOut *)c->bOut.p + r0, n * sizeof(RegionOut), hipMemcpyDeviceToHost, bs) == hipSuccess;
-              ok = ok && hipEventRecord(c->workEvents[nb.ev], bs) == hipSuccess;
-              if (!ok) workerResult = limg_hip_error_Generic;
-            }
-            queue.push_back(nb);
-          }
-        }
+        enqueue_published(head == queue.size());
         const clk::time_point w0b = clk::now();
         dbgEnqueue += ms(w0, w0b);
         // 2. the oldest batch in flight: its shift words are (about to be) back
@@ -1570,9 +1571,14 @@ extern "C"
             // count and place in the noise buffer go up (20 bytes per call) and k_noise_expand_calls produces the byte every pixel adds on the device.  (Rounds
             // 1-3 wrote the bytes here and uploaded them: 200 MB per 8192^2 image through this thread's store buffers and over PCIe.)
             const size_t call0 = callCount;
-            if (ok)
-              chain = chain_walk_batch(chain, pending.r1 - pending.r0, reinterpret_cast<const uint8_t *>(&hOut[pending.r0].shiftWord), sizeof(RegionOut), npx.data() + pending.r0,
-                                       noiseBase + pending.r0, callState, callOff, callPx, noiseOff, callCount, maxCalls, pcg);
+            constexpr size_t kWalkPiece = 8192; // rectangles walked between two looks at what the merge has published (~0.5-2.5 ms of chain)
+            for (size_t w = pending.r0; ok && w < pending.r1; w += kWalkPiece)
+            {
+              const size_t n = pending.r1 - w < kWalkPiece ? pending.r1 - w : kWalkPiece;
+              chain = chain_walk_batch(chain, n, reinterpret_cast<const uint8_t *>(&hOut[w].shiftWord), sizeof(RegionOut), npx.data() + w, noiseBase + w, callState, callOff, callPx,
+                                       noiseOff, callCount, maxCalls, pcg);
+              if (w + n < pending.r1) enqueue_published(false);
+            }
             const clk::time_point w2 = clk::now();
             const BlockedParams q = params_of(pending);
             const size_t nc = callCount - call0;
@@ -1590,6 +1596,8 @@ extern "C"
             if (ok && hipEventRecord(c->workTimers[4 * pending.ev + 3], ss) == hipSuccess) storeTimed[pending.ev] = 1;
             const clk::time_point w3 = clk::now();
             busy[0] += ms(w0, w1); busy[1] += ms(w1, w2); busy[2] += ms(w2, w3);
+            if (dbgTimeline) fprintf(stderr, "batch %zu..%zu (%zu rects): enqueued %.2f, waited from %.2f to %.2f, walked until %.2f, stores enqueued %.2f\n", pending.r0, pending.r1, pending.r1 - pending.r0,
+                                     pending.tq, ms(t0, w0b), ms(t0, w1), ms(t0, w2), ms(t0, w3));
             if (!ok) workerResult = limg_hip_error_Generic;
           }
         }
@@ -1642,6 +1650,7 @@ extern "C"
     }
     c->blockedKernelMs[2] = kernelMs[0]; c->blockedKernelMs[3] = kernelMs[1];
     c->blockedMs[0] = ms(t0, t1); c->blockedMs[1] = ms(t1, t2); c->blockedMs[2] = busy[0]; c->blockedMs[3] = busy[1]; c->blockedMs[4] = busy[2]; c->blockedMs[5] = ms(t0, t5);
+    if (getenv("LIMG_HIP_DEBUG_TIMELINE")) fprintf(stderr, "merge from %.2f to %.2f, call ended %.2f\n", ms(t0, t1), ms(t0, t2), ms(t0, t5));
     if (getenv("LIMG_HIP_DEBUG_TIMING")) fprintf(stderr, "merge waited %.2f ms for similarity-bit bands; ", bandWaitMs);
     if (getenv("LIMG_HIP_DEBUG_TIMING")) fprintf(stderr, "worker: %d batches, enqueue %.2f ms, event wait %.2f ms, chain %.2f ms, store enqueue %.2f ms\n", dbgBatches, dbgEnqueue, dbgWait, busy[1], busy[2]);
     if (mergeFailed) return limg_hip_error_MemoryAllocationFailure;
