@@ -37,7 +37,7 @@ def build(force=False, verbose=False, extra_flags=(), out_dir=None):
         cmd = [hipcc] + FLAGS + SOURCE_FLAGS.get(src, []) + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if src.endswith(".cpp"):
             # host-only translation units; the merge's similarity predicate is float code that must round like the kernels: no contraction
-            cmd = [hipcc, "-O3", "-fPIC", "-std=c++17", "-Wall", "-ffp-contract=off", "-fno-fast-math", "-x", "c++", "-c", os.path.join(CSRC, src), "-o", obj]
+            cmd = [hipcc, "-O3", "-fPIC", "-std=c++17", "-Wall", "-ffp-contract=off", "-fno-fast-math", "-x", "c++"] + [f for f in extra_flags if f.startswith("-D")] + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -171,6 +171,11 @@ namespace limg_hip
 
   namespace
   {
+#ifndef LIMG_MERGE_PF_CENTRE
+#define LIMG_MERGE_PF_CENTRE 4
+#endif
+    constexpr uint32_t kCentreAhead = LIMG_MERGE_PF_CENTRE; // (A/B hook: 0 = the look-ahead requests the seeds' own rows only)
+
     struct Merge
     {
       const limg_hip_block_record *rec;
@@ -300,6 +305,17 @@ namespace limg_hip
               {
                 const char *q = reinterpret_cast<const char *>(bits + ((size_t)oy * bx + pfCol) * kMatchWords);
                 __builtin_prefetch(q); __builtin_prefetch(q + 47);
+                // large-rectangle pass: a seed whose first attempt succeeds is followed by an expansion from the centre third, (rx / 3, ry / 3) blocks further in -- another
+                // similarity row, first touched when it is needed: a DRAM round trip per large rectangle (32 K of them in an 8192^2 photo-noise image: 6-7 ms of
+                // the merge's 25).  Which row is not known before the first attempt is over, but the candidates are few: offsets 1 .. 4 in both directions.
+                // Same box, tools/r04/run36.sh: merge 25.1-25.7 -> 18.1 ms (offsets 1 .. 2: 19.0), one image 32.9 -> 28.2 ms.
+                if (!acceptTiny)
+                  for (uint32_t dy = 1; dy <= kCentreAhead && oy + dy < by; dy++)
+                    for (uint32_t dx = 1; dx <= kCentreAhead && pfCol + dx < bx; dx++)
+                    {
+                      const char *qc = reinterpret_cast<const char *>(bits + ((size_t)(oy + dy) * bx + pfCol + dx) * kMatchWords);
+                      __builtin_prefetch(qc); __builtin_prefetch(qc + 47);
+                    }
                 pfAhead++;
               }
           };
