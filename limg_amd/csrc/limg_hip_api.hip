@@ -1513,14 +1513,20 @@ extern "C"
       // Everything the merge has published since the last look goes to the GPU.  mayWait: nothing is left to walk, so wait for the merge.  Called at the top of
       // every round AND between the pieces of a batch's chain walk: a batch's walk takes milliseconds, and what the merge publishes meanwhile should be on the GPU
       // (kernel latency: the life of its largest rectangle, 0.6-2 ms) before this thread comes looking for it -- not be enqueued when the walk is over.
-      auto enqueue_published = [&](bool mayWait)
+      // A kernel's duration is the life of its largest rectangle whatever the batch's size and the batches of a stream run one after the other, so a look from
+      // inside a walk (minNew > 0) takes a batch only when it is worth a launch; a look with nothing else to do takes whatever there is.
+      // (same-box A/B of these three and of the merge's first report, tools/r04/run38.sh: photo-noise 27.5-27.7 ms against 28.8-32.0 with "any size, looks every
+      //  8192 rectangles, first report at 4096", gradient 20.3-20.4 against 19.9-21.1)
+      constexpr size_t kWorthWithOneInFlight = 16384, kWorthFromInsideAWalk = 8192, kWalkPiece = 2048;
+      auto enqueue_published = [&](bool mayWait, size_t minNew = 0)
       {
         if (fin || queue.size() - head >= kInFlight) return;
         size_t r0 = 0, r1 = 0;
         {
           std::unique_lock<std::mutex> lk(pipe.m);
           if (mayWait) pipe.cv.wait(lk, [&] { return pipe.ready > issued || pipe.finished; });
-          if (pipe.ready > issued) { r0 = issued; r1 = pipe.ready - issued > kBatchRegions ? issued + kBatchRegions : pipe.ready; issued = r1; }
+          if (pipe.ready > issued && (pipe.ready - issued >= minNew || pipe.finished)) { r0 = issued; r1 = pipe.ready - issued > kBatchRegions ? issued + kBatchRegions : pipe.ready; issued = r1; }
+          else if (pipe.ready > issued) {}
           else fin = pipe.finished;
         }
         if (r1 <= r0) return;
@@ -1550,7 +1556,7 @@ extern "C"
       for (;;)
       {
         const clk::time_point w0 = clk::now();
-        enqueue_published(head == queue.size());
+        enqueue_published(head == queue.size(), head == queue.size() ? 0 : kWorthWithOneInFlight); // (with a batch in flight to wait for and walk, small change accumulates meanwhile)
         const clk::time_point w0b = clk::now();
         dbgEnqueue += ms(w0, w0b);
         // 2. the oldest batch in flight: its shift words are (about to be) back
@@ -1571,13 +1577,13 @@ extern "C"
             // count and place in the noise buffer go up (20 bytes per call) and k_noise_expand_calls produces the byte every pixel adds on the device.  (Rounds
             // 1-3 wrote the bytes here and uploaded them: 200 MB per 8192^2 image through this thread's store buffers and over PCIe.)
             const size_t call0 = callCount;
-            constexpr size_t kWalkPiece = 8192; // rectangles walked between two looks at what the merge has published (~0.5-2.5 ms of chain)
+            // (kWalkPiece rectangles between two looks at what the merge has published: 0.1-0.6 ms of chain)
             for (size_t w = pending.r0; ok && w < pending.r1; w += kWalkPiece)
             {
               const size_t n = pending.r1 - w < kWalkPiece ? pending.r1 - w : kWalkPiece;
               chain = chain_walk_batch(chain, n, reinterpret_cast<const uint8_t *>(&hOut[w].shiftWord), sizeof(RegionOut), npx.data() + w, noiseBase + w, callState, callOff, callPx,
                                        noiseOff, callCount, maxCalls, pcg);
-              if (w + n < pending.r1) enqueue_published(false);
+              if (w + n < pending.r1) enqueue_published(false, kWorthFromInsideAWalk);
             }
             const clk::time_point w2 = clk::now();
             const BlockedParams q = params_of(pending);

@@ -370,7 +370,8 @@ namespace limg_hip
     out.clear();
     out.reserve((size_t)blocksX * blocksY);
     size_t told = 0;
-    auto tell = [&](bool force) { if (progress && (force || out.size() - told >= 4096)) { told = out.size(); (*progress)(told); } };
+    // (the first report comes early: the consumer's pipeline -- a GPU round trip, then the serial chain walk that ends the call -- should start as soon as there is anything)
+    auto tell = [&](bool force) { if (progress && (force || out.size() - told >= (told == 0 ? 1024u : 4096u))) { told = out.size(); (*progress)(told); } };
     for (int tiny = 0; tiny < 2; tiny++)
     {
       uint32_t sx = 0, sy = 0;

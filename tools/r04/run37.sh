@@ -8,7 +8,7 @@ python bench.py --blocked --steps 8 --warmup 2 --contexts 4 > $O/bench_blocked.j
 python bench.py --blocked --steps 8 --warmup 2 --contexts 4 --workload random_gradient --no-cpu-baseline > $O/bench_blocked_rg.json 2>/dev/null
 python bench.py --blocked --steps 8 --warmup 2 --contexts 8 --no-cpu-baseline > $O/pn_c8.json 2>/dev/null
 python bench.py --blocked --steps 8 --warmup 2 --contexts 8 --workload random_gradient --no-cpu-baseline > $O/rg_c8.json 2>/dev/null
-LIMG_HIP_DEBUG_TIMELINE=1 python bench.py --blocked --steps 1 --warmup 2 --no-cpu-baseline > $O/tl.json 2> $O/tl.err; grep "^batch\|^merge" $O/tl.err | tail -30 > $O/timeline.txt; tail -3 $O/timeline.txt
+LIMG_HIP_DEBUG_TIMELINE=1 python bench.py --blocked --steps 1 --warmup 2 --no-cpu-baseline > $O/tl.json 2> $O/tl.err; grep "^batch\|^merge" $O/tl.err | tail -30 > $O/timeline.txt; tail -3 $O/timeline.txt; LIMG_HIP_DEBUG_TIMELINE=1 python bench.py --blocked --steps 1 --warmup 2 --no-cpu-baseline --workload random_gradient > $O/tlrg.json 2> $O/tlrg.err; grep "^batch\|^merge" $O/tlrg.err | tail -40 > $O/timeline_rg.txt
 python - "$O" <<'PY'
 import json, sys, glob, os
 for f in sorted(glob.glob(sys.argv[1] + "/*.json")):
