@@ -1273,8 +1273,8 @@ extern "C"
     std::vector<uint8_t> flags;
     if (pMatchBits)
     { // the per-seed viability flags the GPU kernel derives from the same bits (k_blocked_match)
-      flags.resize(blocksX * blocksY);
-      for (size_t i = 0; i < flags.size(); i++)
+      flags.resize(blocksX * blocksY + 16); // (+ 16: the merge's scan reads 16 flags at a time)
+      for (size_t i = 0; i < blocksX * blocksY; i++)
       {
         const uint64_t *w = pMatchBits + i * kMatchWords;
         auto bit = [&](int dx, int dy) -> unsigned { const int cell = (dy + kMatchLo) * kMatchSide + dx + kMatchLo; return (unsigned)(w[cell >> 6] >> (cell & 63)) & 1u; };
@@ -1358,7 +1358,7 @@ extern "C"
     if ((r = c->bMatch.ensure(blocks * kMatchWords * 8)) != limg_hip_success) return r;
     bp.matchBits = (unsigned long long *)c->bMatch.p;
     if ((r = c->bFlags.ensure(blocks)) != limg_hip_success) return r;
-    if ((r = c->hFlags.ensure(blocks)) != limg_hip_success) return r;
+    if ((r = c->hFlags.ensure(blocks + 16)) != limg_hip_success) return r; // (+ 16: the merge's scan reads 16 flags at a time)
     bp.matchFlags = (uint8_t *)c->bFlags.p;
     if (c->opt.test_blocked_no_bound == 0)
     {

@@ -321,6 +321,23 @@ namespace limg_hip
           };
           for (; ox < bx; ox++)
           {
+#if defined(__x86_64__) && !defined(LIMG_MERGE_NO_SIMD_SCAN)
+            // the next seed that is unused and flagged, sixteen at a time (both arrays carry 16 bytes of padding behind their last row; what a load takes from the
+            // next row is masked off): most seeds of a pass are skipped -- in use, or flagged hopeless -- and one branch per seed was a third of the merge
+            if (frow)
+            {
+              const __m128i needv = _mm_set1_epi8((char)need), zero = _mm_setzero_si128();
+              while (ox < bx)
+              {
+                const __m128i u = _mm_loadu_si128(reinterpret_cast<const __m128i *>(urow + ox)), f = _mm_loadu_si128(reinterpret_cast<const __m128i *>(frow + ox));
+                uint32_t cand = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(u, zero)) & ~(uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_and_si128(f, needv), zero)) & 0xFFFFu;
+                if (bx - ox < 16u) cand &= (1u << (bx - ox)) - 1u;
+                if (cand) { ox += (uint32_t)__builtin_ctz(cand); break; }
+                ox += 16u;
+              }
+              if (ox >= bx) break;
+            }
+#endif
             if (urow[ox]) continue;
             if (frow && !(frow[ox] & need)) continue; // cannot become a rectangle of the wanted kind whatever is in use: same outcome as growing and discarding
             if (pfCol <= ox) { pfCol = ox + 1; pfAhead = 0; } else if (pfAhead > 0) pfAhead--;
