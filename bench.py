@@ -39,7 +39,67 @@ VALU_FULL_RATE_PER_S = 960e9
 VALU_HALF_RATE_PER_S = 578e9
 
 
-PMC_ROUND = "r04"   # the round whose kernels this file benches: a counter entry measured on another round's build is refused (lines that quoted round-2 counters for round-3 kernels)
+PMC_ROUND = "r05"   # the round whose kernels this file benches: a counter entry measured on another round's build is refused (lines that quoted round-2 counters for round-3 kernels)
+
+
+# Every leg that fails is recorded here, printed on the line (`errors`) and turns the exit status non-zero: a bench line must not look healthy while one of its
+# legs raised (a look-back timeout sat in config.two_streams.error of three committed "final" lines and the process exited 0).
+ERRORS = []
+
+
+def leg_failed(leg, exc):
+    ERRORS.append({"leg": leg, "error": repr(exc)})
+    print("bench.py: leg %r FAILED: %r" % (leg, exc), file=sys.stderr, flush=True)
+    return {"error": repr(exc)}
+
+
+def _sha256(paths):
+    import hashlib
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            for chunk in iter(lambda: f.read(1 << 20), b""):
+                h.update(chunk)
+    return h.hexdigest()
+
+
+def source_sha():
+    """sha256 over the product's sources (limg_amd/csrc/*, include/*, limg_amd/build.py; sorted by name): identifies the code a line was measured on wherever
+    .git is absent (the GPU box gets a snapshot without it) and can be recomputed from any checkout."""
+    files = []
+    for d in ("limg_amd/csrc", "include"):
+        for f in sorted(os.listdir(os.path.join(ROOT, d))):
+            if f.endswith((".hip", ".h", ".hpp", ".cpp")):
+                files.append(os.path.join(ROOT, d, f))
+    files.append(os.path.join(ROOT, "limg_amd", "build.py"))
+    return _sha256(files)
+
+
+def provenance():
+    """What build a line was measured on: `lib_sha` = sha256 of the liblimg_hip.so that was loaded, `src_sha` = source_sha(), `head` = the git commit (from .git where
+    it exists, else from limg_amd/BUILD_STAMP.json, which tools/stamp.py writes before a gpurun call; null if neither)."""
+    import limg_amd
+    head = None
+    try:
+        import subprocess
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+        if head and subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "limg_amd", "include", "bench.py"], capture_output=True, text=True, timeout=10).stdout.strip():
+            head += "+dirty"
+    except Exception:
+        head = None
+    if not head:
+        try:
+            head = json.load(open(os.path.join(ROOT, "limg_amd", "BUILD_STAMP.json"))).get("head")
+        except Exception:
+            head = None
+    return {"head": head, "lib_sha": _sha256([limg_amd.LIB_PATH]), "src_sha": source_sha(), "bench_sha": _sha256([os.path.abspath(__file__)])[:16]}
+
+
+def emit(line):
+    """The ONE JSON line of rank 0: with the build's provenance and the list of failed legs.  A non-empty list also fails the process (see main)."""
+    line.update(provenance())
+    line["errors"] = list(ERRORS)
+    print(json.dumps(line), flush=True)
 
 
 def pmc_entry(key):
@@ -375,7 +435,7 @@ def run_sharded(args, g, dist, rank, world):
                          "note": "per launch pair = %s on rank 0: k_fit_tpb + k_encode_persistent; HIP events on the launch stream"
                                  % ("the rank's whole image list" if batched else "one image (config 4) / one strip (config 5)")},
         }
-        print(json.dumps(line), flush=True)
+        emit(line)
 
 
 BLOCKED_BYTES_PER_PIXEL = 4 + 4 * 9 + 4  # the RGBA pixel in; pDecoded, pShiftABCX, six colour planes, pBlockIndex (u32) and three factor planes + pBitsPerPixel (u8) out
@@ -490,8 +550,9 @@ def run_blocked(args, g, dist, rank, world, W, H):
                 line["cpu_baseline"] = {"value": round(n * n / dt / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": kind,
                                         "sample": "%dx%d of the same generator, limg_blocked_encode3d_test, single thread (upstream's merge and region stages are single-threaded)" % (n, n)}
             except Exception as e:
+                leg_failed("cpu_baseline", e)
                 line["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
-        print(json.dumps(line), flush=True)
+        emit(line)
 
 
 def run_stream(args, g, dist, rank, world, W, H):
@@ -554,7 +615,7 @@ def run_stream(args, g, dist, rank, world, W, H):
                          "kernels_ms": {"k_fit_tpb+k_encode_persistent": round(enc_ms, 4), "k_stream_count+scan+pack": round(pack_ms, 4), "k_stream_decode": round(dec_ms, 4)},
                          "note": "roofline object = k_stream_decode: (stream bytes + 4 B/px written) / its average duration"},
         }
-        print(json.dumps(line), flush=True)
+        emit(line)
 
 
 def limg_planes():
@@ -849,18 +910,19 @@ def main():
             try:  # what a service encoding a stream of images gets: two contexts on two HIP streams, images alternating (never `value`: the kernels overlap)
                 line["config"]["two_streams"] = two_stream_rate(g, img, planes, W, H, args)
             except Exception as e:
-                line["config"]["two_streams"] = {"error": repr(e)}
+                line["config"]["two_streams"] = leg_failed("two_streams", e)
         if n_gpus == 1 and not args.no_host_rate:
             try:
                 line["config"]["host_entry"] = host_entry_rate(g, W, H, args)
             except Exception as e:
-                line["config"]["host_entry"] = {"error": repr(e)}
+                line["config"]["host_entry"] = leg_failed("host_entry", e)
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(W, 1, height=H)
-            except Exception as e:  # the checker must never sink the measurement
+            except Exception as e:  # the checker does not void the measurement, but the line says so and the process fails
+                leg_failed("cpu_baseline", e)
                 line["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
-        print(json.dumps(line), flush=True)
+        emit(line)
     g.close()
     if dist is not None:
         dist.destroy_process_group()
@@ -881,9 +943,9 @@ def collective_evidence(g, dist, rank, world):
         g.comm_init_from_torch(dist)
         info = g.comm_info()
         g.comm_destroy()
-    except Exception as e:  # the evidence must never sink the measurement: an error here is reported on the line, the timed numbers stand
+    except Exception as e:  # reported on the line (and in `errors`); the timed numbers stand
         info = {"ranks": -1, "rank": rank, "rccl_version": -1}
-        ev["error"] = repr(e)
+        ev["error"] = leg_failed("collective_evidence", e)["error"]
     t = torch.tensor([info["ranks"], info["rank"], info["rccl_version"]], dtype=torch.int64, device="cuda")
     allv = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(allv, t)
@@ -920,8 +982,10 @@ def two_stream_rate(g, img, planes, W, H, args, n_images=12):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     g.check(); g2.check()
-    same = bool(torch.equal(planes["pDecoded"], planes2["pDecoded"]))
+    same = all(bool(torch.equal(planes[k], planes2[k])) for k in planes)  # every plane of the two contexts' last encodes
     g2.close()
+    if not same:
+        raise RuntimeError("two contexts on two streams produced different planes for the same image")
     return {"contexts": 2, "images": n_images, "ms_per_image": round(dt * 1e3 / n_images, 4), "Mpixels_per_s": round(n_images * W * H / dt / 1e6, 1), "outputs_identical": same}
 
 
@@ -950,3 +1014,5 @@ def host_entry_rate(g, W, H, args):
 
 if __name__ == "__main__":
     main()
+    if ERRORS:
+        sys.exit(3)

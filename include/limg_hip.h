@@ -86,6 +86,11 @@ typedef struct limg_hip_options
   int32_t test_fail_chain_phase1; /* test hook, non-0: limg_hip_encode3d_single_chain_device behaves as if this rank's E step had failed (abort rule below) */
   int32_t test_blocked_no_bound; /* test / A-B hook, non-0: the merged-block encoder's similarity kernel evaluates the 27-colour loop for every pair its early exits leave
                                   open, without the certain-match / certain-failure bounds in front of it (limg_hip_blocked.hip).  Same bits either way */
+  int32_t test_lookback_spins; /* test hook, 0 = default (2^22 polls, seconds): bound of one look-back wait of the persistent kernel */
+  int32_t test_base_error_strip; /* test hook, N > 0: work strip N - 1 of the persistent kernel dithers from a chain position that is off by one dither call (every other
+                                  strip is unaffected): the smallest possible look-back error, which the full-size reference hashes must catch (tests/test_gpu_fullsize.py) */
+  int32_t test_skip_publish_strip; /* test hook, N > 0: work strip N - 1 of the persistent kernel never publishes its dither-call count, i.e. the look-back of every
+                                  later strip of its chain times out (see limg_hip_check_device_status: such strips store nothing that depends on the chain) */
 } limg_hip_options;
 
 typedef struct limg_hip_context limg_hip_context;

@@ -484,7 +484,6 @@ namespace
       p.ticket = (uint32_t *)c->lookback.p;
       p.desc = (unsigned long long *)((uint8_t *)c->lookback.p + 16);
       p.zeroLookback = p.prefit ? 1 : 0;
-      p.ticketStart = 0; // (set per launch below, where the workgroup count is known)
       if (!p.prefit) HIP_TRY(hipMemsetAsync(c->lookback.p, 0, 16 + strips * 8, stream));
       if (!c->devStatus.p)
       {
@@ -492,6 +491,9 @@ namespace
         HIP_TRY(hipMemsetAsync(c->devStatus.p, 0, 16, stream));
       }
       p.timeout = (uint32_t *)c->devStatus.p;
+      p.lookbackSpins = c->opt.test_lookback_spins > 0 ? (uint32_t)c->opt.test_lookback_spins : (1u << 22);
+      p.testSkipStrip = c->opt.test_skip_publish_strip > 0 ? (uint32_t)c->opt.test_skip_publish_strip - 1u : ~0u;
+      p.testBaseErrStrip = c->opt.test_base_error_strip > 0 ? (uint32_t)c->opt.test_base_error_strip - 1u : ~0u;
       p.compactOut = compact != nullptr || wantStats; // the statistics are reduced from the raster-order shift words
       if ((r = c->park.ensure((size_t)(c->persistentWorkgroups / 5 * 6) * 2 * 8192)) != limg_hip_success) return r; // 6 workgroups per CU: the kernel's launch bound
       p.park = (uint8_t *)c->park.p;
@@ -517,7 +519,8 @@ namespace
       // A/B hook (limg_hip_options.test_pipeline): bits 0..3 = 1 + k_fit_tpb's wave priority, bits 4..7 = workgroups per CU of the overlapped persistent launches,
       // bits 8..15 = images of the first sub-batch (whose float stage runs alone)
       const uint32_t knobs = (uint32_t)c->opt.test_pipeline;
-      const int fitPrio = (knobs & 15u) ? (int)(knobs & 15u) - 1 : 0, wgOverlap = ((knobs >> 4) & 15u) ? (int)((knobs >> 4) & 15u) : 5;
+      const int fitPrio = (knobs & 15u) ? (int)(knobs & 15u) - 1 : 0, wgOverlapRaw = ((knobs >> 4) & 15u) ? (int)((knobs >> 4) & 15u) : 5,
+                wgOverlap = wgOverlapRaw > 6 ? 6 : wgOverlapRaw; // never above the launch bound the park slots are sized for
       const size_t firstSub = ((knobs >> 8) & 255u) && ((knobs >> 8) & 255u) < subImages ? (size_t)((knobs >> 8) & 255u) : subImages;
       const size_t nSub = 1 + (batchCount - firstSub + subImages - 1) / subImages;
       if ((r = ensure_pipe_events(c, 2 * nSub + 1)) != limg_hip_success) return r;
@@ -532,8 +535,6 @@ namespace
         uint8_t *lb = (uint8_t *)c->lookback.p + k * 16 + i0 * imgStrips * 8; // sub-batch k: its ticket, then the descriptors of its strips
         q.ticket = (uint32_t *)lb; q.desc = (unsigned long long *)(lb + 16);
         q.fitPrio = k == 0 ? 0 : fitPrio;
-        const size_t wgs = (size_t)(c->persistentWorkgroups / 5 * (k + 1 < nSub ? wgOverlap : wg_per_cu(6))), stripsK = n * imgStrips;
-        q.ticketStart = (uint32_t)(stripsK < wgs ? stripsK : wgs); // = the grid launch_encode_persistent gives this sub-batch
         return q;
       };
       hipStream_t fs = c->fitStream;
@@ -561,11 +562,6 @@ namespace
       return stats();
     }
 
-    if (fused && p.prefit)
-    { // the ticket starts at the persistent launch's workgroup count (k_fit_tpb writes it): workgroup i takes strip i without an atomic
-      const size_t wgs = (size_t)(c->persistentWorkgroups / 5 * wg_per_cu(6));
-      p.ticketStart = (uint32_t)(strips < wgs ? strips : wgs);
-    }
     if (p.prefit && chainPhase != 2)
     {
       mark_if(1);

@@ -114,7 +114,7 @@ namespace limg_hip
       if (p.zeroLookback)
       { // this wave's 64 blocks are two work strips of the persistent kernel: clear their look-back descriptors (and, once, the ticket) instead of a memset launch
         if ((uint32_t)lane < 2u && unit * 2u + (uint32_t)lane < p.stripsX) p.desc[(size_t)byS * p.stripsX + unit * 2u + (uint32_t)lane] = 0ull;
-        if (unitId == 0 && lane < 4) p.ticket[lane] = lane == 0 ? p.ticketStart : 0u;
+        if (unitId == 0 && lane < 4) p.ticket[lane] = 0u;
       }
 
       // ---- stage the 8 pixel rows (coalesced 16 bytes per lane) into the block-major layout ----

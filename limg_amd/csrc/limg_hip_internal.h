@@ -59,8 +59,10 @@ namespace limg_hip
     unsigned long long *desc;
     uint32_t *ticket;   // [0] = next strip id
     int32_t zeroLookback; // k_fit_tpb clears `ticket` (16 bytes) and the descriptors of the strips its waves cover (the persistent launch follows it on the stream)
-    uint32_t ticketStart; // ... and starts the ticket at this value: the persistent launch's workgroup count -- workgroup i takes strip i without asking (one atomic round trip less per workgroup); 0: every ticket is drawn
     uint32_t *timeout;  // sticky: set when a look-back spin gave up; lives outside the per-launch words, cleared only by limg_hip_check_device_status
+    uint32_t lookbackSpins; // bound of one look-back wait, in polls (2^22 ~ seconds; limg_hip_options.test_lookback_spins lowers it)
+    uint32_t testBaseErrStrip; // test hook: the strip with this id dithers from a chain position that is off by one call (~0: none); its published count stays right
+    uint32_t testSkipStrip; // test hook: the strip with this id never publishes its dither-call count (~0: none) -- what a lost predecessor looks like to the look-back
     uint8_t *park;      // persistent kernel: per workgroup two 8 KiB slots holding a strip's parked results between its E and F steps
     int32_t compactOut; // persistent kernel: also write records / shift words to the raster-order arrays
     int32_t streamRaw;  // compact mode only: factors with shift 8 store their raw byte instead of 0 (input of the stream packer)

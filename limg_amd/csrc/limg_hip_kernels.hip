@@ -32,8 +32,6 @@
 //     chains at once instead of a 64-step dependent chain per block;
 //   * correctly rounded division (hipcc default), once per batch and lane-parallel; round-to-nearest-even conversions.
 #include "limg_hip_device.h"
-#include <stdio.h>
-#include <stdlib.h>
 #include "limg_search_table.h"
 
 #include <type_traits>
@@ -871,11 +869,20 @@ namespace limg_hip
 
     // ---- decoupled look-back over the per-strip dither-call counts (fused path) ------------------------------------------
     // One 8-byte descriptor per work strip: value in the low word, status in the high word (0 = nothing yet, 1 = this strip's
-    // own count, 2 = inclusive count of the chain up to and including this strip).  Written and read with relaxed agent-scope
-    // 8-byte atomics only: value and status travel in one granule, so no other ordering is needed.  Strip ids are handed out
-    // by a ticket, so every predecessor of a running workgroup has itself started (and never waits on a successor): the
-    // look-back always terminates.  The spin is bounded all the same; a timeout raises the context's sticky status word and the kernel finishes.
+    // own count, 2 = inclusive count of the chain up to and including this strip; the inclusive VALUE kBasePoison = a look-back
+    // gave up here or earlier in the chain).  Written and read with relaxed agent-scope 8-byte atomics only: value and status travel in one granule, so no other ordering is needed.
+    // Progress: EVERY strip id is drawn from the atomic ticket by a workgroup that is already running (k_encode_persistent), so
+    // the holders of all smaller ids are resident whatever else shares the GPU -- other contexts' persistent kernels included --
+    // and each of them publishes its count at the end of an E step, which never waits.  A look-back therefore terminates
+    // without any assumption about how many workgroups of the grid are resident.  (Reference: strips on a thread pool always
+    // complete and the entry points are re-entrant, src/limg.cpp:1890-1893, :2131-2136.)
+    // The spin is bounded all the same (a protocol bug must not hang the GPU).  A timeout is LOUD: the strip raises the
+    // context's sticky status word, publishes the poison value as its inclusive count and stores none of its chain-dependent planes;
+    // every later strip of the chain finds the poison at once (no second spin), hands it on and stores nothing either.  (A poison STATUS of
+    // its own, tested with one more ballot per poll, cost the 4-channel kernel two spilled VGPRs at its 80-register limit; the value does not.)  The host-pointer entries and
+    // limg_hip_check_device_status then return limg_hip_error_Generic.
     constexpr uint32_t kDescAggregate = 1u, kDescInclusive = 2u;
+    constexpr uint32_t kBasePoison = 0xFFFFFFFFu; // (a chain has < 2^26 dither calls: 3 per block)
 
     __device__ __forceinline__ void desc_store(unsigned long long *d, uint32_t status, uint32_t value)
     {
@@ -886,7 +893,7 @@ namespace limg_hip
       return __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
-    // called by all 64 lanes of one wave; returns the number of dither calls of the chain before strip `id`
+    // called by all 64 lanes of one wave; returns the number of dither calls of the chain before strip `id`, or kBasePoison
     template <class P>
     __device__ __forceinline__ uint32_t lookback_base(const P &p, uint32_t id, uint32_t headId, uint32_t agg, int lane)
     {
@@ -912,16 +919,17 @@ namespace limg_hip
             if (incl)
             {
               const int fl = __builtin_ctzll(incl);
+              const uint32_t vi = (uint32_t)__builtin_amdgcn_readlane((int)v, fl);
               base += wave_sum(lane <= fl ? v : 0u);
-              return base;
+              return vi == kBasePoison ? kBasePoison : base; // (a poisoned predecessor publishes "inclusive, kBasePoison")
             }
             base += wave_sum(v);
             break;
           }
-          if (++spins > (1u << 22))
+          if (++spins > p.lookbackSpins)
           {
             if (lane == 0) atomicExch(p.timeout, 1u);
-            return base;
+            return kBasePoison;
           }
           __builtin_amdgcn_s_sleep(2);
         }
@@ -1485,11 +1493,12 @@ namespace limg_hip
             c = c < p.chainCount - 1 ? c : p.chainCount - 1;
             headId = head0 + c * p.chainRows * p.stripsX;
           }
-          if (id == headId) desc_store(p.desc + id, kDescInclusive, agg);
+          if (id == p.testSkipStrip) {} // (test hook: a strip that never publishes)
+          else if (id == headId) desc_store(p.desc + id, kDescInclusive, agg);
           else
           {
             const unsigned long long d = desc_load(p.desc + id - 1);
-            if ((uint32_t)(d >> 32) == kDescInclusive) desc_store(p.desc + id, kDescInclusive, (uint32_t)d + agg);
+            if ((uint32_t)(d >> 32) == kDescInclusive) desc_store(p.desc + id, kDescInclusive, (uint32_t)d == kBasePoison ? kBasePoison : (uint32_t)d + agg);
             else desc_store(p.desc + id, kDescAggregate, agg);
           }
         }
@@ -1657,12 +1666,13 @@ namespace limg_hip
           const uint32_t w = lane < kStripBlocks ? L.shift[lane] : 0u;
           const uint32_t agg = wave_sum(w >> 24);
           const unsigned long long own = desc_load(p.desc + id);
-          if ((uint32_t)(own >> 32) == kDescInclusive) base = (uint32_t)sgpr((int)((uint32_t)own - agg));
+          if ((uint32_t)(own >> 32) == kDescInclusive) base = (uint32_t)sgpr((int)((uint32_t)own == kBasePoison ? kBasePoison : (uint32_t)own - agg));
           else
           {
             base = lookback_base(p, id, headId, agg, lane);
-            if (lane == 0) desc_store(p.desc + id, kDescInclusive, base + agg);
+            if (lane == 0 && id != p.testSkipStrip) desc_store(p.desc + id, kDescInclusive, base == kBasePoison ? kBasePoison : base + agg);
           }
+          if (id == p.testBaseErrStrip) base += 1u; // (test hook: this strip alone dithers from the wrong place)
         }
         else
         {
@@ -1672,6 +1682,7 @@ namespace limg_hip
         phase_f_first_calls(L, base, lane);
       }
       __syncthreads();
+      if (PERSIST && L.first[0] == kBasePoison) return; // the look-back gave up (status word raised): nothing that depends on the chain position is stored
       if (rowsPath) phase_f_rows<CH>(p, io, L, strip, x0, y0, lane, wave, [&]() { if (p.fullPlanes) phase_f_store_const(p, io, L, x0, y0, ry, lane, wave, 2u); });
       else phase_f_pixels<CH>(p, io, L, strip, x0, y0, ry, lane, wave, tid);
     }
@@ -1701,7 +1712,8 @@ namespace limg_hip
     // The one-iteration lag means that by the time an F step asks for its strip's position in the dither chain, every
     // earlier strip has long published its call count, so the look-back does not wait; and since the workgroups of a CU
     // drift apart, E and F steps of different workgroups overlap on every CU.
-    // Progress: a look-back only waits for strips with smaller tickets; those were drawn earlier, and an E step never waits.
+    // Progress: a look-back only waits for strips with smaller tickets; those were drawn earlier by workgroups that are running, and an E step never waits
+    // (see "decoupled look-back" above: no strip id is ever derived from blockIdx).
     template <int CH, bool FAST, bool PREFIT, bool ACC>
 #ifndef LIMG_ACC_WG
 #define LIMG_ACC_WG 6
@@ -1728,17 +1740,16 @@ namespace limg_hip
       // by slot, so slot k (= blockIdx.x / 256) starts k * 3.4 us late: measured -0.5 % on the kernel, and harmless where the placement differs.
       for (uint32_t i = 0; i < (blockIdx.x >> 8); i++) __builtin_amdgcn_s_sleep(127);
       __builtin_amdgcn_s_setprio(LIMG_PRIO_E);
-      bool first = kargs->ticketStart != 0u; // the ticket counter starts at the grid size: workgroup i's first strip is strip i, no atomic needed
       for (;;)
       {
         __syncthreads(); // the previous step's LDS use is over (and the rsqrt table is in place)
-        if (!first)
-        {
-          if (tid == 0) s_ticket = atomicAdd(p.ticket, 1u);
-          __syncthreads();
-        }
-        const uint32_t t = first ? blockIdx.x : (uint32_t)sgpr((int)s_ticket);
-        first = false;
+        // EVERY strip id is drawn from the ticket, the first one included: a workgroup that holds id t is resident, and so is the holder of every id < t (it drew
+        // earlier).  Round 4 let workgroup i take strip i without asking (one atomic round trip less per workgroup): with a second persistent kernel on the GPU
+        // (another context's stream) a resident workgroup then waited for strips of workgroups that were never dispatched, and both kernels spun into the
+        // look-back's bound.  Never derive a strip id from blockIdx.
+        if (tid == 0) s_ticket = atomicAdd(p.ticket, 1u);
+        __syncthreads();
+        const uint32_t t = (uint32_t)sgpr((int)s_ticket);
         int tid_e = tid;
         asm volatile("" : "+v"(tid_e));
         KernArgs *pe = kargs;
@@ -1805,11 +1816,6 @@ namespace limg_hip
   {
     const uint32_t strips = p.imageStrips * p.batchCount;
     const dim3 grid(strips < (uint32_t)workgroups ? strips : (uint32_t)workgroups), block(kThreads);
-    if (p.ticketStart != 0u && p.ticketStart != grid.x)
-    { // internal invariant (the host computes both from the same numbers): a ticket that does not start at the grid size would skip or repeat strips
-      fprintf(stderr, "limg_hip: ticket start %u != persistent grid %u\n", p.ticketStart, grid.x);
-      abort();
-    }
     LIMG_DISPATCH(k_encode_persistent, grid, block, s, p);
   }
 

@@ -29,6 +29,22 @@ def test_full_image_hashes(oracle, name):
     assert psnr == pytest.approx(e["psnr"], abs=1e-9) and mse == pytest.approx(e["mse"], rel=1e-12)
 
 
+@pytest.mark.parametrize("name", ["rg4096", "rg4096_pool2", "pn16384x2048_pool2"])
+def test_fullsize_hashes(oracle, name):
+    """BASELINE sizes: the oracle against the real reference's plane hashes of tests/golden/fullsize.json (tools/make_golden_fullsize.py) -- config 2's 4096^2
+    gradient image with one chain and with eight, and strip 0 of config 5.  (The 8192^2 entries take the scalar oracle a minute each; the GPU tests hash those.)"""
+    import json
+    import os
+    e = json.load(open(os.path.join(gu.G, "fullsize.json")))[name]
+    img = oracle.photo_noise(e["w"], e["h"], e["seed"]) if e["gen"] == "pn" else oracle.random_gradient(e["w"], e["h"], e["seed"], True)
+    assert oracle.fnv(img) == e["input"]
+    o = oracle.encode3d(img, e["alpha"], worker_threads=8, **e["kw"])
+    for k in PLANES:
+        assert oracle.fnv(o[k]) == e["planes"][k], k
+    psnr, _ = oracle.compare(img, o["pDecoded"], e["alpha"])
+    assert psnr == pytest.approx(e["psnr"], abs=1e-9)
+
+
 def test_config1_psnr_baseline(oracle):
     """BASELINE.json configs[0]: assets/original.png, RGB, single thread: perceptual PSNR 40.6994 dB."""
     img = gu.load_png()
