@@ -154,8 +154,12 @@ double limg_hip_compare_device(limg_hip_context *pCtx, const uint32_t *pImageA, 
 limg_hip_result limg_hip_synth_random_gradient_device(uint32_t *pOut, size_t width, size_t height, uint64_t seed, int opaque, size_t y0, void *stream);
 limg_hip_result limg_hip_synth_photo_noise_device(uint32_t *pOut, size_t width, size_t height, uint64_t seed, size_t y0, void *stream);
 
-/* Waits for the device and returns limg_hip_error_Generic if the fused kernel's bounded look-back spin ever timed out
- * (protocol safety net; the host-pointer entry points call it themselves). */
+/* Waits for the device and returns limg_hip_error_Generic if the persistent kernel's bounded look-back wait ever timed out (protocol safety net; the host-pointer
+ * entry points call it themselves and return the error).  Such a timeout is never silent: the strip that gave up and every later strip of its dither chain store
+ * NOTHING that depends on the chain position -- their pDecoded / pFactorsA/B/C pixels keep what the caller's buffers held, the block-uniform planes may be partly
+ * written -- so a caller of the asynchronous *_device entries that skips this check cannot end up with wrongly dithered planes that look complete.
+ * Progress does not depend on what else runs on the GPU: every work strip id is drawn from an atomic ticket by a workgroup that is already resident, so any number
+ * of contexts may have persistent kernels in flight on their own streams at once (tests/test_gpu_concurrency.py). */
 limg_hip_result limg_hip_check_device_status(limg_hip_context *pCtx);
 
 /* The statistics the reference's limg_encode3d_test / limg_blocked_encode3d_test print themselves (src/limg.cpp:2232-2248; counters :1971-1999, :1561-1590):

@@ -1682,7 +1682,8 @@ namespace limg_hip
         phase_f_first_calls(L, base, lane);
       }
       __syncthreads();
-      if (PERSIST && L.first[0] == kBasePoison) return; // the look-back gave up (status word raised): nothing that depends on the chain position is stored
+      if (PERSIST && L.first[0] == kBasePoison) return; // the look-back gave up (status word raised): nothing that depends on the chain position is stored (completing the
+                                                        // block-uniform planes' rows 4..7 here costs the 4-channel kernel two spilled VGPRs: they stay half written, the call has failed anyway)
       if (rowsPath) phase_f_rows<CH>(p, io, L, strip, x0, y0, lane, wave, [&]() { if (p.fullPlanes) phase_f_store_const(p, io, L, x0, y0, ry, lane, wave, 2u); });
       else phase_f_pixels<CH>(p, io, L, strip, x0, y0, ry, lane, wave, tid);
     }
