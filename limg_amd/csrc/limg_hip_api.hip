@@ -95,6 +95,8 @@ struct limg_hip_context
   hipStream_t fitStream = nullptr;               // batched encode in sub-batches: k_fit_tpb of sub-batch k + 1 runs here, next to the persistent kernel of sub-batch k
   std::vector<hipEvent_t> pipeEvents;            // ... and the events that fork it from / join it to the caller's stream
   HostBuf hStage;                                // pinned staging of the ragged paths' host step (shift words down; chain bases and noise up)
+  hipEvent_t hStageEvent = nullptr;              // ... recorded behind the last asynchronous H2D copy that reads it: waited for before it is written, grown or freed again
+  bool hStageBusy = false;
   DevBuf stats;                                  // limg_hip_options.collect_stats: the reference's 3 + 27 bit counters of the last encode
   hipStream_t statsStream = nullptr;
   int statsState = 0;                            // 0 = none, 1 = on the device (8x8 path), 2 = in statsHost (merged-block encoder)
@@ -145,6 +147,18 @@ struct limg_hip_context
 
 namespace
 {
+  // Developer print-outs of the merged-block encoder's pipeline (stderr): compile-time switches (-DLIMG_HIP_DEBUG_TIMELINE / -DLIMG_HIP_DEBUG_TIMING through
+  // limg_amd.build.build(extra_flags=...)), never the environment -- the shipped library reads no environment variable and prints nothing on success.
+#ifdef LIMG_HIP_DEBUG_TIMELINE
+  constexpr bool kDebugTimeline = true;
+#else
+  constexpr bool kDebugTimeline = false;
+#endif
+#ifdef LIMG_HIP_DEBUG_TIMING
+  constexpr bool kDebugTiming = true;
+#else
+  constexpr bool kDebugTiming = false;
+#endif
   constexpr size_t kNoiseChunk = 1u << 16; // table growth granularity (entries)
 
   // The accurate search's automaton (tools/make_search_table.py, src/limg_bit_crush.h:668-830) in the form the kernel's scalar loads want: 8 dwords per state,
@@ -619,6 +633,9 @@ namespace
       // into the call's 64 noise bytes on the device; rounds 1-3 uploaded the 64 bytes).
       const size_t maxCalls = blocks * 3;
       const size_t offPrev = (blocks * 4 + 15) & ~(size_t)15, offBase = offPrev + 16, offStates = (offBase + strips * 4 + 15) & ~(size_t)15, offPixels = offStates + maxCalls * 8;
+      // the previous ragged encode's H2D copies out of this buffer were asynchronous -- possibly on another stream: they must have read it before it is rewritten
+      // or reallocated
+      if (c->hStageBusy) { HIP_TRY(hipEventSynchronize(c->hStageEvent)); c->hStageBusy = false; }
       if ((r = c->hStage.ensure(offPixels + maxCalls + 16)) != limg_hip_success) return r;
       uint32_t *hShifts = (uint32_t *)c->hStage.p;
       unsigned long long *hPrev = (unsigned long long *)((uint8_t *)c->hStage.p + offPrev);
@@ -649,7 +666,11 @@ namespace
         launch_noise_expand((uint8_t *)c->noiseDyn.p, (const unsigned long long *)c->noiseStates.p, (const uint8_t *)c->noiseStates.p + totalCalls * 8, totalCalls, pcg, stream);
       }
       HIP_TRY(hipMemcpyAsync(p.stripBase, hBase, strips * 4, hipMemcpyHostToDevice, stream));
-      // (the staging buffer is the context's: the next encode that uses it synchronises with this stream before it writes -- see the D2H above)
+      // the staging buffer is the context's: the event marks the point where these copies have read it (waited for above by the next encode that uses it, on
+      // whatever stream, and by limg_hip_shutdown)
+      if (!c->hStageEvent) HIP_TRY(hipEventCreateWithFlags(&c->hStageEvent, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(c->hStageEvent, stream));
+      c->hStageBusy = true;
       p.noise = (const uint8_t *)c->noiseDyn.p;
       p.noiseLast = (uint32_t)totalCalls;
     }
@@ -752,7 +773,8 @@ extern "C"
     for (DevBuf *b : bufs) b->release();
     HostBuf *hbufs[] = { &c->hFlags, &c->hRec, &c->hBits, &c->hDesc, &c->hOut, &c->hNoise, &c->hNoiseBase };
     for (HostBuf *b : hbufs) b->release();
-    c->hStage.release();
+    c->hStage.release(); // (the device is idle: hipDeviceSynchronize above)
+    if (c->hStageEvent) (void)hipEventDestroy(c->hStageEvent);
     if (c->fitStream) (void)hipStreamDestroy(c->fitStream);
     for (hipEvent_t e : c->pipeEvents) (void)hipEventDestroy(e);
     if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
@@ -1493,7 +1515,7 @@ extern "C"
       // shift words back, one event per batch, up to kInFlight batches), and the chain -- this thread's real work, serial by construction -- is walked batch by batch
       // in creation order as the results arrive.  (Rounds 2-3 kept one batch in flight: every batch's GPU round trip was waited for, 11-20 ms per image.)
       struct Batch { size_t r0 = 0, r1 = 0; size_t ev = 0; double tq = 0; };
-      const bool dbgTimeline = getenv("LIMG_HIP_DEBUG_TIMELINE") != nullptr;
+      constexpr bool dbgTimeline = kDebugTimeline;
       std::vector<Batch> queue; // FIFO: [head, queue.size())
       size_t head = 0, issued = 0, evNext = 0;
       uint64_t chain = kDitherSeed, noiseOff = 0;
@@ -1652,9 +1674,9 @@ extern "C"
     }
     c->blockedKernelMs[2] = kernelMs[0]; c->blockedKernelMs[3] = kernelMs[1];
     c->blockedMs[0] = ms(t0, t1); c->blockedMs[1] = ms(t1, t2); c->blockedMs[2] = busy[0]; c->blockedMs[3] = busy[1]; c->blockedMs[4] = busy[2]; c->blockedMs[5] = ms(t0, t5);
-    if (getenv("LIMG_HIP_DEBUG_TIMELINE")) fprintf(stderr, "merge from %.2f to %.2f, call ended %.2f\n", ms(t0, t1), ms(t0, t2), ms(t0, t5));
-    if (getenv("LIMG_HIP_DEBUG_TIMING")) fprintf(stderr, "merge waited %.2f ms for similarity-bit bands; ", bandWaitMs);
-    if (getenv("LIMG_HIP_DEBUG_TIMING")) fprintf(stderr, "worker: %d batches, enqueue %.2f ms, event wait %.2f ms, chain %.2f ms, store enqueue %.2f ms\n", dbgBatches, dbgEnqueue, dbgWait, busy[1], busy[2]);
+    if (kDebugTimeline) fprintf(stderr, "merge from %.2f to %.2f, call ended %.2f\n", ms(t0, t1), ms(t0, t2), ms(t0, t5));
+    if (kDebugTiming) fprintf(stderr, "merge waited %.2f ms for similarity-bit bands; ", bandWaitMs);
+    if (kDebugTiming) fprintf(stderr, "worker: %d batches, enqueue %.2f ms, event wait %.2f ms, chain %.2f ms, store enqueue %.2f ms\n", dbgBatches, dbgEnqueue, dbgWait, busy[1], busy[2]);
     if (mergeFailed) return limg_hip_error_MemoryAllocationFailure;
     if (bandError) return limg_hip_error_Generic;
     if (workerResult == limg_hip_success && c->opt.collect_stats)

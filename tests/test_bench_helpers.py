@@ -41,3 +41,53 @@ def test_size_argument_forms():
     assert bench.parse_size(4096) == (4096, 4096)
     assert bench.parse_size("8192x8190") == (8192, 8190)
     assert bench.parse_size("1024x618") == (1024, 618)
+
+
+def test_failed_leg_is_on_the_line_and_fails_the_process(capsys, monkeypatch):
+    """a look-back timeout sat in config.two_streams.error of three committed lines while bench.py exited 0.  Now every failed leg is in `errors`,
+    and a non-empty list turns the exit status non-zero (bench.py's __main__)."""
+    monkeypatch.setattr(bench, "ERRORS", [])
+    monkeypatch.setattr(bench, "provenance", lambda: {"head": "x", "lib_sha": "y", "src_sha": "z", "bench_sha": "w"})
+    r = bench.leg_failed("two_streams", RuntimeError("boom"))
+    assert "boom" in r["error"]
+    bench.emit({"metric": "m", "config": {"two_streams": r}})
+    out = capsys.readouterr()
+    line = json.loads(out.out.strip())
+    assert line["errors"] == [{"leg": "two_streams", "error": "RuntimeError('boom')"}] and line["lib_sha"] == "y"
+    assert "FAILED" in out.err
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "if ERRORS:\n        sys.exit(3)" in src
+
+
+def test_source_sha_is_stable_and_sees_the_kernels():
+    a = bench.source_sha()
+    assert a == bench.source_sha() and len(a) == 64
+
+
+def _final_lines():
+    import glob
+    out = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_bench_final*.json"))):
+        for raw in open(f):
+            if raw.strip().startswith("{"):
+                out.append((os.path.basename(f), json.loads(raw)))
+    return out
+
+
+def test_final_bench_lines_are_one_build_without_failed_legs():
+    """Evidence that cannot go stale silently: every `profiles/r05_bench_final*.json` line carries the build it was measured on; all of them were measured on ONE
+    build (same lib_sha, same src_sha) and none has a failed leg or an "error" anywhere."""
+    lines = _final_lines()
+    assert lines, "no profiles/r05_bench_final*.json yet"
+    shas = {(l.get("lib_sha"), l.get("src_sha")) for _, l in lines}
+    assert len(shas) == 1 and None not in next(iter(shas)), shas
+    for name, l in lines:
+        assert l.get("errors") == [], (name, l.get("errors"))
+        assert '"error"' not in json.dumps(l), name
+        assert l.get("head"), name
+
+
+def test_profiles_index_is_current():
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "profiles_index.py"), "--check"])
+    assert r.returncode == 0, "profiles/README.md's round-5 index is out of date: run python tools/profiles_index.py"
