@@ -267,15 +267,26 @@ def run_sharded(args, g, dist, rank, world):
     torch.cuda.synchronize()
 
     single_chain = args.config == 5 and args.single_chain
+    chain_over_gloo = False
     if single_chain:
         if world == 1:  # a communicator of one rank: the exchange degenerates to a copy (what a one-GPU box can run)
             g.comm_init(g.comm_unique_id(), 0, 1)
-        elif dist is None or dist.get_backend() != "nccl":
-            raise SystemExit("--single-chain: one strip per rank over RCCL; its exchange-free halves are covered by tests/test_gpu_collective.py")
+        elif dist is None:
+            raise SystemExit("--single-chain with several ranks needs torch.distributed")
+        elif dist.get_backend() != "nccl":
+            # REHEARSAL (--share-gpus: several ranks on one card; RCCL refuses duplicate devices): the same chain through the entry's two exchange-free halves
+            # (limg_hip_encode3d_chain_device), the 8-byte counts all-gathered over gloo, the bases by limg_hip_host_chain_bases -- the arithmetic k_chain_base does on
+            # the device.  Every rank is its own process with its own context: their persistent / split kernels share the one GPU.
+            chain_over_gloo = True
+            name += " [REHEARSAL: ranks share a GPU, the 8-byte exchange over gloo instead of RCCL]"
         else:
             g.comm_init_from_torch(dist)
         g._comm_ready = True
         before = [(y0 // 8) * (W // 8) for (y0, _) in strips]
+        if chain_over_gloo:
+            import limg_amd
+            d_calls = torch.zeros(1, dtype=torch.int64, device="cuda")
+            d_base = torch.zeros(1, dtype=torch.int64, device="cuda")
 
     # --contexts K (config 4): the rank's images go round-robin over K contexts, each on a HIP stream of its own -- the next image's float-stage kernel fills the
     # CUs that the previous image's persistent kernel leaves idle while its last strips drain (a 4096^2 image is only ~5 strips per workgroup)
@@ -301,7 +312,15 @@ def run_sharded(args, g, dist, rank, world):
             g.encode3d_batch_device([u[0] for u in units], True, [u[1] for u in units], error_factor=args.error_factor, pool_threads=0, fast=True)
             return
         for i, (img, planes) in enumerate(units):
-            if single_chain:  # ONE dither chain through the 8 strips (== the reference with pThreadPool == nullptr): an 8-byte all-gather between E and F step
+            if single_chain and chain_over_gloo:
+                g.encode3d_chain_device(img, True, planes, 1, calls=d_calls, blocks_before=before[rank], error_factor=args.error_factor)
+                mine_calls = d_calls.cpu()  # (waits for the E step + scan)
+                allc = [torch.zeros_like(mine_calls) for _ in range(world)]
+                dist.all_gather(allc, mine_calls)
+                bases = limg_amd.host_chain_bases(np.array([int(c.item()) for c in allc], dtype=np.uint64))
+                d_base.fill_(int(bases[rank]))
+                g.encode3d_chain_device(img, True, planes, 2, base=d_base, blocks_before=before[rank], error_factor=args.error_factor)
+            elif single_chain:  # ONE dither chain through the 8 strips (== the reference with pThreadPool == nullptr): an 8-byte all-gather between E and F step
                 g.encode3d_single_chain_device(img, True, planes, before[rank], error_factor=args.error_factor)
             elif len(ctxs) > 1:
                 with torch.cuda.stream(streams[i % len(ctxs)]):
@@ -330,11 +349,18 @@ def run_sharded(args, g, dist, rank, world):
         elapsed = float(t.item())
     torch.cuda.synchronize()
     g.check()
-    if single_chain:
+    if single_chain and chain_over_gloo:
+        t = torch.tensor([rank], dtype=torch.int64)
+        views = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(views, t)
+        collective = {"backend": "gloo", "world_size": world, "rccl_version": None, "comm_ranks": len({int(v.item()) for v in views}),
+                      "note": "rehearsal: the ranks are processes sharing one GPU; the chain's 8-byte exchange went through gloo + limg_hip_host_chain_bases"}
+    elif single_chain:
         info = g.comm_info()
         collective = {"backend": None if dist is None else dist.get_backend(), "world_size": world, "rccl_version": info["rccl_version"], "comm_ranks": info["ranks"]}
     else:
         collective = collective_evidence(g, dist, rank, world)
+    golden = verify_golden(args, units, rows, rank, world, dist, single_chain, W, H, kind) if args.verify_golden else None
 
     # reassembly on rank 0 (config 5: the strips of the one image; config 4: every image's planes), timed apart
     gather_ms = None
@@ -421,7 +447,7 @@ def run_sharded(args, g, dist, rank, world):
             "config": {"workload": name + ", errorFactor %d, fast bit-crush" % args.error_factor,
                        "parallelism": "no data-path collective; plane reassembly on rank 0 timed apart",
                        "gather_ms": None if gather_ms is None else round(gather_ms, 3), "gathered_bytes_rank0": gathered_bytes,
-                       "collective": collective,
+                       "collective": collective, "golden": golden,
                        "gather_backend": None if dist is None else dist.get_backend(), "gathered": "LMG3 streams, decoded on rank 0" if args.gather_stream else "planes"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": None if not pmc or pmc.get("fetch_kib") is None else int((2 * pmc["fetch_kib"] + pmc["write_kib"]) * 1024),
@@ -436,6 +462,59 @@ def run_sharded(args, g, dist, rank, world):
                                  % ("the rank's whole image list" if batched else "one image (config 4) / one strip (config 5)")},
         }
         emit(line)
+
+
+def sum64_device(t):
+    """[sum e_i, sum (i + 1) e_i] over the tensor's elements (uint32 words / bytes) as unsigned 64-bit wrap-around sums: the parallel checksum
+    tools/make_golden_fullsize.py records per strip next to the FNV hashes (computed there from the real reference's planes with numpy)."""
+    import torch
+    v = t.reshape(-1)
+    if v.dtype == torch.int32:
+        v = v.to(torch.int64) & 0xFFFFFFFF
+    else:
+        v = v.to(torch.int64)
+    s1 = int(v.sum().item()) & 0xFFFFFFFFFFFFFFFF
+    s2 = 0
+    step = 1 << 24  # in pieces: the int64 temporaries of a 16384 x 2048 plane stay small
+    for o in range(0, v.numel(), step):
+        part = v[o:o + step]
+        idx = torch.arange(o + 1, o + 1 + part.numel(), dtype=torch.int64, device=v.device)
+        s2 = (s2 + int((part * idx).sum().item())) & 0xFFFFFFFFFFFFFFFF
+    return [s1, s2]
+
+
+def verify_golden(args, units, rows, rank, world, dist, single_chain, W, H, kind):
+    """--verify-golden (config 5 at its real size): every rank checks the strips IT produced against the real reference's per-strip checksums of
+    tests/golden/fullsize.json (pn16384_strips: one chain through the image; pn16384_pool2_strips: the chain restarted per strip) -- no plane leaves the rank.
+    A mismatch is a failed leg (non-zero exit)."""
+    import torch
+    entry = "pn16384_strips" if single_chain else "pn16384_pool2_strips"
+    try:
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize.json")))[entry]
+        if (W, H, kind) != (gold["w"], gold["h"], "photo_noise") or args.error_factor != 100:
+            raise RuntimeError("the golden entry %s is for %dx%d photo_noise, errorFactor 100" % (entry, gold["w"], gold["h"]))
+        sr = gold["strip_rows"]
+        bad, checked = [], []
+        per = len(units)
+        for k, (img, planes) in enumerate(units):
+            y0 = rows[rank * per + k][0] if not single_chain else rows[rank][0]
+            for j in range(img.shape[0] // sr):  # the 2048-row golden strips inside this unit
+                si = y0 // sr + j
+                checked.append(si)
+                for name, want in gold["strips"][si]["sum64"].items():
+                    if sum64_device(planes[name][j * sr:(j + 1) * sr]) != want:
+                        bad.append("strip %d %s" % (si, name))
+        flag = torch.tensor([len(bad)], dtype=torch.int64, device="cuda" if (dist is not None and dist.get_backend() == "nccl") else "cpu")
+        allchecked = [checked]
+        if dist is not None:
+            dist.all_reduce(flag)
+            allchecked = [None] * world
+            dist.all_gather_object(allchecked, checked)
+        if int(flag.item()) != 0:
+            raise RuntimeError("planes differ from the reference's: %s (this rank), %d mismatches over all ranks" % (bad[:4], int(flag.item())))
+        return {"entry": entry, "file": "tests/golden/fullsize.json", "strips_checked_by_rank": allchecked, "planes_per_strip": 11, "ok": True}
+    except Exception as e:
+        return leg_failed("verify_golden", e)
 
 
 BLOCKED_BYTES_PER_PIXEL = 4 + 4 * 9 + 4  # the RGBA pixel in; pDecoded, pShiftABCX, six colour planes, pBlockIndex (u32) and three factor planes + pBitsPerPixel (u8) out
@@ -683,6 +762,8 @@ def main():
                                                                      "strips to streams, rank 0 gathers the bytes and decodes them into the full image")
     ap.add_argument("--single-chain", action="store_true", help="--config 5 on 8 ranks: one dither chain through all strips (limg_hip_encode3d_single_chain_device) instead of "
                                                                     "the reference's strip-restart semantics")
+    ap.add_argument("--verify-golden", action="store_true", help="--config 5 at its real size: every rank checks the strips it produced against the real reference's per-strip "
+                                                                     "checksums (tests/golden/fullsize.json)")
     ap.add_argument("--share-gpus", action="store_true", help="rehearsal only: allow more ranks than GPUs (ranks share cards, gloo instead of RCCL)")
     ap.add_argument("--sub-images", type=int, default=0, help="--config 4: limg_hip_options.batch_sub_images -- the list as a pipeline of sub-batches of this many images "
                                                                  "(float stage of sub-batch k + 1 next to the persistent kernel of sub-batch k); 0 = the library's rule, -1 = off")
@@ -690,6 +771,9 @@ def main():
                                                       "are not available inside a graph: roofline.achieved then divides by the wall time per replay")
     ap.add_argument("--pipeline-knobs", type=lambda v: int(v, 0), default=0, help="A/B: limg_hip_options.test_pipeline")
     ap.add_argument("--wg-per-cu", type=int, default=0, help="A/B: limg_hip_options.test_wg_per_cu (workgroups per CU of the persistent kernel, 1..6)")
+    ap.add_argument("--pool-threads", type=int, default=0, help="default mode: the reference's thread-pool argument (0 = nullptr = one dither chain; T > 0 = 4 T row strips with restarted chains)")
+    ap.add_argument("--ragged-bands", type=int, default=0, help="limg_hip_options.ragged_bands (images with a partial last block column: bands of the host walk's pipeline; -1 = off)")
+    ap.add_argument("--walk-threads", type=int, default=0, help="limg_hip_options.ragged_walk_threads (several chains: host threads that walk them; 1 = serial)")
     ap.add_argument("--whole-image-ragged", action="store_true", help="A/B: height-ragged images through the whole-image ragged path (host walk over every dither call)")
     args = ap.parse_args()
     args.width, args.height = parse_size(args.size)
@@ -700,6 +784,7 @@ def main():
 
     if not os.environ.get("LIMG_KEEP_NCCL_DEBUG"):
         os.environ["NCCL_DEBUG"] = "WARN"  # RCCL's version banner goes to stdout, where the one JSON line belongs
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")  # ... and so do its warnings (seen: "Missing iommu=pt" on a GPU box, which broke the line's parse)
     import torch
     import numpy as np
     import limg_amd
@@ -756,7 +841,7 @@ def main():
             dist.destroy_process_group()
         return
     g.set_options(forced_shift=(args.forced_shift,) * 3 if args.forced_shift >= 0 else None, force_split=args.split, float_fast=(args.float_mode == "fast"), legacy_float_stage=args.legacy_float_stage,
-                  test_wg_per_cu=args.wg_per_cu, test_whole_image_ragged=args.whole_image_ragged)
+                  test_wg_per_cu=args.wg_per_cu, test_whole_image_ragged=args.whole_image_ragged, ragged_bands=args.ragged_bands, ragged_walk_threads=args.walk_threads)
     ragged = (W % 8 != 0) or (H % 8 != 0)
     ragged_fast = ragged and W % 8 == 0 and H > 8 and not (args.whole_image_ragged or args.split or args.legacy_float_stage)
     img = g.synth_device(args.workload, W, H, seed=1 + rank)
@@ -770,7 +855,7 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        g.encode3d_device(img, not args.rgb, planes, error_factor=args.error_factor, pool_threads=0, fast=not args.accurate, records=rec, shifts=sh)
+        g.encode3d_device(img, not args.rgb, planes, error_factor=args.error_factor, pool_threads=args.pool_threads, fast=not args.accurate, records=rec, shifts=sh)
 
     # cold cost, reported apart: the first encode of a size class builds the context's dither noise table and scratch
     t0 = time.perf_counter()
@@ -878,6 +963,7 @@ def main():
                       "u8/i32 integer stage (bit-exact given the records) + f32 float stage in FAST mode (PSNR-tolerance contract)"), "data": "synthetic",
             "config": {"workload": "synthetic %dx%d %s %s (seed 1+rank) per GPU, errorFactor %d, %s bit-crush, single dither chain"
                                    % (W, H, "RGB (hasAlpha = false)" if args.rgb else "RGBA", args.workload, args.error_factor, "ACCURATE" if args.accurate else "fast")
+                                   + ("" if args.pool_threads == 0 else " -- NO: pool of %d threads = %d restarted chains" % (args.pool_threads, 4 * args.pool_threads))
                                    + ("" if args.forced_shift < 0 else ", forced shift %d" % args.forced_shift)
                                    + (", COMPACT outputs (8.06 B/px)" if args.compact else "") + (", FAST float stage" if args.float_mode == "fast" else ""),
                        "ragged": None if not ragged else ("width in whole blocks, last block row partial: fast path + last row (limg_hip_api.hip encode_height_ragged)" if ragged_fast else
@@ -911,6 +997,11 @@ def main():
                 line["config"]["two_streams"] = two_stream_rate(g, img, planes, W, H, args)
             except Exception as e:
                 line["config"]["two_streams"] = leg_failed("two_streams", e)
+        if n_gpus == 1 and args.contexts > 1:
+            try:  # K host threads x own context x own stream: what a service gets out of one GPU for this image class (the ragged paths block their calling thread)
+                line["config"]["multi_context"] = multi_context_rate(img, W, H, args, args.contexts)
+            except Exception as e:
+                line["config"]["multi_context"] = leg_failed("multi_context", e)
         if n_gpus == 1 and not args.no_host_rate:
             try:
                 line["config"]["host_entry"] = host_entry_rate(g, W, H, args)
@@ -987,6 +1078,51 @@ def two_stream_rate(g, img, planes, W, H, args, n_images=12):
     if not same:
         raise RuntimeError("two contexts on two streams produced different planes for the same image")
     return {"contexts": 2, "images": n_images, "ms_per_image": round(dt * 1e3 / n_images, 4), "Mpixels_per_s": round(n_images * W * H / dt / 1e6, 1), "outputs_identical": same}
+
+
+def multi_context_rate(img, W, H, args, K, n_each=6):
+    """Throughput of a stream of images over K contexts, each driven by its own host thread on its own HIP stream (ctypes releases the GIL inside the library).  Same
+    image and options as the timed loop.  Every context's last planes must equal context 0's."""
+    import threading
+    import torch
+    import limg_amd
+    dev = torch.cuda.current_device()
+    ctxs = [limg_amd.LimgHip(dev) for _ in range(K)]
+    for c in ctxs:
+        c.set_options(float_fast=(args.float_mode == "fast"), legacy_float_stage=args.legacy_float_stage, ragged_bands=args.ragged_bands, ragged_walk_threads=args.walk_threads)
+    outs = [c.alloc_planes_device(W, H) for c in ctxs]
+    streams = [torch.cuda.Stream() for _ in ctxs]
+    errs = []
+
+    def worker(i, n):
+        try:
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(streams[i]):
+                for _ in range(n):
+                    ctxs[i].encode3d_device(img, not args.rgb, outs[i], error_factor=args.error_factor, pool_threads=args.pool_threads, fast=not args.accurate)
+                streams[i].synchronize()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    dt = None
+    for n in (1, n_each):  # warm-up round, then the timed one
+        ths = [threading.Thread(target=worker, args=(i, n)) for i in range(K)]
+        t0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    for c in ctxs:
+        c.check()
+    same = all(bool(torch.equal(outs[0][k], o[k])) for o in outs[1:] for k in outs[0])
+    for c in ctxs:
+        c.close()
+    if errs or not same:
+        raise RuntimeError("multi-context run failed: %r, outputs identical: %s" % (errs, same))
+    n_img = K * n_each
+    return {"contexts": K, "images": n_img, "ms_per_image": round(dt * 1e3 / n_img, 4), "Mpixels_per_s": round(n_img * W * H / dt / 1e6, 1), "outputs_identical": same}
 
 
 def host_entry_rate(g, W, H, args):

@@ -86,6 +86,11 @@ typedef struct limg_hip_options
   int32_t test_fail_chain_phase1; /* test hook, non-0: limg_hip_encode3d_single_chain_device behaves as if this rank's E step had failed (abort rule below) */
   int32_t test_blocked_no_bound; /* test / A-B hook, non-0: the merged-block encoder's similarity kernel evaluates the 27-colour loop for every pair its early exits leave
                                   open, without the certain-match / certain-failure bounds in front of it (limg_hip_blocked.hip).  Same bits either way */
+  int32_t ragged_bands;        /* images with a partial last block COLUMN and one dither chain (poolThreads == 0): the host's chain walk -- the floor of this class -- is
+                                  pipelined with the GPU in this many bands of block rows (E step band by band, the walk under it, every band's F step under the next band's
+                                  walk).  0 = automatic (16 bands from 64 block rows x 32 block columns on), N > 0 = N bands, < 0 = off (one E launch, walk, one F launch) */
+  int32_t ragged_walk_threads; /* ... with several chains (poolThreads > 0) the chains are independent, as on the reference's thread pool (src/limg.cpp:2114-2134): they are
+                                  walked on this many host threads (0 = one per chain, at most 16 and the host's hardware threads; 1 = serial) */
   int32_t test_lookback_spins; /* test hook, 0 = default (2^22 polls, seconds): bound of one look-back wait of the persistent kernel */
   int32_t test_base_error_strip; /* test hook, N > 0: work strip N - 1 of the persistent kernel dithers from a chain position that is off by one dither call (every other
                                   strip is unaffected): the smallest possible look-back error, which the full-size reference hashes must catch (tests/test_gpu_fullsize.py) */

@@ -63,7 +63,7 @@ class Options(C.Structure):
     _fields_ = [("forced_shift", C.c_int32 * 3), ("force_split_kernels", C.c_int32), ("dither_pcg", C.c_int32), ("test_record_limit", C.c_int32), ("float_mode", C.c_int32), ("legacy_float_stage", C.c_int32),
                 ("collect_stats", C.c_int32), ("host_noise_table", C.c_int32), ("test_batch_chunk", C.c_int32), ("batch_sub_images", C.c_int32), ("test_wg_per_cu", C.c_int32),
                 ("test_whole_image_ragged", C.c_int32), ("test_pipeline", C.c_int32), ("test_fail_chain_phase1", C.c_int32),
-                ("test_blocked_no_bound", C.c_int32), ("test_lookback_spins", C.c_int32), ("test_base_error_strip", C.c_int32),
+                ("test_blocked_no_bound", C.c_int32), ("ragged_bands", C.c_int32), ("ragged_walk_threads", C.c_int32), ("test_lookback_spins", C.c_int32), ("test_base_error_strip", C.c_int32),
                 ("test_skip_publish_strip", C.c_int32)]
 
 
@@ -264,7 +264,7 @@ class LimgHip:
 
     def set_options(self, forced_shift=None, force_split=False, dither_pcg=False, test_record_limit=0, float_fast=False, legacy_float_stage=False, test_batch_chunk=0, host_noise_table=False, collect_stats=False,
                     batch_sub_images=0, test_wg_per_cu=0, test_whole_image_ragged=False, test_fail_chain_phase1=False, test_pipeline=0, test_blocked_no_bound=False,
-                    test_lookback_spins=0, test_skip_publish_strip=0, test_base_error_strip=0):
+                    test_lookback_spins=0, test_skip_publish_strip=0, test_base_error_strip=0, ragged_bands=0, ragged_walk_threads=0):
         o = Options()
         self.lib.limg_hip_default_options(C.byref(o))
         if forced_shift is not None:
@@ -287,6 +287,8 @@ class LimgHip:
         o.test_lookback_spins = int(test_lookback_spins)
         o.test_skip_publish_strip = int(test_skip_publish_strip)
         o.test_base_error_strip = int(test_base_error_strip)
+        o.ragged_bands = int(ragged_bands)
+        o.ragged_walk_threads = int(ragged_walk_threads)
         _check(self.lib.limg_hip_set_options(self.ctx, C.byref(o)), "limg_hip_set_options")
 
     def get_options(self):

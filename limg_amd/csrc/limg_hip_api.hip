@@ -21,6 +21,8 @@ namespace limg_hip
   uint64_t chain_call(uint64_t h, unsigned n, uint8_t *noise64, bool forceSoft, bool pcg);
   uint64_t fill_noise_table(uint64_t h, uint8_t *noise, size_t count, bool pcg);
   uint64_t chain_checkpoints(uint64_t h, size_t calls, size_t every, uint64_t *pOut, bool pcg);
+  void chain_walk_rows(uint64_t &h, size_t &call, uint32_t by0, uint32_t by1, uint32_t blocksX, uint32_t stripsX, size_t sizeX, size_t sizeY, uint32_t chainCount, uint32_t chainRows,
+                       const uint32_t *shifts, uint32_t *stripBase, unsigned long long *states, uint8_t *pixels, size_t maxCalls, bool pcg);
   size_t chain_walk_blocks(uint64_t h0, uint32_t blocksX, uint32_t blocksY, uint32_t stripsX, size_t sizeX, size_t sizeY, uint32_t chainCount, uint32_t chainRows, const uint32_t *shifts,
                            uint32_t *stripBase, unsigned long long *states, uint8_t *pixels, size_t maxCalls, bool pcg);
 }
@@ -97,6 +99,7 @@ struct limg_hip_context
   HostBuf hStage;                                // pinned staging of the ragged paths' host step (shift words down; chain bases and noise up)
   hipEvent_t hStageEvent = nullptr;              // ... recorded behind the last asynchronous H2D copy that reads it: waited for before it is written, grown or freed again
   bool hStageBusy = false;
+  std::vector<hipEvent_t> raggedEvents;          // banded ragged encode: "the shift words of band b are down"
   DevBuf stats;                                  // limg_hip_options.collect_stats: the reference's 3 + 27 bit counters of the last encode
   hipStream_t statsStream = nullptr;
   int statsState = 0;                            // 0 = none, 1 = on the device (8x8 path), 2 = in statsHost (merged-block encoder)
@@ -317,6 +320,14 @@ namespace
 
   limg_hip_result encode_height_ragged(limg_hip_context *c, const uint32_t *dIn, size_t sizeX, size_t sizeY, int hasAlpha, const limg_hip_encode3d_info *dInfo,
                                        const limg_hip_compact_out *compact, uint32_t errorFactor, int poolThreads, int fast, hipStream_t stream, const EncodeExtra &x);
+
+  // pinned staging of the ragged paths' host step: shift words | previous descriptor | strip bases | per call: chain value, pixel count (worst case: 3 calls per block)
+  size_t ragged_stage_bytes(size_t blocks, size_t strips)
+  {
+    const size_t maxCalls = blocks * 3;
+    const size_t offPrev = (blocks * 4 + 15) & ~(size_t)15, offBase = offPrev + 16, offStates = (offBase + strips * 4 + 15) & ~(size_t)15, offPixels = offStates + maxCalls * 8;
+    return offPixels + maxCalls + 16;
+  }
 
   // The chain value the dither call number `calls` of a chain of full 8x8 blocks starts from: the nearest embedded checkpoint, then at most 1023 calls on foot.
   bool chain_value_at(uint64_t calls, uint64_t *pValue)
@@ -605,8 +616,59 @@ namespace
       HIP_TRY(hipGetLastError());
       return limg_hip_success;
     }
+    // Images with a partial last block COLUMN (any photograph whose width is not a multiple of 8): the whole dither chain is data dependent, so the host walks it
+    // (below).  The walk is the floor of this class -- ~26 ms for 8190 x 8192, one dependent AESDEC chain -- so everything else is taken off its path: the E step runs
+    // in BANDS of block rows whose shift words come back band by band (the walk starts when the first band is down and runs under the rest of the E step), and the F
+    // step of a band is launched as soon as its chain values are up (it runs under the walk of the next band).  Only for one chain (poolThreads == 0): independent
+    // chains are walked in parallel instead.  A band is a sub-image: pointers advanced, block rows counted from its top.
+    uint32_t nBands = 1;
+    // (an explicit band count is honoured from 2 x 2 blocks on -- tests and the fuzz tool; a band must not be one block wide: the corner block of fewer than four
+    //  pixels sums its LEFT neighbour's pixels, which for a one-block-wide image would be the row above, in another band)
+    if (ragged && dInfo && chainPhase == 0 && !x.dPrevDesc && pt.chainCount <= 1 && c->opt.ragged_bands >= 0 && p.blocksX >= 2 && p.blocksY >= 2 &&
+        (c->opt.ragged_bands > 0 || (p.blocksX >= 32 && p.blocksY >= 64)))
+      nBands = c->opt.ragged_bands > 0 ? (uint32_t)c->opt.ragged_bands : 16u;
+    if (nBands > p.blocksY / 2) nBands = p.blocksY / 2 ? p.blocksY / 2 : 1;
+    if (nBands > 64) nBands = 64;
+    const uint32_t bandRows = (p.blocksY + nBands - 1) / nBands;
+    nBands = (p.blocksY + bandRows - 1) / bandRows;
+    auto band_params = [&](uint32_t b) -> EncodeParams
+    {
+      EncodeParams q = p;
+      const uint32_t r0 = b * bandRows, r1 = r0 + bandRows < p.blocksY ? r0 + bandRows : p.blocksY;
+      const size_t y0 = (size_t)r0 * kBlock, skip = y0 * sizeX;
+      q.io.in = p.io.in + skip;
+      uint32_t **words[] = { &q.io.info.pDecoded, &q.io.info.pShiftABCX, &q.io.info.pColAMin, &q.io.info.pColAMax, &q.io.info.pColBMin, &q.io.info.pColBMax, &q.io.info.pColCMin, &q.io.info.pColCMax };
+      uint8_t **bytes[] = { &q.io.info.pFactorsA, &q.io.info.pFactorsB, &q.io.info.pFactorsC };
+      for (uint32_t **w : words) if (*w) *w += skip;
+      for (uint8_t **w : bytes) if (*w) *w += skip;
+      q.sizeY = (uint32_t)(((size_t)r1 * kBlock < sizeY ? (size_t)r1 * kBlock : sizeY) - y0);
+      q.blocksY = r1 - r0;
+      q.imageStrips = q.stripsX * q.blocksY;
+      q.records += (size_t)r0 * p.blocksX; q.shifts += (size_t)r0 * p.blocksX; q.invN += (size_t)r0 * p.blocksX * 4;
+      q.stripCalls += (size_t)r0 * p.stripsX; q.stripBase += (size_t)r0 * p.stripsX;
+      return q;
+    };
     if (!p.prefit) mark_if(1); // split path intervals: {k_fit_tpb + k_fit_search, scan, k_dither_store}
-    launch_fit_search(p, channels, stream);
+    if (nBands > 1)
+    {
+      if (c->hStageBusy) { HIP_TRY(hipEventSynchronize(c->hStageEvent)); c->hStageBusy = false; } // (see below: the staging area is about to be rewritten)
+      if ((r = c->hStage.ensure(ragged_stage_bytes(blocks, strips))) != limg_hip_success) return r;
+      while (c->raggedEvents.size() < nBands)
+      {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->raggedEvents.push_back(e);
+      }
+      for (uint32_t b = 0; b < nBands; b++)
+      {
+        const EncodeParams q = band_params(b);
+        launch_fit_search(q, channels, stream);
+        const size_t off = (size_t)b * bandRows * p.blocksX;
+        HIP_TRY(hipMemcpyAsync((uint32_t *)c->hStage.p + off, p.shifts + off, (size_t)q.blocksY * p.blocksX * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipEventRecord(c->raggedEvents[b], stream));
+      }
+    }
+    else launch_fit_search(p, channels, stream);
     if (chainPhase != 1) mark_if(1);
     if (!dInfo)
     {
@@ -628,51 +690,120 @@ namespace
     else
     {
       // Partial edge blocks: the chain walk depends on each block's pixel count (a call over N pixels is N / 8 AES rounds + N % 8 PCG steps: G_N), so it is
-      // evaluated in raster order on the host from the per-block call counts (blocking).  What crosses PCIe: the shift words down, then -- through pinned
-      // staging -- the strips' first call indices and, per dither call, the chain value it starts from and its pixel count (9 bytes; k_noise_expand turns them
-      // into the call's 64 noise bytes on the device; rounds 1-3 uploaded the 64 bytes).
+      // evaluated in raster order on the host from the per-block call counts.  What crosses PCIe: the shift words down, then -- through pinned staging -- the
+      // strips' first call indices and, per dither call, the chain value it starts from and its pixel count (9 bytes; k_noise_expand turns them into the call's
+      // 64 noise bytes on the device; rounds 1-3 uploaded the 64 bytes).
       const size_t maxCalls = blocks * 3;
       const size_t offPrev = (blocks * 4 + 15) & ~(size_t)15, offBase = offPrev + 16, offStates = (offBase + strips * 4 + 15) & ~(size_t)15, offPixels = offStates + maxCalls * 8;
-      // the previous ragged encode's H2D copies out of this buffer were asynchronous -- possibly on another stream: they must have read it before it is rewritten
-      // or reallocated
-      if (c->hStageBusy) { HIP_TRY(hipEventSynchronize(c->hStageEvent)); c->hStageBusy = false; }
-      if ((r = c->hStage.ensure(offPixels + maxCalls + 16)) != limg_hip_success) return r;
+      if (nBands == 1)
+      {
+        // the previous ragged encode's H2D copies out of this buffer were asynchronous -- possibly on another stream: they must have read it before it is rewritten
+        // or reallocated
+        if (c->hStageBusy) { HIP_TRY(hipEventSynchronize(c->hStageEvent)); c->hStageBusy = false; }
+        if ((r = c->hStage.ensure(ragged_stage_bytes(blocks, strips))) != limg_hip_success) return r;
+      }
       uint32_t *hShifts = (uint32_t *)c->hStage.p;
       unsigned long long *hPrev = (unsigned long long *)((uint8_t *)c->hStage.p + offPrev);
       uint32_t *hBase = (uint32_t *)((uint8_t *)c->hStage.p + offBase);
       unsigned long long *hStates = (unsigned long long *)((uint8_t *)c->hStage.p + offStates);
       uint8_t *hPixels = (uint8_t *)c->hStage.p + offPixels;
+      // device side: sized for the worst case up front (3 calls per block), so that a band's calls can go up while later bands are still being walked
+      if ((r = c->noiseDyn.ensure((maxCalls + 1) * 64)) != limg_hip_success) return r;
+      if ((r = c->noiseStates.ensure(maxCalls * 9 + 16)) != limg_hip_success) return r;
+      unsigned long long *dStates = (unsigned long long *)c->noiseStates.p;
+      uint8_t *dPixels = (uint8_t *)c->noiseStates.p + maxCalls * 8;
+      const bool pcg = c->opt.dither_pcg != 0;
+      p.noise = (const uint8_t *)c->noiseDyn.p;
+      p.noiseLast = (uint32_t)maxCalls;
+      auto upload_calls = [&](size_t call0, size_t n) -> limg_hip_result
+      {
+        if (!n) return limg_hip_success;
+        HIP_TRY(hipMemcpyAsync(dStates + call0, hStates + call0, n * 8, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(dPixels + call0, hPixels + call0, n, hipMemcpyHostToDevice, stream));
+        launch_noise_expand((uint8_t *)c->noiseDyn.p + call0 * 64, dStates + call0, dPixels + call0, n, pcg, stream);
+        return limg_hip_success;
+      };
+      if (nBands > 1)
+      { // ---- one chain, walked band by band under the E step; every band's F step under the walk of the next ----
+        uint64_t h = kDitherSeed;
+        size_t call = 0;
+        for (uint32_t b = 0; b < nBands; b++)
+        {
+          EncodeParams q = band_params(b);
+          const uint32_t r0 = b * bandRows, r1 = r0 + q.blocksY;
+          HIP_TRY(hipEventSynchronize(c->raggedEvents[b])); // this band's shift words are down
+          const size_t call0 = call;
+          chain_walk_rows(h, call, r0, r1, p.blocksX, p.stripsX, sizeX, sizeY, 1, 0, hShifts, hBase, hStates, hPixels, maxCalls, pcg);
+          if ((r = upload_calls(call0, call - call0)) != limg_hip_success) return r;
+          HIP_TRY(hipMemcpyAsync(p.stripBase + (size_t)r0 * p.stripsX, hBase + (size_t)r0 * p.stripsX, (size_t)q.blocksY * p.stripsX * 4, hipMemcpyHostToDevice, stream));
+          q.noise = p.noise; q.noiseLast = p.noiseLast;
+          if (b + 1 == nBands) mark_if(1); // intervals of a banded encode: {E step of all bands, the walk with the other bands' F steps under it, the last band's F step}
+          launch_dither_store(q, channels, stream);
+        }
+        if (!c->hStageEvent) HIP_TRY(hipEventCreateWithFlags(&c->hStageEvent, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->hStageEvent, stream));
+        c->hStageBusy = true;
+        mark_if(2);
+        HIP_TRY(hipGetLastError());
+        return stats();
+      }
       HIP_TRY(hipMemcpyAsync(hShifts, p.shifts, blocks * 4, hipMemcpyDeviceToHost, stream));
       if (x.dPrevDesc) HIP_TRY(hipMemcpyAsync(hPrev, x.dPrevDesc, 8, hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
       uint64_t h0 = kDitherSeed;
       if (x.dPrevDesc)
       { // the block rows above this sub-image ran through the persistent kernel: every strip's descriptor ends as the inclusive call count of its chain
-        if ((uint32_t)(*hPrev >> 32) != 2u || !chain_value_at((uint32_t)*hPrev, &h0))
+        if ((uint32_t)(*hPrev >> 32) != 2u || (uint32_t)*hPrev == 0xFFFFFFFFu || !chain_value_at((uint32_t)*hPrev, &h0))
         {
           fprintf(stderr, "limg_hip: the chain position of the last block row is unavailable (descriptor %016llx)\n", *hPrev);
           return limg_hip_error_Generic;
         }
       }
-      const bool pcg = c->opt.dither_pcg != 0;
-      const size_t call = chain_walk_blocks(h0, p.blocksX, p.blocksY, p.stripsX, sizeX, sizeY, pt.chainCount, pt.chainRows, hShifts, hBase, hStates, hPixels, maxCalls, pcg);
-      const size_t totalCalls = call;
-      if ((r = c->noiseDyn.ensure((totalCalls + 1) * 64)) != limg_hip_success) return r;
-      if ((r = c->noiseStates.ensure(totalCalls * 9 + 16)) != limg_hip_success) return r;
-      if (totalCalls)
+      size_t totalCalls = 0;
+      // chains that restart at the seed are independent (the reference walks them on its pool's threads, src/limg.cpp:2114-2134): count every chain's calls, then
+      // walk them side by side on up to limg_hip_options.ragged_walk_threads host threads (0: as many as there are chains, at most 16)
+      unsigned threads = 1;
+      if (pt.chainCount > 1 && pt.chainRows != 0 && !x.dPrevDesc && (blocks >= 4096 || c->opt.ragged_walk_threads > 1))
       {
-        HIP_TRY(hipMemcpyAsync(c->noiseStates.p, hStates, totalCalls * 8, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipMemcpyAsync((uint8_t *)c->noiseStates.p + totalCalls * 8, hPixels, totalCalls, hipMemcpyHostToDevice, stream));
-        launch_noise_expand((uint8_t *)c->noiseDyn.p, (const unsigned long long *)c->noiseStates.p, (const uint8_t *)c->noiseStates.p + totalCalls * 8, totalCalls, pcg, stream);
+        threads = c->opt.ragged_walk_threads > 0 ? (unsigned)c->opt.ragged_walk_threads : 16u;
+        const unsigned hw = std::thread::hardware_concurrency();
+        if (hw && threads > hw) threads = hw;
+        if (threads > pt.chainCount) threads = pt.chainCount;
       }
+      if (threads > 1)
+      {
+        std::vector<size_t> first(pt.chainCount + 1, 0);
+        std::vector<uint32_t> row0(pt.chainCount + 1, 0);
+        for (uint32_t k = 0; k < pt.chainCount; k++)
+        {
+          row0[k] = k * pt.chainRows;
+          const uint32_t r1 = k + 1 < pt.chainCount ? (k + 1) * pt.chainRows : p.blocksY;
+          size_t n = 0;
+          for (size_t i = (size_t)row0[k] * p.blocksX; i < (size_t)r1 * p.blocksX; i++) n += hShifts[i] >> 24;
+          first[k + 1] = first[k] + n;
+        }
+        row0[pt.chainCount] = p.blocksY;
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; t++)
+          pool.emplace_back([&, t]() {
+            for (uint32_t k = t; k < pt.chainCount; k += threads)
+            {
+              uint64_t h = kDitherSeed;
+              size_t call = first[k];
+              chain_walk_rows(h, call, row0[k], row0[k + 1], p.blocksX, p.stripsX, sizeX, sizeY, pt.chainCount, pt.chainRows, hShifts, hBase, hStates, hPixels, maxCalls, pcg);
+            }
+          });
+        for (std::thread &t : pool) t.join();
+        totalCalls = first[pt.chainCount] < maxCalls ? first[pt.chainCount] : maxCalls;
+      }
+      else totalCalls = chain_walk_blocks(h0, p.blocksX, p.blocksY, p.stripsX, sizeX, sizeY, pt.chainCount, pt.chainRows, hShifts, hBase, hStates, hPixels, maxCalls, pcg);
+      if ((r = upload_calls(0, totalCalls)) != limg_hip_success) return r;
       HIP_TRY(hipMemcpyAsync(p.stripBase, hBase, strips * 4, hipMemcpyHostToDevice, stream));
       // the staging buffer is the context's: the event marks the point where these copies have read it (waited for above by the next encode that uses it, on
       // whatever stream, and by limg_hip_shutdown)
       if (!c->hStageEvent) HIP_TRY(hipEventCreateWithFlags(&c->hStageEvent, hipEventDisableTiming));
       HIP_TRY(hipEventRecord(c->hStageEvent, stream));
       c->hStageBusy = true;
-      p.noise = (const uint8_t *)c->noiseDyn.p;
-      p.noiseLast = (uint32_t)totalCalls;
     }
     mark_if(1);
     launch_dither_store(p, channels, stream);
@@ -775,6 +906,7 @@ extern "C"
     for (HostBuf *b : hbufs) b->release();
     c->hStage.release(); // (the device is idle: hipDeviceSynchronize above)
     if (c->hStageEvent) (void)hipEventDestroy(c->hStageEvent);
+    for (hipEvent_t e : c->raggedEvents) (void)hipEventDestroy(e);
     if (c->fitStream) (void)hipStreamDestroy(c->fitStream);
     for (hipEvent_t e : c->pipeEvents) (void)hipEventDestroy(e);
     if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
@@ -806,8 +938,10 @@ extern "C"
     return limg_hip_success;
   }
 
-  // Blocks until the device is idle and reports a look-back timeout of the fused kernel (never observed; the spin is bounded so
-  // that a protocol bug could not hang the GPU) as limg_hip_error_Generic.
+  // Blocks until the device is idle and reports a look-back timeout of the persistent kernel as limg_hip_error_Generic.  Observed once, in round 4: a build whose
+  // workgroups took their first strip from blockIdx instead of the ticket dead-locked two contexts' kernels against each other until the bound fired;
+  // with every strip id drawn from the ticket a look-back cannot wait on a workgroup that is not running.  The bound stays as the safety net, and a timeout is loud:
+  // the strips behind it store nothing chain-dependent (limg_hip_kernels.hip "decoupled look-back").
   limg_hip_result limg_hip_check_device_status(limg_hip_context *c)
   {
     if (!c) return limg_hip_error_ArgumentNull;

@@ -211,16 +211,16 @@ namespace limg_hip
 #if defined(__x86_64__)
     __attribute__((target("aes,sse4.1")))
 #endif
-    size_t walk_blocks_impl(uint64_t h0, uint32_t blocksX, uint32_t blocksY, uint32_t stripsX, size_t sizeX, size_t sizeY, uint32_t chainCount, uint32_t chainRows,
-                            const uint32_t *shifts, uint32_t *stripBase, unsigned long long *states, uint8_t *pixels, size_t maxCalls, bool pcg)
+    void walk_blocks_impl(uint64_t &hIo, size_t &callIo, uint32_t by0, uint32_t by1, uint32_t blocksX, uint32_t stripsX, size_t sizeX, size_t sizeY, uint32_t chainCount, uint32_t chainRows,
+                          const uint32_t *shifts, uint32_t *stripBase, unsigned long long *states, uint8_t *pixels, size_t maxCalls, bool pcg)
     {
 #if defined(__x86_64__)
       const __m128i key = _mm_set_epi64x(0x2A76E98006CB4CADLL, (long long)0x824A73EAAB705E1DULL);
 #endif
       auto chain_of = [&](uint32_t row) -> uint32_t { if (chainCount <= 1 || chainRows == 0) return 0u; const uint32_t c = row / chainRows; return c < chainCount - 1 ? c : chainCount - 1; };
-      uint64_t h = h0;
-      size_t call = 0;
-      for (uint32_t by = 0; by < blocksY; by++)
+      uint64_t h = hIo;
+      size_t call = callIo;
+      for (uint32_t by = by0; by < by1; by++)
       {
         if (by != 0 && chain_of(by) != chain_of(by - 1)) h = 0xCA7F00D15BADF00DULL; // src/limg.cpp:1893
         const unsigned ry = (unsigned)((sizeY - (size_t)by * 8) < 8 ? (sizeY - (size_t)by * 8) : 8);
@@ -248,17 +248,28 @@ namespace limg_hip
           }
         }
       }
-      return call;
+      hIo = h; callIo = call;
     }
+  }
+
+  // Block rows [by0, by1) of the walk: continues from chain value `h` at call index `call` (both updated), restarts the chain where the partition says so.  The rows of
+  // an image may be walked in pieces, in order (the band pipeline of limg_hip_api.hip), and chains that start at the seed may be walked by different threads at once.
+  void chain_walk_rows(uint64_t &h, size_t &call, uint32_t by0, uint32_t by1, uint32_t blocksX, uint32_t stripsX, size_t sizeX, size_t sizeY, uint32_t chainCount, uint32_t chainRows,
+                       const uint32_t *shifts, uint32_t *stripBase, unsigned long long *states, uint8_t *pixels, size_t maxCalls, bool pcg)
+  {
+#if defined(__x86_64__)
+    if (!pcg && have_aesni()) { walk_blocks_impl<true>(h, call, by0, by1, blocksX, stripsX, sizeX, sizeY, chainCount, chainRows, shifts, stripBase, states, pixels, maxCalls, pcg); return; }
+#endif
+    walk_blocks_impl<false>(h, call, by0, by1, blocksX, stripsX, sizeX, sizeY, chainCount, chainRows, shifts, stripBase, states, pixels, maxCalls, pcg);
   }
 
   size_t chain_walk_blocks(uint64_t h0, uint32_t blocksX, uint32_t blocksY, uint32_t stripsX, size_t sizeX, size_t sizeY, uint32_t chainCount, uint32_t chainRows, const uint32_t *shifts,
                            uint32_t *stripBase, unsigned long long *states, uint8_t *pixels, size_t maxCalls, bool pcg)
   {
-#if defined(__x86_64__)
-    if (!pcg && have_aesni()) return walk_blocks_impl<true>(h0, blocksX, blocksY, stripsX, sizeX, sizeY, chainCount, chainRows, shifts, stripBase, states, pixels, maxCalls, pcg);
-#endif
-    return walk_blocks_impl<false>(h0, blocksX, blocksY, stripsX, sizeX, sizeY, chainCount, chainRows, shifts, stripBase, states, pixels, maxCalls, pcg);
+    uint64_t h = h0;
+    size_t call = 0;
+    chain_walk_rows(h, call, 0, blocksY, blocksX, stripsX, sizeX, sizeY, chainCount, chainRows, shifts, stripBase, states, pixels, maxCalls, pcg);
+    return call;
   }
 
   uint64_t chain_walk_batch(uint64_t h, size_t count, const uint8_t *shiftWords, size_t stride, const uint32_t *npx, unsigned long long *noiseBase, unsigned long long *callState,

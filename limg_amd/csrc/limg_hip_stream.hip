@@ -235,16 +235,44 @@ namespace limg_hip
     }
 
     // ---- decode ----------------------------------------------------------------------------------------------------------
+    // PERSISTENT since round 5.  The work unit is what a wave always owned: 64 consecutive blocks (raster order), walked in 8 groups of 8 with lane = (block j = lane & 7,
+    // block row r = lane >> 3).  Until round 4 a workgroup was 4 such waves behind one barrier and lived for one tile of 256 blocks: header check, entry loads (56-byte
+    // records, one per lane), their turn into decode constants, barrier, and only then the first payload request -- a serial prologue per workgroup, 4096 of them in four
+    // rounds over the residency slots (VALU busy 0.71 at 16 waves per CU).  Now a wave loops over units with NO workgroup-level synchronisation at all (its LDS is its
+    // own): the NEXT unit's entries are requested before the current unit's groups are decoded, and a unit's first payload run is requested as soon as its offsets are
+    // known, ahead of the (long) constant preparation.  Units go to waves with a fixed stride: there is no dependence between units, so no ticket is needed.
+    // The re-expansion multiplier is folded into the normals (value * (mul * n) == (value * mul) * n exactly: 8 + 21 bits for records the packed form accepts);
+    // blocks with larger records (never from a fit of byte pixels) keep both apart and take the generic loop.
+    struct DecodeWaveLds
+    {
+      int nm[64][24];           // per block: 12 effective normals (multiplier folded in unless the block is `big`), 12 additive constants
+      uint32_t bits[64], off[64], mul[64], bx[64], by[64], flags[64];
+      uint8_t stage[kGroupBytes + 16];
+    };
+    static_assert(sizeof(DecodeWaveLds) * 4 <= 163840 / 4, "4 workgroups of 4 waves per CU");
+
+    __device__ __forceinline__ void load_entry(const DecodeParams &p, uint32_t g, uint32_t e[14])
+    {
+      if (g < p.nBlocks)
+      {
+        const uint2 *ep = reinterpret_cast<const uint2 *>(p.stream + sizeof(limg_hip_stream_header) + (size_t)g * kEntry);
+#pragma unroll
+        for (int i = 0; i < 7; i++) { const uint2 v = ep[i]; e[2 * i] = v.x; e[2 * i + 1] = v.y; }
+      }
+      else
+      {
+#pragma unroll
+        for (int i = 0; i < 14; i++) e[i] = 0u;
+      }
+    }
 
     __global__ __launch_bounds__(kTile, 4) void k_stream_decode(const DecodeParams p)
     {
-      __shared__ __align__(16) int sNm[kTile][24];
-      __shared__ uint32_t sBits[kTile], sOff[kTile], sMul[kTile], sBx[kTile], sBy[kTile], sFlags[kTile];
-      __shared__ __align__(16) uint8_t sStage[4][kGroupBytes + 16];
+      __shared__ __align__(16) DecodeWaveLds sW[4];
       const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-      const uint32_t tile = blockIdx.x, g = tile * kTile + tid;
+      DecodeWaveLds &S = sW[wave];
 
-      // every workgroup validates the header it is about to trust (scalar loads; a mismatch raises the context's status word)
+      // every wave validates the header it is about to trust (scalar loads; a mismatch raises the context's status word)
       const limg_hip_stream_header *h = reinterpret_cast<const limg_hip_stream_header *>(p.stream);
       const unsigned long long payloadWords = h->payloadWords;
       const bool ok = h->magic == LIMG_HIP_STREAM_MAGIC && h->version == LIMG_HIP_STREAM_VERSION && h->sizeX == p.sizeX && h->sizeY == p.sizeY &&
@@ -257,222 +285,256 @@ namespace limg_hip
         return;
       }
       const int channels = (int)h->channels;
-
-      if (g < p.nBlocks)
-      {
-        const uint2 *ep = reinterpret_cast<const uint2 *>(p.stream + sizeof(limg_hip_stream_header) + (size_t)g * kEntry);
-        uint32_t e[14];
-#pragma unroll
-        for (int i = 0; i < 7; i++) { const uint2 v = ep[i]; e[2 * i] = v.x; e[2 * i + 1] = v.y; }
-        const uint32_t sw = e[12];
-        uint32_t bits = 0, mul = 0, big = 0;
-#pragma unroll
-        for (int f = 0; f < 3; f++)
-        {
-          const uint32_t s = min((sw >> (8 * f)) & 0xFFu, 8u);
-          const bool raw = (sw >> (24 + f)) & 1u;
-          bits |= (s == 8 ? (raw ? 8u : 0u) : 8u - s) << (8 * f);
-          mul |= shift_mul(s) << (10 * f);
-#pragma unroll
-          for (int c = 0; c < 4; c++)
-          {
-            // vector f: min/offset at int16 index f*8 + c, max/mag at f*8 + 4 + c
-            const int mnv = (int)(int16_t)(e[f * 4 + (c >> 1)] >> (16 * (c & 1)));
-            const int mxv = (int)(int16_t)(e[f * 4 + 2 + (c >> 1)] >> (16 * (c & 1)));
-            int n = mxv - mnv, m = mnv;
-            big |= (mnv > kPackedLimit || mnv < -kPackedLimit || mxv > kPackedLimit || mxv < -kPackedLimit) ? 1u : 0u;
-            if (c < 3)
-            {
-              if (s > 7) { n = 0; if (f > 0) m = 0; } // src/limg_decode.h:150-170
-            }
-            else if (channels == 3) { n = 0; m = 0xFFFF; } // src/limg_decode.h:95-97
-            sNm[tid][f * 4 + c] = n;
-            sNm[tid][12 + f * 4 + c] = (int)(((uint32_t)m << 8) + 128u + (uint32_t)(c < 2 ? (f == 2 ? 0x200000 : 0x300000) : 0)); // R and G carry the packed form's biases
-          }
-        }
-        { // per-block flags of the packed decode (same rules as the F step's phase_f_prepare, limg_hip_kernels.hip)
-          uint32_t fl = big;
-          if (channels == 3) fl |= 255u << 8;
-          else
-          {
-            const int a0 = (int)(int16_t)(e[1] >> 16), a1 = (int)(int16_t)(e[3] >> 16), b0 = (int)(int16_t)(e[5] >> 16), b1 = (int)(int16_t)(e[7] >> 16), c0 = (int)(int16_t)(e[9] >> 16),
-                      c1 = (int)(int16_t)(e[11] >> 16); // lane 3 of dirA_min, dirA_max, dirB_offset, dirB_mag, dirC_offset, dirC_mag
-            int a = a0 + b0 + c0;
-            a = a < 0 ? 0 : (a > 255 ? 255 : a);
-            fl |= (a0 != a1 || b0 != b1 || c0 != c1) ? 2u : ((uint32_t)a << 8);
-          }
-          sFlags[tid] = fl;
-        }
-        sBits[tid] = bits; sMul[tid] = mul; sOff[tid] = e[13];
-        const uint32_t by = g / p.blocksX;
-        sBy[tid] = by; sBx[tid] = g - by * p.blocksX;
-      }
-      __syncthreads();
-
-      const uint32_t inTile = min((uint32_t)kTile, p.nBlocks - tile * kTile);
+      const uint32_t nUnits = (p.nBlocks + 63u) / 64u, nWaves = gridDim.x * 4u;
+      uint32_t unit = blockIdx.x * 4u + (uint32_t)wave;
+      if (unit >= nUnits) return; // (wave-uniform; nothing below synchronises across waves)
       const uint2 *payload = reinterpret_cast<const uint2 *>(p.stream + sizeof(limg_hip_stream_header) + (size_t)p.nBlocks * kEntry);
       const int j = lane & 7, r = lane >> 3;
-      uint8_t *stage = sStage[wave];
+      uint8_t *stage = S.stage;
       const bool rowAligned = (p.sizeX & 3u) == 0;
-      // Per group of 8 blocks: where its payload run lies.  The run of group g + 1 is requested (into registers) before group g
-      // is decoded, so the HBM round trip hides behind ~400 VALU instructions.
-      struct Group { uint32_t t, bw, myOff, off0, n; bool valid, any, ok; };
-      auto group_info = [&](int grp) {
-        Group G;
-        const uint32_t jb = wave * 64 + grp * 8;
-        G.any = grp < 8 && jb < inTile; // wave-uniform
-        G.t = jb + j; G.bw = 0; G.myOff = 0; G.off0 = 0; G.n = 0; G.valid = false; G.ok = false;
-        if (!G.any) return G;
-        const uint32_t nValid = min(8u, inTile - jb);
-        G.valid = (uint32_t)j < nValid;
-        G.bw = G.valid ? sBits[G.t] : 0u;
-        G.myOff = G.valid ? sOff[G.t] : 0u;
-        G.off0 = sOff[jb];
-        // the group's payload is one contiguous run in a stream this library wrote; anything else (corrupt offsets) is refused
-        // All of this in 64 bits: offsets come from the (untrusted) stream, and 32-bit sums such as 0xFFFFFFF0 + 24 wrap to small values that pass.
-        const unsigned long long myEnd = (unsigned long long)G.myOff + words_of(G.bw);
-        const uint32_t lastOff = (uint32_t)__shfl((int)G.myOff, (int)nValid - 1, 64), lastWords = (uint32_t)__shfl((int)words_of(G.bw), (int)nValid - 1, 64);
-        const unsigned long long endWord = (unsigned long long)lastOff + lastWords;
-        const bool sane = G.myOff >= G.off0 && myEnd <= endWord && endWord >= G.off0 && endWord - G.off0 <= (unsigned long long)(kGroupBytes / 8) && endWord <= payloadWords;
-        G.ok = __builtin_amdgcn_ballot_w64(G.valid && !sane) == 0;
-        G.n = G.ok ? (uint32_t)(endWord - G.off0) : 0u;
-        return G;
-      };
-      auto fetch = [&](const Group &G, uint2 buf[3]) {
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-        {
-          buf[i] = make_uint2(0, 0);
-          if ((uint32_t)(lane + 64 * i) < G.n) buf[i] = payload[(size_t)G.off0 + lane + 64 * i];
-        }
-      };
-      Group cur = group_info(0);
-      uint2 buf[3];
-      fetch(cur, buf);
-      for (int grp = 0; grp < 8; grp++)
+
+      uint32_t e[14];
+      load_entry(p, unit * 64u + (uint32_t)lane, e);
+      for (;;)
       {
-        if (!cur.any) break; // wave-uniform
-        const Group G = cur;
+        const uint32_t g = unit * 64u + (uint32_t)lane;
+        const uint32_t inUnit = min(64u, p.nBlocks - unit * 64u);
+        const uint32_t sw = e[12];
+        // ---- 1. what the first payload request needs: field widths and offsets ----
         {
-          uint2 *dst = reinterpret_cast<uint2 *>(stage);
+          uint32_t bits = 0;
+#pragma unroll
+          for (int f = 0; f < 3; f++)
+          {
+            const uint32_t s = min((sw >> (8 * f)) & 0xFFu, 8u);
+            const bool raw = (sw >> (24 + f)) & 1u;
+            bits |= (s == 8 ? (raw ? 8u : 0u) : 8u - s) << (8 * f);
+          }
+          S.bits[lane] = bits; S.off[lane] = e[13];
+        }
+        wave_lds_fence();
+        // Per group of 8 blocks: where its payload run lies.  The run of group g + 1 is requested (into registers) before group g
+        // is decoded, so the HBM round trip hides behind ~400 VALU instructions.
+        struct Group { uint32_t t, bw, myOff, off0, n; bool valid, any, ok; };
+        auto group_info = [&](int grp) {
+          Group G;
+          const uint32_t jb = (uint32_t)grp * 8u;
+          G.any = grp < 8 && jb < inUnit; // wave-uniform
+          G.t = jb + j; G.bw = 0; G.myOff = 0; G.off0 = 0; G.n = 0; G.valid = false; G.ok = false;
+          if (!G.any) return G;
+          const uint32_t nValid = min(8u, inUnit - jb);
+          G.valid = (uint32_t)j < nValid;
+          G.bw = G.valid ? S.bits[G.t] : 0u;
+          G.myOff = G.valid ? S.off[G.t] : 0u;
+          G.off0 = S.off[jb];
+          // the group's payload is one contiguous run in a stream this library wrote; anything else (corrupt offsets) is refused
+          // All of this in 64 bits: offsets come from the (untrusted) stream, and 32-bit sums such as 0xFFFFFFF0 + 24 wrap to small values that pass.
+          const unsigned long long myEnd = (unsigned long long)G.myOff + words_of(G.bw);
+          const uint32_t lastOff = (uint32_t)__shfl((int)G.myOff, (int)nValid - 1, 64), lastWords = (uint32_t)__shfl((int)words_of(G.bw), (int)nValid - 1, 64);
+          const unsigned long long endWord = (unsigned long long)lastOff + lastWords;
+          const bool sane = G.myOff >= G.off0 && myEnd <= endWord && endWord >= G.off0 && endWord - G.off0 <= (unsigned long long)(kGroupBytes / 8) && endWord <= payloadWords;
+          G.ok = __builtin_amdgcn_ballot_w64(G.valid && !sane) == 0;
+          G.n = G.ok ? (uint32_t)(endWord - G.off0) : 0u;
+          return G;
+        };
+        auto fetch = [&](const Group &G, uint2 buf[3]) {
 #pragma unroll
           for (int i = 0; i < 3; i++)
-            if ((uint32_t)(lane + 64 * i) < G.n) dst[lane + 64 * i] = buf[i];
-        }
-        cur = group_info(grp + 1);
-        fetch(cur, buf);
-        if (!G.ok)
-        {
-          if (lane == 0) atomicOr(p.status, 2u);
-          continue;
-        }
-        const uint32_t t = G.t, bw = G.bw, myOff = G.myOff, off0 = G.off0;
-        const bool valid = G.valid;
-        const uint32_t fl = valid ? sFlags[t] : 0u;
-        const bool generic = __builtin_amdgcn_ballot_w64((fl & 1u) != 0u) != 0ull, anyAlpha = __builtin_amdgcn_ballot_w64((fl & 2u) != 0u) != 0ull; // wave-uniform
-        wave_lds_fence();
-        if (valid)
-        {
-          const uint32_t y = sBy[t] * 8 + r, x0 = sBx[t] * 8;
-          uint32_t fieldByte = (myOff - off0) * 8;
-          unsigned long long packed[3];
-          uint32_t bb[3];
-#pragma unroll
-          for (int k = 0; k < 3; k++)
           {
-            const uint32_t b = (bw >> (8 * k)) & 0xFF;
-            bb[k] = b;
-            const uint32_t o = fieldByte + r * b;
-            const uint32_t *wp = reinterpret_cast<const uint32_t *>(stage + (o & ~3u));
-            const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2];
-            const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, o & 3u), hi = __builtin_amdgcn_alignbyte(d2, d1, o & 3u);
-            packed[k] = ((unsigned long long)hi << 32) | lo;
-            fieldByte += b * 8;
+            buf[i] = make_uint2(0, 0);
+            if ((uint32_t)(lane + 64 * i) < G.n) buf[i] = payload[(size_t)G.off0 + lane + 64 * i];
           }
-          const uint32_t mulw = sMul[t];
-          const int mulA = (int)(mulw & 0x3FF), mulB = (int)((mulw >> 10) & 0x3FF), mulC = (int)((mulw >> 20) & 0x3FF);
-          const int *nm = sNm[t];
-          // values 0..3 of a row sit in the low dword (4 b <= 32 bits), values 4..7 in the low dword of (packed >> 4 b)
-          uint32_t lo[3], hi[3];
+        };
+        Group cur = group_info(0);
+        uint2 buf[3];
+        fetch(cur, buf);
+
+        // ---- 2. the block's decode constants (lane == block of the unit), under the first payload request ----
+        if (g < p.nBlocks)
+        {
+          uint32_t mul = 0, big = 0;
+          // (pass 1: is any record value beyond the packed form's range?  decides whether the multiplier may be folded into the normals)
 #pragma unroll
-          for (int k = 0; k < 3; k++) { lo[k] = (uint32_t)packed[k]; hi[k] = (uint32_t)(packed[k] >> (4 * bb[k])); }
-          uint32_t px[8];
-          if (!generic)
-          { // a16 in the packed form of the F step (limg_hip_kernels.hip phase_f_rows): factor by factor, per factor three 24-bit multiply-adds per pixel, the R and G
-            // terms packed by one v_perm_b32 (>> 8 included) and biased (0x3000 + 0x3000 + 0x2000 = 0x8000) so that plain 32-bit adds sum the halves independently
-            uint32_t accRG[8];
-            int accB[8], accA[8];
-            const int mulK[3] = { mulA, mulB, mulC };
+          for (int w = 0; w < 12; w++)
+          {
+            const int lo16 = (int)(int16_t)e[w], hi16 = (int)(int16_t)(e[w] >> 16);
+            big |= (lo16 > kPackedLimit || lo16 < -kPackedLimit || hi16 > kPackedLimit || hi16 < -kPackedLimit) ? 1u : 0u;
+          }
+#pragma unroll
+          for (int f = 0; f < 3; f++)
+          {
+            const uint32_t s = min((sw >> (8 * f)) & 0xFFu, 8u);
+            const int fmul = (int)shift_mul(s);
+            mul |= (big ? (uint32_t)fmul : 1u) << (10 * f);
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+            {
+              // vector f: min/offset at int16 index f*8 + c, max/mag at f*8 + 4 + c
+              const int mnv = (int)(int16_t)(e[f * 4 + (c >> 1)] >> (16 * (c & 1)));
+              const int mxv = (int)(int16_t)(e[f * 4 + 2 + (c >> 1)] >> (16 * (c & 1)));
+              int n = mxv - mnv, m = mnv;
+              if (c < 3)
+              {
+                if (s > 7) { n = 0; if (f > 0) m = 0; } // src/limg_decode.h:150-170
+              }
+              else if (channels == 3) { n = 0; m = 0xFFFF; } // src/limg_decode.h:95-97
+              S.nm[lane][f * 4 + c] = big ? n : n * fmul; // |n| <= 5400 and mul <= 256: 21 bits, a 24-bit operand
+              S.nm[lane][12 + f * 4 + c] = (int)(((uint32_t)m << 8) + 128u + (uint32_t)(c < 2 ? (f == 2 ? 0x200000 : 0x300000) : 0)); // R and G carry the packed form's biases
+            }
+          }
+          { // per-block flags of the packed decode (same rules as the F step's phase_f_prepare, limg_hip_kernels.hip)
+            uint32_t fl = big;
+            if (channels == 3) fl |= 255u << 8;
+            else
+            {
+              const int a0 = (int)(int16_t)(e[1] >> 16), a1 = (int)(int16_t)(e[3] >> 16), b0 = (int)(int16_t)(e[5] >> 16), b1 = (int)(int16_t)(e[7] >> 16), c0 = (int)(int16_t)(e[9] >> 16),
+                        c1 = (int)(int16_t)(e[11] >> 16); // lane 3 of dirA_min, dirA_max, dirB_offset, dirB_mag, dirC_offset, dirC_mag
+              int a = a0 + b0 + c0;
+              a = a < 0 ? 0 : (a > 255 ? 255 : a);
+              fl |= (a0 != a1 || b0 != b1 || c0 != c1) ? 2u : ((uint32_t)a << 8);
+            }
+            S.flags[lane] = fl;
+          }
+          S.mul[lane] = mul;
+          const uint32_t by = g / p.blocksX;
+          S.by[lane] = by; S.bx[lane] = g - by * p.blocksX;
+        }
+        // ---- 3. the NEXT unit's entries: in flight while this unit's groups are decoded ----
+        const uint32_t next = unit + nWaves;
+        uint32_t en[14];
+        if (next < nUnits) load_entry(p, next * 64u + (uint32_t)lane, en);
+        wave_lds_fence();
+
+        for (int grp = 0; grp < 8; grp++)
+        {
+          if (!cur.any) break; // wave-uniform
+          const Group G = cur;
+          {
+            uint2 *dst = reinterpret_cast<uint2 *>(stage);
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+              if ((uint32_t)(lane + 64 * i) < G.n) dst[lane + 64 * i] = buf[i];
+          }
+          cur = group_info(grp + 1);
+          fetch(cur, buf);
+          if (!G.ok)
+          {
+            if (lane == 0) atomicOr(p.status, 2u);
+            continue;
+          }
+          const uint32_t t = G.t, bw = G.bw, myOff = G.myOff, off0 = G.off0;
+          const bool valid = G.valid;
+          const uint32_t fl = valid ? S.flags[t] : 0u;
+          const bool generic = __builtin_amdgcn_ballot_w64((fl & 1u) != 0u) != 0ull, anyAlpha = __builtin_amdgcn_ballot_w64((fl & 2u) != 0u) != 0ull; // wave-uniform
+          wave_lds_fence();
+          if (valid)
+          {
+            const uint32_t y = S.by[t] * 8 + r, x0 = S.bx[t] * 8;
+            uint32_t fieldByte = (myOff - off0) * 8;
+            unsigned long long packed[3];
+            uint32_t bb[3];
 #pragma unroll
             for (int k = 0; k < 3; k++)
             {
-              const int4 n = *reinterpret_cast<const int4 *>(nm + 4 * k), m = *reinterpret_cast<const int4 *>(nm + 12 + 4 * k);
+              const uint32_t b = (bw >> (8 * k)) & 0xFF;
+              bb[k] = b;
+              const uint32_t o = fieldByte + r * b;
+              const uint32_t *wp = reinterpret_cast<const uint32_t *>(stage + (o & ~3u));
+              const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2];
+              const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, o & 3u), hi = __builtin_amdgcn_alignbyte(d2, d1, o & 3u);
+              packed[k] = ((unsigned long long)hi << 32) | lo;
+              fieldByte += b * 8;
+            }
+            const int *nm = S.nm[t];
+            // values 0..3 of a row sit in the low dword (4 b <= 32 bits), values 4..7 in the low dword of (packed >> 4 b)
+            uint32_t lo[3], hi[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { lo[k] = (uint32_t)packed[k]; hi[k] = (uint32_t)(packed[k] >> (4 * bb[k])); }
+            uint32_t px[8];
+            if (!generic)
+            { // a16 in the packed form of the F step (limg_hip_kernels.hip phase_f_rows): factor by factor, per factor three 24-bit multiply-adds per pixel (the
+              // re-expansion multiplier sits in the normals), the R and G terms packed by one v_perm_b32 (>> 8 included) and biased (0x3000 + 0x3000 + 0x2000 =
+              // 0x8000) so that plain 32-bit adds sum the halves independently
+              uint32_t accRG[8];
+              int accB[8], accA[8];
+#pragma unroll
+              for (int k = 0; k < 3; k++)
+              {
+                const int4 n = *reinterpret_cast<const int4 *>(nm + 4 * k), m = *reinterpret_cast<const int4 *>(nm + 12 + 4 * k);
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                {
+                  const int d = (int)bfe(i < 4 ? lo[k] : hi[k], (i & 3) * bb[k], bb[k]);
+                  const int t0 = mad_i24(d, n.x, m.x), t1 = mad_i24(d, n.y, m.y), t2 = mad_i24(d, n.z, m.z);
+                  const uint32_t rg = __builtin_amdgcn_perm((uint32_t)t1, (uint32_t)t0, 0x06050201u);
+                  if (k == 0) { accRG[i] = rg; accB[i] = t2 >> 8; } else { accRG[i] += rg; accB[i] += t2 >> 8; }
+                  if (anyAlpha)
+                  {
+                    const int ta = mad_i24(d, n.w, m.w) >> 8;
+                    if (k == 0) accA[i] = ta; else accA[i] += ta;
+                    asm volatile("" : "+v"(accA[i]));
+                  }
+                  asm volatile("" : "+v"(accRG[i]), "+v"(accB[i])); // materialised here (otherwise the packing sinks to the next factor's adds and the products stay live)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+              }
+              const uint32_t alphaConst = fl & 0xFF00u;
 #pragma unroll
               for (int i = 0; i < 8; i++)
               {
-                const int d = (int)mul_u24(bfe(i < 4 ? lo[k] : hi[k], (i & 3) * bb[k], bb[k]), (uint32_t)mulK[k]);
-                const int t0 = mad_i24(d, n.x, m.x), t1 = mad_i24(d, n.y, m.y), t2 = mad_i24(d, n.z, m.z);
-                const uint32_t rg = __builtin_amdgcn_perm((uint32_t)t1, (uint32_t)t0, 0x06050201u);
-                if (k == 0) { accRG[i] = rg; accB[i] = t2 >> 8; } else { accRG[i] += rg; accB[i] += t2 >> 8; }
-                if (anyAlpha)
-                {
-                  const int ta = mad_i24(d, n.w, m.w) >> 8;
-                  if (k == 0) accA[i] = ta; else accA[i] += ta;
-                  asm volatile("" : "+v"(accA[i]));
-                }
-                asm volatile("" : "+v"(accRG[i]), "+v"(accB[i])); // materialised here (otherwise the packing sinks to the next factor's adds and the products stay live)
+                ushort2_t ev = __builtin_bit_cast(ushort2_t, accRG[i]); // estimate + 0x8000 in both halves
+                ev = __builtin_elementwise_max(ev, __builtin_bit_cast(ushort2_t, 0x80008000u));
+                ev = __builtin_elementwise_min(ev, __builtin_bit_cast(ushort2_t, 0x80FF80FFu));
+                uint32_t ba = (uint32_t)med3_i32(accB[i], 0, 255);
+                if (anyAlpha) ba |= (uint32_t)med3_i32(accA[i], 0, 255) << 8; else ba |= alphaConst;
+                px[i] = __builtin_amdgcn_perm(ba, __builtin_bit_cast(uint32_t, ev), 0x05040200u);
               }
-              __builtin_amdgcn_sched_barrier(0);
-            }
-            const uint32_t alphaConst = fl & 0xFF00u;
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-            {
-              ushort2_t ev = __builtin_bit_cast(ushort2_t, accRG[i]); // estimate + 0x8000 in both halves
-              ev = __builtin_elementwise_max(ev, __builtin_bit_cast(ushort2_t, 0x80008000u));
-              ev = __builtin_elementwise_min(ev, __builtin_bit_cast(ushort2_t, 0x80FF80FFu));
-              uint32_t ba = (uint32_t)med3_i32(accB[i], 0, 255);
-              if (anyAlpha) ba |= (uint32_t)med3_i32(accA[i], 0, 255) << 8; else ba |= alphaConst;
-              px[i] = __builtin_amdgcn_perm(ba, __builtin_bit_cast(uint32_t, ev), 0x05040200u);
-            }
-          }
-          else
-          { // record values beyond the packed form's range (never from a fit of byte pixels): 32-bit terms, the low 32 bits of the products like PMULLD
-#pragma unroll 1
-            for (int i = 0; i < 8; i++)
-            {
-              const uint32_t sel = (uint32_t)i & 3u;
-              const int dA = (int)mul_u24(bfe(i < 4 ? lo[0] : hi[0], sel * bb[0], bb[0]), (uint32_t)mulA);
-              const int dB = (int)mul_u24(bfe(i < 4 ? lo[1] : hi[1], sel * bb[1], bb[1]), (uint32_t)mulB);
-              const int dC = (int)mul_u24(bfe(i < 4 ? lo[2] : hi[2], sel * bb[2], bb[2]), (uint32_t)mulC);
-              uint32_t out = 0;
-#pragma unroll
-              for (int c = 0; c < 4; c++)
-              {
-                const int bA = c < 2 ? 0x300000 : 0, bC = c < 2 ? 0x200000 : 0;
-                const int est = add3(mad_i24(dA, nm[c], nm[12 + c] - bA) >> 8, mad_i24(dB, nm[4 + c], nm[16 + c] - bA) >> 8, mad_i24(dC, nm[8 + c], nm[20 + c] - bC) >> 8);
-                out |= (uint32_t)med3_i32(est, 0, 255) << (8 * c);
-              }
-              if (y < p.sizeY && x0 + i < p.sizeX) p.out[(size_t)y * p.sizeX + x0 + i] = out;
-            }
-          }
-          if (y < p.sizeY && !generic)
-          {
-            uint32_t *dst = p.out + (size_t)y * p.sizeX + x0;
-            if (rowAligned && x0 + 8 <= p.sizeX)
-            {
-              reinterpret_cast<uint4 *>(dst)[0] = make_uint4(px[0], px[1], px[2], px[3]);
-              reinterpret_cast<uint4 *>(dst)[1] = make_uint4(px[4], px[5], px[6], px[7]);
             }
             else
-            {
-#pragma unroll
+            { // record values beyond the packed form's range somewhere in this group (never from a fit of byte pixels): 32-bit terms, the low 32 bits of the products
+              // like PMULLD; a block of the group that is NOT beyond the range has its multiplier in its normals and 1 here
+              const uint32_t mulw = S.mul[t];
+              const uint32_t mulA = mulw & 0x3FF, mulB = (mulw >> 10) & 0x3FF, mulC = (mulw >> 20) & 0x3FF;
+#pragma unroll 1
               for (int i = 0; i < 8; i++)
-                if (x0 + i < p.sizeX) dst[i] = px[i];
+              {
+                const uint32_t sel = (uint32_t)i & 3u;
+                const int dA = (int)mul_u24(bfe(i < 4 ? lo[0] : hi[0], sel * bb[0], bb[0]), mulA);
+                const int dB = (int)mul_u24(bfe(i < 4 ? lo[1] : hi[1], sel * bb[1], bb[1]), mulB);
+                const int dC = (int)mul_u24(bfe(i < 4 ? lo[2] : hi[2], sel * bb[2], bb[2]), mulC);
+                uint32_t out = 0;
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                {
+                  const int bA = c < 2 ? 0x300000 : 0, bC = c < 2 ? 0x200000 : 0;
+                  const int est = add3(mad_i24(dA, nm[c], nm[12 + c] - bA) >> 8, mad_i24(dB, nm[4 + c], nm[16 + c] - bA) >> 8, mad_i24(dC, nm[8 + c], nm[20 + c] - bC) >> 8);
+                  out |= (uint32_t)med3_i32(est, 0, 255) << (8 * c);
+                }
+                if (y < p.sizeY && x0 + i < p.sizeX) p.out[(size_t)y * p.sizeX + x0 + i] = out;
+              }
+            }
+            if (y < p.sizeY && !generic)
+            {
+              uint32_t *dst = p.out + (size_t)y * p.sizeX + x0;
+              if (rowAligned && x0 + 8 <= p.sizeX)
+              {
+                reinterpret_cast<uint4 *>(dst)[0] = make_uint4(px[0], px[1], px[2], px[3]);
+                reinterpret_cast<uint4 *>(dst)[1] = make_uint4(px[4], px[5], px[6], px[7]);
+              }
+              else
+              {
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                  if (x0 + i < p.sizeX) dst[i] = px[i];
+              }
             }
           }
+          wave_lds_fence();
         }
-        wave_lds_fence();
+        if (next >= nUnits) break; // (wave-uniform)
+        unit = next;
+#pragma unroll
+        for (int i = 0; i < 14; i++) e[i] = en[i];
       }
     }
   }
@@ -486,6 +548,15 @@ namespace limg_hip
 
   void launch_stream_decode(const DecodeParams &p, hipStream_t s)
   {
-    hipLaunchKernelGGL(k_stream_decode, dim3((p.nBlocks + kTile - 1) / kTile), dim3(kTile), 0, s, p);
+    // persistent: one workgroup of four waves per residency slot (4 per CU), every wave strides over the units of 64 blocks
+    static int slots = 0;
+    if (!slots)
+    {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      slots = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount * 4 : 1024;
+    }
+    const uint32_t units = (p.nBlocks + 63u) / 64u, need = (units + 3u) / 4u;
+    hipLaunchKernelGGL(k_stream_decode, dim3(need < (uint32_t)slots ? need : (uint32_t)slots), dim3(kTile), 0, s, p);
   }
 }

@@ -126,6 +126,37 @@ def test_height_ragged_shapes(gpu, oracle, w, h, alpha):
         _assert_planes(gpu.encode3d(img, alpha, error_factor=25), oracle.encode3d(img, alpha, error_factor=25), (w, h, alpha, "ef25"))
 
 
+@pytest.mark.parametrize("w,h,alpha", [(510, 520, True), (509, 515, False), (1022, 1024, True)])
+def test_width_ragged_band_pipeline(gpu, oracle, w, h, alpha):
+    """A partial last block COLUMN puts the whole dither chain on the host (reference: a call over rx x ry pixels is N / 8 AES rounds + N % 8 PCG steps, src/limg.cpp:824-879,
+    :1899-1905).  From 64 x 32 blocks on the walk is pipelined with the GPU in bands of block rows (limg_hip_options.ragged_bands): automatic, off, 3 and 64 bands must all
+    give the oracle's planes."""
+    img = oracle.photo_noise(w, h, 47)
+    want = oracle.encode3d(img, alpha)
+    for bands in (0, -1, 3, 64):
+        gpu.set_options(ragged_bands=bands)
+        try:
+            _assert_planes(gpu.encode3d(img, alpha), want, (w, h, alpha, "bands", bands))
+        finally:
+            gpu.set_options()
+    _assert_planes(gpu.encode3d(img, alpha, error_factor=25), oracle.encode3d(img, alpha, error_factor=25), (w, h, alpha, "ef25"))
+
+
+@pytest.mark.parametrize("w,h", [(300, 1000), (1022, 517)])
+def test_width_ragged_parallel_chain_walks(gpu, oracle, w, h):
+    """With a thread pool the reference's strips restart the chain (src/limg.cpp:2114-2134): independent chains, walked on several host threads at once
+    (limg_hip_options.ragged_walk_threads: automatic, serial, 3) -- same planes as the oracle's strip partition."""
+    img = oracle.photo_noise(w, h, 53)
+    for pool in (1, 2, 3):
+        want = oracle.encode3d(img, True, pool_threads=pool)
+        for threads in (0, 1, 3):
+            gpu.set_options(ragged_walk_threads=threads)
+            try:
+                _assert_planes(gpu.encode3d(img, True, pool_threads=pool), want, (w, h, "pool", pool, "threads", threads))
+            finally:
+                gpu.set_options()
+
+
 def test_height_ragged_at_4096(gpu, oracle):
     """4096 x 4090 photo-noise: fast path + last row against the whole-image ragged path of the same build, every plane compared on the device; the bottom band
     (rows 3968 ...: the last full block rows and the partial one) cannot be checked by the oracle alone -- its chain position depends on everything above -- so the

@@ -53,7 +53,10 @@ def main():
         kw = dict(error_factor=ef, fast=fast)
         whole = bool(rng.random() < 0.3)  # images with a partial last block row: the whole-image host walk instead of fast path + last row
         recipe["whole_image_ragged"] = whole
-        g.set_options(force_split=split, dither_pcg=pcg, legacy_float_stage=legacy, test_whole_image_ragged=whole)
+        bands = int([0, 0, 2, 3, 7, -1][int(rng.integers(0, 6))])   # images with a partial last column: the host's chain walk pipelined in this many bands
+        wthreads = int([0, 1, 2, 5][int(rng.integers(0, 4))])       # ... or, with several chains, walked on this many host threads
+        recipe["ragged_bands"], recipe["ragged_walk_threads"] = bands, wthreads
+        g.set_options(force_split=split, dither_pcg=pcg, legacy_float_stage=legacy, test_whole_image_ragged=whole, ragged_bands=bands, ragged_walk_threads=wthreads)
         mode = ["fixed", "stream", "blocked", "batch"][int(rng.integers(0, 4))]
         if mode == "fixed":
             want = orc.encode3d(img, alpha, pool_threads=pool, dither_mode=int(pcg), **kw)

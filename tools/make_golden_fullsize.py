@@ -31,11 +31,28 @@ CASES = {
     "pn16384x2048": ("pn", 16384, 2048, 1, {}),                            # strip 0 of BASELINE config 5 (rows 0..2047 of the 16384^2 image)
     "pn16384x2048_pool2": ("pn", 16384, 2048, 1, {"pool_threads": 2}),
 }
+# BASELINE config 5 whole (16384^2 photo-noise), hashed PER STRIP of 2048 rows (the 8 strips of src/limg.cpp:2114-2134 for a pool of 2 threads = what the ranks of a
+# multi-GPU job hold): with one chain through all strips (pThreadPool == nullptr) and with the chain restarted per strip (pool of 2).  A rank -- whatever the world
+# size that divides 8 -- can check the rows it produced without the other ranks' planes.
+STRIPPED = {
+    "pn16384_strips": ("pn", 16384, 16384, 1, {}),
+    "pn16384_pool2_strips": ("pn", 16384, 16384, 1, {"pool_threads": 2}),
+}
 # merged-block encoder: (generator, size, seed)
 BLOCKED = {
     "blocked_pn4096": ("pn", 4096, 1), "blocked_rg4096": ("rg", 4096, 1),
     "blocked_pn8192": ("pn", 8192, 1), "blocked_rg8192": ("rg", 8192, 1),
 }
+
+
+def sum64(a):
+    """A position-sensitive checksum a GPU can compute in parallel (bench.py --verify-golden does, with torch): over the array's elements e_i (uint32 words or bytes) as
+    unsigned 64-bit wrap-around sums [sum e_i, sum (i + 1) e_i].  (FNV-1a is a byte-serial chain: fine for tests that bring the planes to the host, useless on the device.)"""
+    import numpy as np
+    v = np.ascontiguousarray(a).reshape(-1).astype(np.uint64)
+    idx = np.arange(1, v.size + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        return [int(v.sum(dtype=np.uint64)), int((v * idx).sum(dtype=np.uint64))]
 
 
 def make_input(orc, gen, w, h, seed):
@@ -57,6 +74,20 @@ def main():
         psnr, mse = ref.compare(img, r["pDecoded"], True)
         out[name] = {"kind": "encode3d", "gen": gen, "w": w, "h": h, "seed": seed, "alpha": True, "kw": kw, "input": orc.fnv(img), "psnr": psnr, "mse": mse,
                      "planes": {k: orc.fnv(r[k]) for k in PLANES}}
+        print(name, "%.4f dB" % psnr, "%.1f s" % (time.time() - t0), flush=True)
+        del r, img
+        json.dump(out, open(OUT, "w"), indent=1)
+    for name, (gen, w, h, seed, kw) in STRIPPED.items():
+        if args.only is not None and name not in args.only:
+            continue
+        t0 = time.time()
+        img = make_input(orc, gen, w, h, seed)
+        r = ref.encode3d(img, True, **kw)
+        psnr, mse = ref.compare(img, r["pDecoded"], True)
+        rows = h // 8
+        out[name] = {"kind": "encode3d_strips", "gen": gen, "w": w, "h": h, "seed": seed, "alpha": True, "kw": kw, "psnr": psnr, "mse": mse, "strip_rows": rows,
+                     "strips": [{"input": orc.fnv(img[i * rows:(i + 1) * rows]), "planes": {k: orc.fnv(r[k][i * rows:(i + 1) * rows]) for k in PLANES},
+                                 "sum64": {k: sum64(r[k][i * rows:(i + 1) * rows]) for k in PLANES}} for i in range(8)]}
         print(name, "%.4f dB" % psnr, "%.1f s" % (time.time() - t0), flush=True)
         del r, img
         json.dump(out, open(OUT, "w"), indent=1)

@@ -1,0 +1,14 @@
+#!/usr/bin/env bash
+# Build container, after tools/r05/suite_prof.sh and suite_bench.sh ran on the GPU box: copy what is to be judged from gpurun_out/ (scratch) into profiles/ (tracked).
+set -e
+for t in r05_final r05_final_rg4096 r05_final_c4 r05_final_stream; do
+  [ -f gpurun_out/prof_$t/summary.txt ] && cp gpurun_out/prof_$t/summary.txt profiles/${t}_summary.txt
+  f=$(find gpurun_out/prof_$t/trace -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" profiles/${t}_kernel_stats.csv
+done
+[ -s gpurun_out/profiles/pmc_by_workload.json ] && cp gpurun_out/profiles/pmc_by_workload.json profiles/pmc_by_workload.json
+for f in gpurun_out/r05_final/bench_*.json; do
+  n=$(basename $f .json); n=${n#bench_}
+  if [ "$n" = default ]; then cp $f profiles/r05_bench_final.json; else cp $f profiles/r05_bench_final_$n.json; fi
+done
+cp gpurun_out/r05_final/rc.txt profiles/r05_bench_final_rc.txt
+python tools/profiles_index.py

@@ -1,0 +1,9 @@
+#!/usr/bin/env bash
+# Round 5 evidence, part 1 (GPU box): rocprofv3 kernel trace + PMC passes of the bench modes whose lines quote counters, on the build in the tree.
+# Writes gpurun_out/prof_r05_*/ and gpurun_out/profiles/pmc_by_workload.json; copy the summaries and the json into profiles/ afterwards (tools/r05/collect.sh).
+set -o pipefail
+rm -f gpurun_out/profiles/pmc_by_workload.json; mkdir -p gpurun_out/profiles; echo '{}' > gpurun_out/profiles/pmc_by_workload.json
+bash tools/prof.sh r05_final --steps 25 | tail -1
+bash tools/prof.sh r05_final_rg4096 --size 4096 --workload random_gradient | tail -1
+bash tools/prof.sh r05_final_c4 --config 4 --steps 2 --warmup 1 | tail -1
+PROF_KERNEL=k_stream_decode bash tools/prof.sh r05_final_stream --stream | tail -1
