@@ -243,6 +243,61 @@ namespace limg_hip
     // known, ahead of the (long) constant preparation.  Units go to waves with a fixed stride: there is no dependence between units, so no ticket is needed.
     // The re-expansion multiplier is folded into the normals (value * (mul * n) == (value * mul) * n exactly: 8 + 21 bits for records the packed form accepts);
     // blocks with larger records (never from a fit of byte pixels) keep both apart and take the generic loop.
+    // a16 for the 8 pixels of one block row in the packed form of the F step (limg_hip_kernels.hip phase_f_rows), factor by factor: per factor and pixel one v_bfe_u32 and
+    // three 24-bit multiply-adds (the re-expansion multiplier sits in the normals).  The terms never live as 32-bit values: one v_perm_b32 packs a pixel's R and G terms
+    // (>> 8 included) into the halves of a register, another the B terms of a PAIR of pixels; the additive constants carry biases (0x3000 + 0x3000 + 0x2000 = 0x8000
+    // over the three factors) so that plain 32-bit adds sum the halves independently and the sums are the estimates in offset binary, which unsigned packed max / min
+    // clamp.  ALPHA: some block of the group has a varying alpha lane: that lane as 32-bit terms; otherwise it is one value per block (alphaRep: the byte
+    // at bits 8..15 and 24..31).  A template on ALPHA, not a run-time test inside the loops: the test per (factor, pixel) compiled to 24 scalar branches per row.
+    template <bool ALPHA>
+    __device__ __forceinline__ void decode_row_packed(const int *nm, const uint32_t lo[3], const uint32_t hi[3], const uint32_t bb[3], uint32_t alphaRep, uint32_t px[8])
+    {
+      uint32_t accRG[8], accBB[4];
+      int accA[8];
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+      {
+        const int4 n = *reinterpret_cast<const int4 *>(nm + 4 * k), m = *reinterpret_cast<const int4 *>(nm + 12 + 4 * k);
+#pragma unroll
+        for (int i = 0; i < 8; i += 2)
+        {
+          const int d0 = (int)bfe(i < 4 ? lo[k] : hi[k], (uint32_t)(i & 3) * bb[k], bb[k]), d1 = (int)bfe(i < 4 ? lo[k] : hi[k], (uint32_t)((i + 1) & 3) * bb[k], bb[k]);
+          const int r0 = mad_i24(d0, n.x, m.x), g0 = mad_i24(d0, n.y, m.y), b0 = mad_i24(d0, n.z, m.z);
+          const int r1 = mad_i24(d1, n.x, m.x), g1 = mad_i24(d1, n.y, m.y), b1 = mad_i24(d1, n.z, m.z);
+          const uint32_t rg0 = __builtin_amdgcn_perm((uint32_t)g0, (uint32_t)r0, 0x06050201u), rg1 = __builtin_amdgcn_perm((uint32_t)g1, (uint32_t)r1, 0x06050201u);
+          const uint32_t bbp = __builtin_amdgcn_perm((uint32_t)b1, (uint32_t)b0, 0x06050201u);
+          if (k == 0) { accRG[i] = rg0; accRG[i + 1] = rg1; accBB[i >> 1] = bbp; }
+          else { accRG[i] += rg0; accRG[i + 1] += rg1; accBB[i >> 1] += bbp; }
+          if (ALPHA)
+          {
+            const int a0 = mad_i24(d0, n.w, m.w) >> 8, a1 = mad_i24(d1, n.w, m.w) >> 8;
+            if (k == 0) { accA[i] = a0; accA[i + 1] = a1; } else { accA[i] += a0; accA[i + 1] += a1; }
+            asm volatile("" : "+v"(accA[i]), "+v"(accA[i + 1]));
+          }
+          asm volatile("" : "+v"(accRG[i]), "+v"(accRG[i + 1]), "+v"(accBB[i >> 1])); // materialised here (otherwise the packing sinks to the next factor's adds and the products stay live)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; i += 2)
+      {
+        ushort2_t bv = __builtin_bit_cast(ushort2_t, accBB[i >> 1]); // B estimates of the pair + 0x8000
+        bv = __builtin_elementwise_max(bv, __builtin_bit_cast(ushort2_t, 0x80008000u));
+        bv = __builtin_elementwise_min(bv, __builtin_bit_cast(ushort2_t, 0x80FF80FFu));
+        uint32_t ba = __builtin_bit_cast(uint32_t, bv); // bytes: B of pixel i, 0x80, B of pixel i + 1, 0x80
+        if (!ALPHA) ba = (ba & 0x00FF00FFu) | alphaRep;  // ... the block's alpha value in the odd bytes
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+        {
+          ushort2_t ev = __builtin_bit_cast(ushort2_t, accRG[i + q]); // R and G estimates + 0x8000
+          ev = __builtin_elementwise_max(ev, __builtin_bit_cast(ushort2_t, 0x80008000u));
+          ev = __builtin_elementwise_min(ev, __builtin_bit_cast(ushort2_t, 0x80FF80FFu));
+          if (!ALPHA) px[i + q] = __builtin_amdgcn_perm(ba, __builtin_bit_cast(uint32_t, ev), q == 0 ? 0x05040200u : 0x07060200u); // R, G = low bytes of ev's halves; B, A from `ba`
+          else px[i + q] = lshl_or((uint32_t)med3_i32(accA[i + q], 0, 255), 24u, __builtin_amdgcn_perm(ba, __builtin_bit_cast(uint32_t, ev), q == 0 ? 0x0C040200u : 0x0C060200u));
+        }
+      }
+    }
+
     struct DecodeWaveLds
     {
       int nm[64][24];           // per block: 12 effective normals (multiplier folded in unless the block is `big`), 12 additive constants
@@ -379,7 +434,7 @@ namespace limg_hip
               }
               else if (channels == 3) { n = 0; m = 0xFFFF; } // src/limg_decode.h:95-97
               S.nm[lane][f * 4 + c] = big ? n : n * fmul; // |n| <= 5400 and mul <= 256: 21 bits, a 24-bit operand
-              S.nm[lane][12 + f * 4 + c] = (int)(((uint32_t)m << 8) + 128u + (uint32_t)(c < 2 ? (f == 2 ? 0x200000 : 0x300000) : 0)); // R and G carry the packed form's biases
+              S.nm[lane][12 + f * 4 + c] = (int)(((uint32_t)m << 8) + 128u + (uint32_t)(c < 3 ? (f == 2 ? 0x200000 : 0x300000) : 0)); // R, G and B carry the packed form's biases
             }
           }
           { // per-block flags of the packed decode (same rules as the F step's phase_f_prepare, limg_hip_kernels.hip)
@@ -452,43 +507,9 @@ namespace limg_hip
             for (int k = 0; k < 3; k++) { lo[k] = (uint32_t)packed[k]; hi[k] = (uint32_t)(packed[k] >> (4 * bb[k])); }
             uint32_t px[8];
             if (!generic)
-            { // a16 in the packed form of the F step (limg_hip_kernels.hip phase_f_rows): factor by factor, per factor three 24-bit multiply-adds per pixel (the
-              // re-expansion multiplier sits in the normals), the R and G terms packed by one v_perm_b32 (>> 8 included) and biased (0x3000 + 0x3000 + 0x2000 =
-              // 0x8000) so that plain 32-bit adds sum the halves independently
-              uint32_t accRG[8];
-              int accB[8], accA[8];
-#pragma unroll
-              for (int k = 0; k < 3; k++)
-              {
-                const int4 n = *reinterpret_cast<const int4 *>(nm + 4 * k), m = *reinterpret_cast<const int4 *>(nm + 12 + 4 * k);
-#pragma unroll
-                for (int i = 0; i < 8; i++)
-                {
-                  const int d = (int)bfe(i < 4 ? lo[k] : hi[k], (i & 3) * bb[k], bb[k]);
-                  const int t0 = mad_i24(d, n.x, m.x), t1 = mad_i24(d, n.y, m.y), t2 = mad_i24(d, n.z, m.z);
-                  const uint32_t rg = __builtin_amdgcn_perm((uint32_t)t1, (uint32_t)t0, 0x06050201u);
-                  if (k == 0) { accRG[i] = rg; accB[i] = t2 >> 8; } else { accRG[i] += rg; accB[i] += t2 >> 8; }
-                  if (anyAlpha)
-                  {
-                    const int ta = mad_i24(d, n.w, m.w) >> 8;
-                    if (k == 0) accA[i] = ta; else accA[i] += ta;
-                    asm volatile("" : "+v"(accA[i]));
-                  }
-                  asm volatile("" : "+v"(accRG[i]), "+v"(accB[i])); // materialised here (otherwise the packing sinks to the next factor's adds and the products stay live)
-                }
-                __builtin_amdgcn_sched_barrier(0);
-              }
-              const uint32_t alphaConst = fl & 0xFF00u;
-#pragma unroll
-              for (int i = 0; i < 8; i++)
-              {
-                ushort2_t ev = __builtin_bit_cast(ushort2_t, accRG[i]); // estimate + 0x8000 in both halves
-                ev = __builtin_elementwise_max(ev, __builtin_bit_cast(ushort2_t, 0x80008000u));
-                ev = __builtin_elementwise_min(ev, __builtin_bit_cast(ushort2_t, 0x80FF80FFu));
-                uint32_t ba = (uint32_t)med3_i32(accB[i], 0, 255);
-                if (anyAlpha) ba |= (uint32_t)med3_i32(accA[i], 0, 255) << 8; else ba |= alphaConst;
-                px[i] = __builtin_amdgcn_perm(ba, __builtin_bit_cast(uint32_t, ev), 0x05040200u);
-              }
+            {
+              if (anyAlpha) decode_row_packed<true>(nm, lo, hi, bb, 0u, px);
+              else decode_row_packed<false>(nm, lo, hi, bb, (fl & 0xFF00u) * 0x10001u, px);
             }
             else
             { // record values beyond the packed form's range somewhere in this group (never from a fit of byte pixels): 32-bit terms, the low 32 bits of the products
@@ -506,7 +527,7 @@ namespace limg_hip
 #pragma unroll
                 for (int c = 0; c < 4; c++)
                 {
-                  const int bA = c < 2 ? 0x300000 : 0, bC = c < 2 ? 0x200000 : 0;
+                  const int bA = c < 3 ? 0x300000 : 0, bC = c < 3 ? 0x200000 : 0;
                   const int est = add3(mad_i24(dA, nm[c], nm[12 + c] - bA) >> 8, mad_i24(dB, nm[4 + c], nm[16 + c] - bA) >> 8, mad_i24(dC, nm[8 + c], nm[20 + c] - bC) >> 8);
                   out |= (uint32_t)med3_i32(est, 0, 255) << (8 * c);
                 }
