@@ -14,7 +14,10 @@ SOURCES = ["limg_hip_kernels.hip", "limg_hip_fit_tpb.hip", "limg_hip_stream.hip"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 # per-source extras.  limg_hip_kernels.hip: every atomic in it is issued by one lane (block queue, ticket, look-back descriptors); LLVM's atomic optimizer would still
 # wrap each in its wave-aggregation prologue (v_mbcnt x 2, compare, s_bcnt1, broadcast, add) -- five vector instructions per 8x8 block for nothing
-SOURCE_FLAGS = {"limg_hip_kernels.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]}
+SOURCE_FLAGS = {"limg_hip_kernels.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
+                # k_stream_decode: LLVM reports one `#pragma unroll` it did not honour (a transformation-ordering note, no particular loop: every loop over a register
+                # array IS unrolled -- the kernel has no scratch, which tests/test_decode_isa.py asserts on the compiled assembly)
+                "limg_hip_stream.hip": ["-Wno-pass-failed"]}
 
 
 def _newer(target, deps):

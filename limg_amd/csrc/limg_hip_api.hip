@@ -1334,7 +1334,7 @@ extern "C"
     limg_hip_result r;
     if (!c->streamStatus.p)
     {
-      if ((r = c->streamStatus.ensure(8)) != limg_hip_success) return r;
+      if ((r = c->streamStatus.ensure(256 + 2048)) != limg_hip_success) return r; // the status word, then the decode kernel's store sink (see DecodeParams::sink)
       HIP_TRY(hipMemsetAsync(c->streamStatus.p, 0, 8, s));
     }
     DecodeParams dp;
@@ -1343,7 +1343,7 @@ extern "C"
     dp.blocksX = (uint32_t)((sizeX + kBlock - 1) / kBlock); dp.blocksY = (uint32_t)((sizeY + kBlock - 1) / kBlock);
     dp.nBlocks = dp.blocksX * dp.blocksY;
     if (streamBytes < sizeof(limg_hip_stream_header) + (size_t)dp.nBlocks * sizeof(limg_hip_stream_block)) return limg_hip_error_OutOfBounds;
-    dp.stream = pStream; dp.streamBytes = streamBytes; dp.out = pOut; dp.status = (uint32_t *)c->streamStatus.p;
+    dp.stream = pStream; dp.streamBytes = streamBytes; dp.out = pOut; dp.status = (uint32_t *)c->streamStatus.p; dp.sink = (uint32_t *)((uint8_t *)c->streamStatus.p + 256);
     mark(c, s);
     launch_stream_decode(dp, s);
     mark(c, s); mark(c, s); mark(c, s);

@@ -98,6 +98,8 @@ namespace limg_hip
     unsigned long long streamBytes;
     uint32_t *out;
     uint32_t *status; // bit 0: header mismatch, bit 1: inconsistent payload offsets
+    uint32_t *sink;   // 2 KiB nobody reads: where lanes whose block row is not (wholly) inside the image send their two 16-byte stores, so that EVERY lane of EVERY group issues
+                      // exactly two stores and the wait for the next payload run can be counted (s_waitcnt vmcnt(2)) instead of draining the stores (vmcnt(0)); see k_stream_decode
   };
 
   const uint64_t *noise_checkpoints_host(size_t *pCount, size_t *pEvery);

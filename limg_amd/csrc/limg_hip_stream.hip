@@ -392,16 +392,30 @@ namespace limg_hip
           G.n = G.ok ? (uint32_t)(endWord - G.off0) : 0u;
           return G;
         };
-        auto fetch = [&](const Group &G, uint2 buf[3]) {
+        // The payload run of a group: up to three 8-byte loads per lane, issued as inline assembly and waited for with an explicit COUNTED s_waitcnt.  Why by hand: vmcnt counts loads and stores alike and retires them in order, so "wait until at most
+        // two are outstanding" right behind a group's two stores means "my three loads, issued before them, are back" -- while the compiler's own bookkeeping for a load
+        // that is consumed across the loop's back edge ends in vmcnt(0), which also drains those stores: every wave then sat out the HBM write latency once per group
+        // (SQ_WAIT_ANY: 0.51 of the waves' cycles).  The compiler believes the three registers are defined where the asm statement stands; nothing may read them before
+        // payload_wait<N>() -- the only reader is stage_run() below, and the ISA is checked for stray copies (tools/r05/check_decode_isa.sh).
+        auto fetch = [&](const Group &G, unsigned long long buf[3]) {
 #pragma unroll
           for (int i = 0; i < 3; i++)
           {
-            buf[i] = make_uint2(0, 0);
-            if ((uint32_t)(lane + 64 * i) < G.n) buf[i] = payload[(size_t)G.off0 + lane + 64 * i];
+            if ((uint32_t)(lane + 64 * i) < G.n) // (G.n: validated against the payload's size in group_info; a typical run needs the first of the three only)
+            {
+              const uint2 *src = payload + ((size_t)G.off0 + (uint32_t)(lane + 64 * i));
+              asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(buf[i]) : "v"(src) : "memory");
+            }
           }
         };
+        auto stage_run = [&](const Group &G, const unsigned long long buf[3]) {
+          unsigned long long *dst = reinterpret_cast<unsigned long long *>(stage);
+#pragma unroll
+          for (int i = 0; i < 3; i++)
+            if ((uint32_t)(lane + 64 * i) < G.n) dst[lane + 64 * i] = buf[i];
+        };
         Group cur = group_info(0);
-        uint2 buf[3];
+        unsigned long long buf[3];
         fetch(cur, buf);
 
         // ---- 2. the block's decode constants (lane == block of the unit), under the first payload request ----
@@ -454,7 +468,10 @@ namespace limg_hip
           const uint32_t by = g / p.blocksX;
           S.by[lane] = by; S.bx[lane] = g - by * p.blocksX;
         }
-        // ---- 3. the NEXT unit's entries: in flight while this unit's groups are decoded ----
+        // ---- 3. the first run into the LDS stage (the one full wait per unit: nothing counted lies between its loads and here), then the NEXT unit's entries:
+        //         in flight while this unit's groups are decoded ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stage_run(cur, buf);
         const uint32_t next = unit + nWaves;
         uint32_t en[14];
         if (next < nUnits) load_entry(p, next * 64u + (uint32_t)lane, en);
@@ -463,27 +480,22 @@ namespace limg_hip
         for (int grp = 0; grp < 8; grp++)
         {
           if (!cur.any) break; // wave-uniform
-          const Group G = cur;
-          {
-            uint2 *dst = reinterpret_cast<uint2 *>(stage);
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-              if ((uint32_t)(lane + 64 * i) < G.n) dst[lane + 64 * i] = buf[i];
-          }
+          const Group G = cur; // its run is in the stage
           cur = group_info(grp + 1);
-          fetch(cur, buf);
+          fetch(cur, buf); // the next group's run: three loads, then (below) this group's two stores, then the counted wait
           if (!G.ok)
-          {
+          { // inconsistent offsets: the stream is refused (status word) and this group is not decoded; no stores follow the loads here, so the wait is a full one
             if (lane == 0) atomicOr(p.status, 2u);
-            continue;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           }
+          else
+          {
           const uint32_t t = G.t, bw = G.bw, myOff = G.myOff, off0 = G.off0;
           const bool valid = G.valid;
           const uint32_t fl = valid ? S.flags[t] : 0u;
           const bool generic = __builtin_amdgcn_ballot_w64((fl & 1u) != 0u) != 0ull, anyAlpha = __builtin_amdgcn_ballot_w64((fl & 2u) != 0u) != 0ull; // wave-uniform
           wave_lds_fence();
-          if (valid)
-          {
+          { // (no `if (valid)` around this: lanes without a block decode zeros and store to the sink -- see the stores below)
             const uint32_t y = S.by[t] * 8 + r, x0 = S.bx[t] * 8;
             uint32_t fieldByte = (myOff - off0) * 8;
             unsigned long long packed[3];
@@ -516,7 +528,7 @@ namespace limg_hip
               // like PMULLD; a block of the group that is NOT beyond the range has its multiplier in its normals and 1 here
               const uint32_t mulw = S.mul[t];
               const uint32_t mulA = mulw & 0x3FF, mulB = (mulw >> 10) & 0x3FF, mulC = (mulw >> 20) & 0x3FF;
-#pragma unroll 1
+#pragma unroll
               for (int i = 0; i < 8; i++)
               {
                 const uint32_t sel = (uint32_t)i & 3u;
@@ -531,25 +543,29 @@ namespace limg_hip
                   const int est = add3(mad_i24(dA, nm[c], nm[12 + c] - bA) >> 8, mad_i24(dB, nm[4 + c], nm[16 + c] - bA) >> 8, mad_i24(dC, nm[8 + c], nm[20 + c] - bC) >> 8);
                   out |= (uint32_t)med3_i32(est, 0, 255) << (8 * c);
                 }
-                if (y < p.sizeY && x0 + i < p.sizeX) p.out[(size_t)y * p.sizeX + x0 + i] = out;
+                px[i] = out;
               }
             }
-            if (y < p.sizeY && !generic)
-            {
-              uint32_t *dst = p.out + (size_t)y * p.sizeX + x0;
-              if (rowAligned && x0 + 8 <= p.sizeX)
-              {
-                reinterpret_cast<uint4 *>(dst)[0] = make_uint4(px[0], px[1], px[2], px[3]);
-                reinterpret_cast<uint4 *>(dst)[1] = make_uint4(px[4], px[5], px[6], px[7]);
-              }
-              else
-              {
+            // EVERY lane issues exactly two 16-byte stores per group, on every path: a block row wholly inside the image to its place, anything else to the sink.
+            // With the three payload loads above equally unconditional, the wait for the next run is a counted one (vmcnt(2): "all but my last two stores")
+            // and no longer drains the stores of the group just decoded -- which is what the waves spent half their life on (SQ_WAIT_ANY 0.51 of their cycles).
+            const bool inImage = valid && y < p.sizeY;
+            const bool whole = inImage && rowAligned && x0 + 8 <= p.sizeX;
+            uint32_t *dst = whole ? p.out + (size_t)y * p.sizeX + x0 : p.sink + lane * 8;
+            reinterpret_cast<uint4 *>(dst)[0] = make_uint4(px[0], px[1], px[2], px[3]);
+            reinterpret_cast<uint4 *>(dst)[1] = make_uint4(px[4], px[5], px[6], px[7]);
+            if (inImage && !whole)
+            { // partial edge blocks, rows that are not 16-byte aligned: pixel by pixel
+              uint32_t *row = p.out + (size_t)y * p.sizeX + x0;
 #pragma unroll
-                for (int i = 0; i < 8; i++)
-                  if (x0 + i < p.sizeX) dst[i] = px[i];
-              }
+              for (int i = 0; i < 8; i++)
+                if (x0 + i < p.sizeX) row[i] = px[i];
             }
           }
+          } // (G.ok)
+          wave_lds_fence(); // every lane is done reading this group's run
+          asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); // all but the two stores above (more on the edge path: then this waits for a few stores too): the run of `cur` is in
+          stage_run(cur, buf);
           wave_lds_fence();
         }
         if (next >= nUnits) break; // (wave-uniform)

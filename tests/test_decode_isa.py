@@ -1,0 +1,92 @@
+"""k_stream_decode requests its payload runs with inline-assembly loads and waits for them with a hand-counted `s_waitcnt vmcnt(2)` (limg_hip_stream.hip: the compiler's
+own wait for a load consumed across the loop's back edge is vmcnt(0), which also drains the group's stores).  The compiler therefore believes the loaded registers are
+valid from the asm statement on.  This test compiles the kernel to assembly (hipcc cross-compiles without a GPU) and checks the two things that belief must not break:
+no instruction reads a register pair with a load in flight before the next hand-written wait, and every path from those loads to the wait is free of scratch traffic
+(a spill reload would count in vmcnt and void the count)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_inflight_payload_registers_are_not_touched(tmp_path):
+    out = tmp_path / "stream.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-S", "--cuda-device-only",
+                           os.path.join(ROOT, "limg_amd", "csrc", "limg_hip_stream.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+    text = out.read_text().splitlines()
+    start = next(i for i, l in enumerate(text) if l.startswith("_ZN8limg_hip12_GLOBAL__N_115k_stream_decodeE"))
+    end = next(i for i in range(start, len(text)) if text[i].startswith(".Lfunc_end"))
+    body = text[start:end]
+    assert not any("scratch_" in l for l in body), "k_stream_decode spills: a scratch reload counts in vmcnt and voids the hand-counted wait"
+    # basic blocks (labels, branches) and a forward data-flow of "register pairs with a hand-issued load in flight" over them: the loads of a run's second and third
+    # piece sit in out-of-line blocks, so a linear scan would not do
+    blocks, order, cur, in_asm = {}, [], "entry", False
+    blocks[cur] = []
+    order.append(cur)
+    for l in body[1:]:
+        t = l.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        m = re.match(r"^(\.LBB\d+_\d+):", t)
+        if m:
+            cur = m.group(1)
+            blocks[cur] = []
+            order.append(cur)
+            continue
+        if not t or t.startswith(";") or t.startswith("."):
+            continue
+        blocks[cur].append((t.split(";")[0].strip(), in_asm))
+    succ = {}
+    for i, b in enumerate(order):
+        out, fall = [], True
+        for t, _ in blocks[b]:
+            m = re.match(r"s_(cbranch_\w+|branch) (\.LBB\d+_\d+)", t)
+            if m:
+                out.append(m.group(2))
+                if m.group(1) == "branch":
+                    fall = False
+            if t.startswith("s_endpgm"):
+                fall = False
+        if fall and i + 1 < len(order):
+            out.append(order[i + 1])
+        succ[b] = out
+    loads = waits = 0
+    state = {b: None for b in order}
+    state["entry"] = frozenset()
+    work = ["entry"]
+    while work:
+        b = work.pop()
+        pending = set(state[b])
+        for t, asm in blocks[b]:
+            if asm and t.startswith("global_load_dwordx2"):
+                m = re.match(r"global_load_dwordx2 v\[(\d+):(\d+)\]", t)
+                assert m, t
+                pending |= {int(m.group(1)), int(m.group(2))}
+                loads += 1
+                continue
+            if asm and t.startswith("s_waitcnt vmcnt("):
+                pending.clear()
+                waits += 1
+                continue
+            if t.startswith("s_cbranch") or t.startswith("s_branch"):
+                continue
+            if pending:
+                regs = set(int(x) for x in re.findall(r"\bv(\d+)\b", t))
+                for a0, b0 in re.findall(r"v\[(\d+):(\d+)\]", t):
+                    regs |= set(range(int(a0), int(b0) + 1))
+                assert not (regs & pending), "register with a payload load in flight is touched before the counted wait: %s (in flight: v%s, block %s)" % (t, sorted(pending), b)
+        for n in succ[b]:
+            new = frozenset(pending) if state[n] is None else state[n] | frozenset(pending)
+            if new != state[n]:
+                state[n] = new
+                work.append(n)
+    assert loads >= 6 and waits >= 2, (loads, waits)  # three loads at a unit's top, three in the group loop; the full wait and the counted one
