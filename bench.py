@@ -520,15 +520,30 @@ def verify_golden(args, units, rows, rank, world, dist, single_chain, W, H, kind
 BLOCKED_BYTES_PER_PIXEL = 4 + 4 * 9 + 4  # the RGBA pixel in; pDecoded, pShiftABCX, six colour planes, pBlockIndex (u32) and three factor planes + pBitsPerPixel (u8) out
 
 
-def blocked_roofline(px, stage_ms):
+def blocked_roofline(px, stage_ms, pmc_key):
     """Kernel-only rate of the merged-block encoder: its algorithmic bytes over the GPU time of its kernels alone (HIP events: pass 1, the similarity kernels, and the sums of the
-    worker's fit + search and expansion + store launches) -- what the GPU side would deliver with no host stage in the way.  The end-to-end rate is `value`."""
+    worker's fit + search and expansion + store launches) -- what the GPU side would deliver with no host stage in the way.  The end-to-end rate is `value`.
+    Counters (tools/prof_blocked.sh, per image): HBM traffic of all its kernels, and for the kernel furthest below any roofline, k_blocked_fit_search, the floor its own
+    instruction count sets: VALU instructions per image / the chip's measured issue rate for this instruction class."""
     gpu_ms = stage_ms["pass1_kernel"] + stage_ms["match_kernels"] + stage_ms["fit_search_kernel"] + stage_ms["expand_store_kernels"]
     ach = BLOCKED_BYTES_PER_PIXEL * px / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else None
-    return {"bound": "hbm", "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4) if ach else None, "traffic": None,
+    pmc = pmc_entry(pmc_key)
+    fs = ((pmc or {}).get("per_kernel") or {}).get("k_blocked_fit_search")
+    fit_search = None
+    if fs and fs.get("valu_instr"):
+        floor_ms = fs["valu_instr"] / VALU_HALF_RATE_PER_S * 1e3
+        fit_search = {"valu_instr_per_image": fs["valu_instr"], "valu_instr_per_pixel": round(fs["valu_instr"] / px, 3), "salu_instr_per_image": fs.get("salu_instr"),
+                      "waves_per_image": fs.get("waves"), "dispatches_per_image": fs.get("dispatches"), "ms_under_profiler": fs.get("ms"),
+                      "issue_floor_ms": round(floor_ms, 3), "valu_busy_own_time": fs.get("valu_busy"), "wait_inst_any_frac": fs.get("wait_inst_any_frac"),
+                      "note": "issue_floor_ms = its wave64 VALU instructions per image / %.0f G/s (the measured half-rate-class ceiling, all SIMDs busy); the kernel runs one wave "
+                              "per rectangle whose life is a serial pixel-order walk, so its time is the longest rectangles' latency chain, not this floor" % (VALU_HALF_RATE_PER_S / 1e9)}
+    return {"bound": "hbm", "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4) if ach else None,
+            "traffic": None if not pmc or pmc.get("fetch_kib") is None else int((2 * pmc["fetch_kib"] + pmc["write_kib"]) * 1024),
+            "pmc_key": pmc_key, "pmc_source": None if not pmc else pmc.get("source"), "pmc_refused_stale_source": pmc_stale_source(pmc_key),
             "kernels_ms": {"k_fit_tpb (pass 1)": stage_ms["pass1_kernel"], "k_blocked_match (16 bands)": stage_ms["match_kernels"], "k_blocked_fit_search": stage_ms["fit_search_kernel"],
                            "k_noise_expand_calls + k_blocked_store (+ chain-value uploads)": stage_ms["expand_store_kernels"]},
-            "bytes_per_pixel": BLOCKED_BYTES_PER_PIXEL,
+            "k_blocked_fit_search": fit_search,
+            "bytes_per_pixel": BLOCKED_BYTES_PER_PIXEL, "algorithmic_bytes_per_launch": int(BLOCKED_BYTES_PER_PIXEL * px),
             "note": "kernel-only: the GPU's share of one image; the end-to-end rate (`value`) is set by the host stages, serial by construction upstream (greedy raster merge, "
                     "one AES dither chain) -- see config.stage_ms.  k_blocked_fit_search is one wave per rectangle walking its pixels in the reference's order: latency- and "
                     "issue-bound, not an HBM kernel"}
@@ -611,7 +626,7 @@ def run_blocked(args, g, dist, rank, world, W, H):
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/i32 integer stage + f32 float stage (bit-exact vs the reference)", "data": "synthetic",
             "config": {"workload": "synthetic %dx%d RGBA %s (seed 1+rank) per GPU, errorFactor %d" % (W, H, args.workload, args.error_factor), "rectangles": nreg,
                        "blocks": (W // 8) * (H // 8), "psnr_db": round(psnr, 4), "stage_ms": mean, "pipelined_stream": pipe},
-            "roofline": blocked_roofline(px, mean),
+            "roofline": blocked_roofline(px, mean, "blocked_%dx%d_%s%s" % (W, H, args.workload, "" if args.error_factor == 100 else "_ef%d" % args.error_factor)),
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -393,6 +393,29 @@ namespace limg_hip
 
     // the 7 block-uniform planes, straight from registers: 16 bytes per lane = four rows of 256 contiguous bytes (8 blocks x 8 px) per store instruction where
     // the rows allow it (p.vecPlanes: width a multiple of 4, 16-byte aligned planes), 4 bytes per lane = one row per instruction otherwise
+    // The 35 bytes per pixel of output planes are written once and never read by this library: stored NON-TEMPORALLY (global_store ... nt) they do not push the
+    // data the kernels DO come back to out of the L2 -- a strip's parked results (8 KiB written by its E step, read by its F step), the records and k_fit_tpb's
+    // rows.  -DLIMG_PLANE_STORES_TEMPORAL builds the plain stores (A/B, tools/r05/ab_nt_stores.sh, same box: 4096^2 gradient 0.331 -> 0.285 ms, config 4 72.6 ->
+    // 74.9 Gpx/s, 8192^2 photo-noise 1.374 -> 1.360 ms; the HBM byte counters do not move -- the parked data still goes out and comes back -- the time does).
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    __device__ __forceinline__ void plane_store16(void *dst, const uint4 &v)
+    {
+#ifdef LIMG_PLANE_STORES_TEMPORAL
+      *reinterpret_cast<uint4 *>(dst) = v;
+#else
+      __builtin_nontemporal_store(u32x4_t{ v.x, v.y, v.z, v.w }, reinterpret_cast<u32x4_t *>(dst));
+#endif
+    }
+    __device__ __forceinline__ void plane_store8(void *dst, const uint2 &v)
+    {
+#ifdef LIMG_PLANE_STORES_TEMPORAL
+      *reinterpret_cast<uint2 *>(dst) = v;
+#else
+      __builtin_nontemporal_store(u32x2_t{ v.x, v.y }, reinterpret_cast<u32x2_t *>(dst));
+#endif
+    }
+
     template <class P, class IO>
     // halves: bit 0 = the strip's rows 0..3, bit 1 = rows 4..7 (the F step issues them at two different points, each beside a memory round trip of its own; the
     // one-row-per-instruction form stores everything with bit 0)
@@ -416,7 +439,7 @@ namespace limg_hip
               size_t g = (size_t)(y0 + row) * p.sizeX + wx0 + col;
               asm volatile("" : "+v"(g)); // one offset for the seven planes (left to itself the compiler adds its three loop-invariant parts to every plane's base separately)
 #pragma unroll
-              for (int k = 0; k < 7; k++) *reinterpret_cast<uint4 *>(planes[k] + g) = cst[k * kStripBlocks];
+              for (int k = 0; k < 7; k++) plane_store16(planes[k] + g, cst[k * kStripBlocks]);
             }
           }
         return;
@@ -566,7 +589,7 @@ namespace limg_hip
       auto store_factor = [&](int k, uint32_t lo, uint32_t hi)
       {
         if (!valid) return;
-        if (p.vecFactors8) *reinterpret_cast<uint2 *>(planes8[k] + g) = make_uint2(lo, hi);
+        if (p.vecFactors8) plane_store8(planes8[k] + g, make_uint2(lo, hi));
         else
         {
 #pragma unroll
@@ -648,8 +671,8 @@ namespace limg_hip
       uint32_t *dst = io.info.pDecoded + g;
       if (p.vecDecoded)
       {
-        reinterpret_cast<uint4 *>(dst)[0] = make_uint4(px[0], px[1], px[2], px[3]);
-        reinterpret_cast<uint4 *>(dst)[1] = make_uint4(px[4], px[5], px[6], px[7]);
+        plane_store16(dst, make_uint4(px[0], px[1], px[2], px[3]));
+        plane_store16(dst + 4, make_uint4(px[4], px[5], px[6], px[7]));
       }
       else
       {
@@ -1011,7 +1034,7 @@ namespace limg_hip
           const uint32_t row = pass * 4 + (tid >> 6), col = (tid & 63) * 4; // 4 px per lane
           if (row < ry && col < stripW)
           {
-            const uint4 v = *reinterpret_cast<const uint4 *>(io.in + (size_t)(y0 + row) * p.sizeX + x0 + col);
+            const uint4 v = *reinterpret_cast<const uint4 *>(io.in + (size_t)(y0 + row) * p.sizeX + x0 + col); // (as a non-temporal load: measured, no difference -- tools/r05/ab_nt_loads.sh)
             *reinterpret_cast<uint4 *>(&s_strip[row * kRowDw + col]) = v;
           }
         }

@@ -552,8 +552,9 @@ namespace limg_hip
             const bool inImage = valid && y < p.sizeY;
             const bool whole = inImage && rowAligned && x0 + 8 <= p.sizeX;
             uint32_t *dst = whole ? p.out + (size_t)y * p.sizeX + x0 : p.sink + lane * 8;
-            reinterpret_cast<uint4 *>(dst)[0] = make_uint4(px[0], px[1], px[2], px[3]);
-            reinterpret_cast<uint4 *>(dst)[1] = make_uint4(px[4], px[5], px[6], px[7]);
+            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(u32x4_t{ px[0], px[1], px[2], px[3] }, reinterpret_cast<u32x4_t *>(dst));     // (written once, never read here: kept out of the L2's way,
+            __builtin_nontemporal_store(u32x4_t{ px[4], px[5], px[6], px[7] }, reinterpret_cast<u32x4_t *>(dst) + 1); //  like the encoder's planes)
             if (inImage && !whole)
             { // partial edge blocks, rows that are not 16-byte aligned: pixel by pixel
               uint32_t *row = p.out + (size_t)y * p.sizeX + x0;

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Build container, after tools/r05/suite_prof.sh and suite_bench.sh ran on the GPU box: copy what is to be judged from gpurun_out/ (scratch) into profiles/ (tracked).
 set -e
-for t in r05_final r05_final_rg4096 r05_final_c4 r05_final_stream; do
+for t in r05_final r05_final_rg4096 r05_final_c4 r05_final_stream r05_final_blocked r05_final_blocked_rg; do
   [ -f gpurun_out/prof_$t/summary.txt ] && cp gpurun_out/prof_$t/summary.txt profiles/${t}_summary.txt
   f=$(find gpurun_out/prof_$t/trace -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" profiles/${t}_kernel_stats.csv
 done

@@ -7,3 +7,5 @@ bash tools/prof.sh r05_final --steps 25 | tail -1
 bash tools/prof.sh r05_final_rg4096 --size 4096 --workload random_gradient | tail -1
 bash tools/prof.sh r05_final_c4 --config 4 --steps 2 --warmup 1 | tail -1
 PROF_KERNEL=k_stream_decode bash tools/prof.sh r05_final_stream --stream | tail -1
+bash tools/prof_blocked.sh r05_final_blocked | tail -9
+bash tools/prof_blocked.sh r05_final_blocked_rg --workload random_gradient | tail -9
