@@ -20,7 +20,11 @@ run legacy --legacy-float-stage --steps 20 $Q
 run split --split --steps 20 $Q
 run 8192x8190 --steps 20 --size 8192x8190 $Q
 run 8190x8192 --steps 5 --warmup 1 --size 8190x8192 $Q
+run 8190x8192_pool2 --steps 10 --warmup 1 --size 8190x8192 --pool-threads 2 $Q
+run 8190x8192_ctx4 --steps 5 --warmup 1 --size 8190x8192 --contexts 4 $Q
 run 1024x618 --steps 50 --size 1024x618 --rgb $Q
+run gpus2_c5_single_chain_rehearsal --gpus 2 --config 5 --single-chain --share-gpus --verify-golden --no-gather --steps 2 --warmup 1 $Q
+run gpus2_c5_rehearsal --gpus 2 --config 5 --share-gpus --verify-golden --no-gather --steps 2 --warmup 1 $Q
 run stream --stream $Q
 run blocked --blocked --steps 6 --contexts 4 $Q
 run blocked_rg --blocked --steps 6 --contexts 4 --workload random_gradient $Q
