@@ -112,7 +112,7 @@ struct limg_hip_context
   DevBuf in, planes;                             // staging for the host-pointer entry points
   DevBuf cmp;                                    // 8-byte accumulator of limg_hip_compare
   DevBuf bFlags, bBound;
-  DevBuf bMatch, bRegions, bOut, bPx, bV, bFac, bNoise, bNoiseBase; // merged-block encoder: similarity bits, region table / results, scratch, noise
+  DevBuf bMatch, bRegions, bOut, bPx, bFac, bNoise, bNoiseBase; // merged-block encoder: similarity bits, region table / results, scratch (gathered pixels, factor bytes), noise
   HostBuf hFlags;
   HostBuf hRec, hBits, hDesc, hOut, hNoise, hNoiseBase;
   hipStream_t workStream = nullptr; // the merged-block encoder's worker thread launches on its own stream
@@ -900,7 +900,7 @@ extern "C"
     (void)hipDeviceSynchronize();
     DevBuf *bufs[] = { &c->noiseStates, &c->invN, &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->noiseCk, &c->stats, &c->lookback, &c->devStatus, &c->accTable, &c->commWords, &c->park, &c->batchTable, &c->in, &c->planes, &c->cmp,
                        &c->streamFac, &c->streamTiles, &c->streamStatus, &c->streamBuf,
-                       &c->bFlags, &c->bBound, &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bV, &c->bFac, &c->bNoise, &c->bNoiseBase };
+                       &c->bFlags, &c->bBound, &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bFac, &c->bNoise, &c->bNoiseBase };
     for (DevBuf *b : bufs) b->release();
     HostBuf *hbufs[] = { &c->hFlags, &c->hRec, &c->hBits, &c->hDesc, &c->hOut, &c->hNoise, &c->hNoiseBase };
     for (HostBuf *b : hbufs) b->release();
@@ -1072,7 +1072,7 @@ extern "C"
     if (!c) return 0;
     const DevBuf *bufs[] = { &c->bCalls, &c->noiseStates, &c->records, &c->shifts, &c->invN, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->noiseCk, &c->lookback, &c->park, &c->batchTable, &c->stats,
                              &c->accTable, &c->devStatus, &c->commWords, &c->in, &c->planes, &c->cmp, &c->streamFac, &c->streamTiles, &c->streamStatus, &c->streamBuf,
-                             &c->bFlags, &c->bBound, &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bV, &c->bFac, &c->bNoise, &c->bNoiseBase };
+                             &c->bFlags, &c->bBound, &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bFac, &c->bNoise, &c->bNoiseBase };
     size_t sum = 0;
     for (const DevBuf *b : bufs) sum += b->cap;
     return sum;
@@ -1600,7 +1600,6 @@ extern "C"
     if ((r = c->bNoiseBase.ensure(blocks * 8 + 8)) != limg_hip_success) return r;
     if ((r = c->bNoise.ensure(3 * px + 64)) != limg_hip_success) return r;
     if ((r = c->bPx.ensure(capMax * 4)) != limg_hip_success) return r;
-    if ((r = c->bV.ensure(capMax * 16)) != limg_hip_success) return r;
     if ((r = c->bFac.ensure(capMax * 3)) != limg_hip_success) return r;
     if (!c->workStream) HIP_TRY(hipStreamCreateWithFlags(&c->workStream, hipStreamNonBlocking));
     RegionDesc *desc = (RegionDesc *)c->hDesc.p;
@@ -1611,7 +1610,7 @@ extern "C"
     unsigned long long *dCallState = (unsigned long long *)c->bCalls.p, *dCallOff = dCallState + maxCalls;
     uint32_t *dCallPx = (uint32_t *)(dCallOff + maxCalls);
     std::vector<uint32_t> npx(blocks);
-    bp.scratchPx = (uint32_t *)c->bPx.p; bp.scratchV = (float *)c->bV.p; bp.scratchFac = (uint8_t *)c->bFac.p; bp.scratchCap = (uint32_t)capMax;
+    bp.scratchPx = (uint32_t *)c->bPx.p; bp.scratchFac = (uint8_t *)c->bFac.p; bp.scratchCap = (uint32_t)capMax;
     bp.noise = (const uint8_t *)c->bNoise.p;
 
     struct Pipe { std::mutex m; std::condition_variable cv; size_t ready = 0; bool finished = false; } pipe;

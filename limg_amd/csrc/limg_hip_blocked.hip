@@ -9,8 +9,8 @@
 //   k_blocked_store        one wave per region: dither (noise bytes of the host's chain walk), planes (src/limg.cpp:1604-1700), decode (a16).
 //
 // Lane = pixel of a 64-pixel chunk; a region of N pixels is a loop over ceil(N / 64) chunks.  The three direction sums are serial in pixel
-// order upstream; here the per-pixel unit vectors of a pass are parked in global scratch (slot-planar, so the walkers read float4s) and
-// 4 lanes -- one per channel -- walk the N-term chains.  All arithmetic helpers are the ones of the 8x8 kernels (limg_hip_device.h).
+// order upstream; here a chunk's per-pixel unit vectors are parked in LDS (slot-planar, so the walkers read float4s) and 4 lanes -- one per
+// channel -- add them to running sums carried from chunk to chunk.  All arithmetic helpers are the ones of the 8x8 kernels (limg_hip_device.h).
 // Pass-1 (every 8x8 block's own fit, src/limg.cpp:1088-1119) is the 8x8 path's E step in `fitOnly` mode (limg_hip_kernels.hip).
 #include "limg_hip_device.h"
 
@@ -433,13 +433,13 @@ namespace limg_hip
     template <int CH>
     __global__ __launch_bounds__(64) void k_blocked_fit_search(const BlockedParams p)
     {
+      __shared__ __attribute__((aligned(16))) float s_park[4][64 + 4]; // one chunk's unit vectors, slot-planar; plane stride 68 floats: the four walkers' 16-byte reads hit different banks
       const uint32_t r = blockIdx.x;
       const int lane = lane_id();
       const RegionDesc R = p.regions[r];
       const Geo g = region_geo(p, R);
       const uint32_t n = g.n, cap = p.scratchCap;
       uint32_t *spx = p.scratchPx + R.scratch;
-      float *sv = p.scratchV + R.scratch;
       uint8_t *sf = p.scratchFac + R.scratch;
       const unsigned short *tab = d_rsqrt_x86_tab;
 
@@ -472,42 +472,40 @@ namespace limg_hip
         float mm[6] = { 0, 0, 0, 0, 0, 0 };
         bool zeroA = true, zeroB = true, zeroC = true;
 
-        auto park = [&](uint32_t i, const V4 &u) { sv[i] = u.a.x; sv[(size_t)cap + i] = u.a.y; sv[2 * (size_t)cap + i] = u.b.x; sv[3 * (size_t)cap + i] = u.b.y; };
-        // pixel-order sum of the parked vectors: lane s (< 4) walks slot plane s; slot order x0 x2 x1 x3 (see V4)
-        auto serial_sum = [&]() -> V4 {
-          scratch_fence();
-          float s = 0.0f;
+        // Pixel-order sums of the parked unit vectors (the three direction sums are serial in pixel order upstream).  Round 5: a chunk's 64 vectors are parked in LDS
+        // (slot-planar: 4 planes of 64 floats) and lane s (< 4) adds plane s to its running sum right there, before the next chunk overwrites them -- the sum is carried
+        // from chunk to chunk in the walker lanes' registers, so the order of the additions is the reference's whatever the rectangle's size, and nothing is parked in
+        // global memory.  (Rounds 1-4 parked ALL N vectors of a pass in global scratch and walked them afterwards: 96 of the kernel's 117 bytes of HBM traffic per
+        // pixel, and every walk a chain of global-memory round trips -- ~160 cycles per four terms, later ~40 with sixteen terms requested ahead; a batch's kernel
+        // ends with its largest rectangle, whose three walks were most of its life.  Counters: profiles/r05_final_blocked_summary.txt.)
+        float walk = 0.0f; // lanes 0..3: the running sum of their slot plane
+        auto park_and_walk = [&](const V4 &u, uint32_t count /* pixels of this chunk, 1..64: wave-uniform */) {
+          s_park[0][lane] = u.a.x; s_park[1][lane] = u.a.y; s_park[2][lane] = u.b.x; s_park[3][lane] = u.b.y;
+          wave_lds_fence();
           if (lane < 4)
           {
-            const float *src = sv + (size_t)lane * cap;
-            uint32_t i = 0;
-            // sixteen terms per iteration, the next sixteen already requested: the adds are one dependent chain (that IS the reference's order), and with the loads
-            // issued where they are used an iteration cost ~160 cycles per four terms -- five times what the chain itself needs.  A batch's kernel ends with its
-            // largest rectangle (10 816 terms per walk for 13 x 13 blocks), and the worker thread waits for exactly that (profiles/r04_blocked_pipeline.md).
-            if (n >= 32)
+            const float *src = s_park[lane];
+            if (count == 64u)
             {
-              float4 a0 = *reinterpret_cast<const float4 *>(src), a1 = *reinterpret_cast<const float4 *>(src + 4), a2 = *reinterpret_cast<const float4 *>(src + 8),
-                     a3 = *reinterpret_cast<const float4 *>(src + 12); // R.scratch and cap are multiples of 4
-              for (; i + 32 <= n; i += 16)
+#pragma unroll
+              for (int h = 0; h < 4; h++) // sixteen terms at a time: their four LDS reads are issued together, the adds are one dependent chain
               {
-                const float4 b0 = *reinterpret_cast<const float4 *>(src + i + 16), b1 = *reinterpret_cast<const float4 *>(src + i + 20),
-                             b2 = *reinterpret_cast<const float4 *>(src + i + 24), b3 = *reinterpret_cast<const float4 *>(src + i + 28);
-                s = s + a0.x; s = s + a0.y; s = s + a0.z; s = s + a0.w; s = s + a1.x; s = s + a1.y; s = s + a1.z; s = s + a1.w;
-                s = s + a2.x; s = s + a2.y; s = s + a2.z; s = s + a2.w; s = s + a3.x; s = s + a3.y; s = s + a3.z; s = s + a3.w;
-                a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+                float4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[q] = *reinterpret_cast<const float4 *>(src + 16 * h + 4 * q);
+#pragma unroll
+                for (int q = 0; q < 4; q++) { walk = walk + v[q].x; walk = walk + v[q].y; walk = walk + v[q].z; walk = walk + v[q].w; }
               }
-              s = s + a0.x; s = s + a0.y; s = s + a0.z; s = s + a0.w; s = s + a1.x; s = s + a1.y; s = s + a1.z; s = s + a1.w;
-              s = s + a2.x; s = s + a2.y; s = s + a2.z; s = s + a2.w; s = s + a3.x; s = s + a3.y; s = s + a3.z; s = s + a3.w;
-              i += 16;
             }
-            for (; i + 4 <= n; i += 4)
-            {
-              const float4 v = *reinterpret_cast<const float4 *>(src + i);
-              s = s + v.x; s = s + v.y; s = s + v.z; s = s + v.w;
-            }
-            for (; i < n; i++) s = s + src[i];
+            else
+              for (uint32_t i = 0; i < count; i++) walk = walk + src[i];
           }
-          s = s * inv_count;
+          wave_lds_fence(); // (the next chunk's vectors overwrite the planes)
+        };
+        // the pass's sum / N in slot order x0 x2 x1 x3 (see V4), broadcast to every lane; the walkers start the next pass from zero
+        auto serial_sum = [&]() -> V4 {
+          const float s = walk * inv_count;
+          walk = 0.0f;
           V4 d;
           d.a = float2_t{ bcast(s, 0), bcast(s, 1) };
           d.b = float2_t{ bcast(s, 2), bcast(s, 3) };
@@ -524,7 +522,7 @@ namespace limg_hip
           V4 d = pf - avg;
           mask_alpha<CH>(d);
           const V4 u = unit4<CH>(tab, d, active);
-          if (active) park(i, u);
+          park_and_walk(u, min(64u, n - base));
         }
         dirA = serial_sum();
         zeroA = is_zero(dirA);
@@ -543,7 +541,7 @@ namespace limg_hip
             V4 e = pf - (avg + dirA * fA);
             mask_alpha<CH>(e);
             const V4 u = unit4<CH>(tab, e, active);
-            if (active) park(i, u);
+            park_and_walk(u, min(64u, n - base));
           }
           wave_min_max(mn, mx);
           mm[0] = mn; mm[1] = mx;
@@ -568,7 +566,7 @@ namespace limg_hip
                 if (active) { mnB = vmin(mnB, fB); mxB = vmax(mxB, fB); }
                 const V4 est2 = est + dirB * fB;
                 const V4 u = unit4<CH>(tab, pf - est2, active);
-                if (active) park(i, u);
+                park_and_walk(u, min(64u, n - base));
                 if (base == 0) est0 = est2;
               }
               wave_min_max(mnB, mxB);
@@ -802,14 +800,15 @@ namespace limg_hip
           }
           v[k] = f;
         }
-        p.info.pFactorsA[o] = (uint8_t)(v[0] << shift[0]); // shift 8 => 0, like the uint8 store upstream
-        p.info.pFactorsB[o] = (uint8_t)(v[1] << shift[1]);
-        p.info.pFactorsC[o] = (uint8_t)(v[2] << shift[2]);
-        p.info.pBitsPerPixel[o] = bpp;
-        p.info.pShiftABCX[o] = shiftVal;
-        p.info.pColAMin[o] = col[0]; p.info.pColAMax[o] = col[1]; p.info.pColBMin[o] = col[2];
-        p.info.pColBMax[o] = col[3]; p.info.pColCMin[o] = col[4]; p.info.pColCMax[o] = col[5];
-        p.info.pBlockIndex[o] = blockIndex;
+        // (the 13 planes are written once and never read here: non-temporal stores, like the 8x8 path's planes -- limg_hip_kernels.hip plane_store16)
+        __builtin_nontemporal_store((uint8_t)(v[0] << shift[0]), p.info.pFactorsA + o); // shift 8 => 0, like the uint8 store upstream
+        __builtin_nontemporal_store((uint8_t)(v[1] << shift[1]), p.info.pFactorsB + o);
+        __builtin_nontemporal_store((uint8_t)(v[2] << shift[2]), p.info.pFactorsC + o);
+        __builtin_nontemporal_store(bpp, p.info.pBitsPerPixel + o);
+        __builtin_nontemporal_store(shiftVal, p.info.pShiftABCX + o);
+        __builtin_nontemporal_store(col[0], p.info.pColAMin + o); __builtin_nontemporal_store(col[1], p.info.pColAMax + o); __builtin_nontemporal_store(col[2], p.info.pColBMin + o);
+        __builtin_nontemporal_store(col[3], p.info.pColBMax + o); __builtin_nontemporal_store(col[4], p.info.pColCMin + o); __builtin_nontemporal_store(col[5], p.info.pColCMax + o);
+        __builtin_nontemporal_store(blockIndex, p.info.pBlockIndex + o);
         // a16
         const int dA = (int)v[0] * mulA, dB = (int)v[1] * mulB, dC = (int)v[2] * mulC;
         uint32_t decoded = 0;
@@ -820,7 +819,7 @@ namespace limg_hip
           est = est < 0 ? 0 : (est > 255 ? 255 : est);
           decoded |= (uint32_t)est << (8 * c);
         }
-        p.info.pDecoded[o] = decoded;
+        __builtin_nontemporal_store(decoded, p.info.pDecoded + o);
       }
     }
   }

@@ -154,7 +154,6 @@ namespace limg_hip
     uint32_t regionBase;       // index of regions[0] in creation order (block index = regionBase + r + 1)
     RegionOut *out;
     uint32_t *scratchPx; // gathered pixels, region-major (src/limg.cpp:1747-1748)
-    float *scratchV;     // 4 slot planes of scratchCap floats: the parked unit vectors of the current direction pass
     uint8_t *scratchFac; // 3 planes of scratchCap bytes: pre-dither factor bytes
     uint32_t scratchCap;
     const uint8_t *noise;              // one byte per pixel per dither call, region after region in chain order
