@@ -14,9 +14,11 @@
 // pixel (row r, column x) of the 8x8 grid at bit (r*8 + x) * b -- i.e. every block row is exactly b bytes.  Pixels outside the
 // image (partial edge blocks) are stored as 0.
 //
-// Work mapping: tile = 256 consecutive blocks (raster order) per 256-thread workgroup.  Thread t prepares block t's entry; then
+// Work mapping.  Pack: tile = 256 consecutive blocks (raster order) per 256-thread workgroup; thread t prepares block t's entry; then
 // each wave walks its 64 blocks in groups of 8 with lane = (block j = lane & 7, block row r = lane >> 3), so a lane owns the
 // 8 pixels of one block row: 8 B of each factor plane, 32 B of the decoded image, b bytes of each payload field.
+// Decode: the same lane mapping, but persistent -- a wave strides over units of 64 blocks on its own, nothing synchronises
+// across waves (k_stream_decode).
 #include "limg_hip_internal.h"
 
 namespace limg_hip
@@ -396,7 +398,7 @@ namespace limg_hip
         // two are outstanding" right behind a group's two stores means "my three loads, issued before them, are back" -- while the compiler's own bookkeeping for a load
         // that is consumed across the loop's back edge ends in vmcnt(0), which also drains those stores: every wave then sat out the HBM write latency once per group
         // (SQ_WAIT_ANY: 0.51 of the waves' cycles).  The compiler believes the three registers are defined where the asm statement stands; nothing may read them before
-        // payload_wait<N>() -- the only reader is stage_run() below, and the ISA is checked for stray copies (tools/r05/check_decode_isa.sh).
+        // the hand-written s_waitcnt -- the only reader is stage_run() below, and tests/test_decode_isa.py proves on the compiled assembly that nothing else is.
         auto fetch = [&](const Group &G, unsigned long long buf[3]) {
 #pragma unroll
           for (int i = 0; i < 3; i++)
