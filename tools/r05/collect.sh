@@ -8,7 +8,8 @@ done
 [ -s gpurun_out/profiles/pmc_by_workload.json ] && cp gpurun_out/profiles/pmc_by_workload.json profiles/pmc_by_workload.json
 for f in gpurun_out/r05_final/bench_*.json; do
   n=$(basename $f .json); n=${n#bench_}
-  if [ "$n" = default ]; then cp $f profiles/r05_bench_final.json; else cp $f profiles/r05_bench_final_$n.json; fi
+  # (only the JSON line: the gloo rehearsals' stdout also carries gloo's own "[Gloo] Rank ... is connected" message)
+  if [ "$n" = default ]; then grep '^{' $f > profiles/r05_bench_final.json; else grep '^{' $f > profiles/r05_bench_final_$n.json; fi
 done
 cp gpurun_out/r05_final/rc.txt profiles/r05_bench_final_rc.txt
 python tools/profiles_index.py
