@@ -192,3 +192,45 @@ def test_lookback_timeout_is_loud(ctxs):
     g.check()
     for k in want:
         assert torch.equal(got[k], want[k]), k
+
+
+def test_width_ragged_encodes_on_three_threads(oracle):
+    """The width-ragged path blocks its calling thread (the host walks the dither chain while the GPU works around it in bands): a service runs it from several threads, each
+    with its own context and stream.  Three threads x 4 encodes of a 2046 x 1024 image (banded pipeline: 256 x 128 blocks) and, on one of them, the pool-of-2 variant
+    (parallel chain walks): every result equals the oracle's."""
+    import threading
+    import numpy as np
+    import torch
+    import limg_amd
+    from oracle.bind import PLANES
+    W, H = 2046, 1024
+    img = oracle.photo_noise(W, H, 61)
+    want = {0: oracle.encode3d(img, True, worker_threads=8), 2: oracle.encode3d(img, True, pool_threads=2, worker_threads=8)}
+    d_img = torch.from_numpy(img.view(np.int32)).cuda()
+    errs = []
+
+    def work(k):
+        try:
+            torch.cuda.set_device(0)
+            g = limg_amd.LimgHip(0)
+            st = torch.cuda.Stream()
+            planes = g.alloc_planes_device(W, H)
+            with torch.cuda.stream(st):
+                for it in range(4):
+                    pool = 2 if (k == 1 and it % 2 == 1) else 0
+                    g.encode3d_device(d_img, True, planes, pool_threads=pool)
+                    st.synchronize()
+                    bad = [p for p in PLANES if not np.array_equal(planes[p].cpu().numpy().view(np.uint32 if planes[p].dtype == torch.int32 else np.uint8), want[pool][p])]
+                    if bad:
+                        errs.append((k, it, pool, bad))
+            g.check()
+            g.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((k, repr(e)))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
