@@ -485,15 +485,11 @@ namespace limg_hip
           const Group G = cur; // its run is in the stage
           cur = group_info(grp + 1);
           fetch(cur, buf); // the next group's run: three loads, then (below) this group's two stores, then the counted wait
-          if (!G.ok)
-          { // inconsistent offsets: the stream is refused (status word) and this group is not decoded; no stores follow the loads here, so the wait is a full one
-            if (lane == 0) atomicOr(p.status, 2u);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          }
-          else
-          {
-          const uint32_t t = G.t, bw = G.bw, myOff = G.myOff, off0 = G.off0;
-          const bool valid = G.valid;
+          // inconsistent offsets: the stream is refused (status word) and the group decodes as if it had no blocks -- every lane then unpacks nothing and stores to the
+          // sink.  No branch around the decode: the two stores below must lie on EVERY path between the payload loads above and the counted wait behind them.
+          if (!G.ok && lane == 0) atomicOr(p.status, 2u);
+          const uint32_t t = G.t, bw = G.ok ? G.bw : 0u, off0 = G.off0, myOff = G.ok ? G.myOff : off0;
+          const bool valid = G.valid && G.ok;
           const uint32_t fl = valid ? S.flags[t] : 0u;
           const bool generic = __builtin_amdgcn_ballot_w64((fl & 1u) != 0u) != 0ull, anyAlpha = __builtin_amdgcn_ballot_w64((fl & 2u) != 0u) != 0ull; // wave-uniform
           wave_lds_fence();
@@ -565,7 +561,6 @@ namespace limg_hip
                 if (x0 + i < p.sizeX) row[i] = px[i];
             }
           }
-          } // (G.ok)
           wave_lds_fence(); // every lane is done reading this group's run
           asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); // all but the two stores above (more on the edge path: then this waits for a few stores too): the run of `cur` is in
           stage_run(cur, buf);

@@ -90,3 +90,30 @@ def test_inflight_payload_registers_are_not_touched(tmp_path):
                 state[n] = new
                 work.append(n)
     assert loads >= 6 and waits >= 2, (loads, waits)  # three loads at a unit's top, three in the group loop; the full wait and the counted one
+
+    # The count itself: on EVERY path from a hand-issued load to a hand-written `s_waitcnt vmcnt(N)`, at least N vector-memory operations must have been issued after the
+    # last such load (vmcnt retires in order: then "at most N outstanding" implies the loads are back).  Minimum over paths of the operations since the last load.
+    INF = 1 << 30
+    cnt = {b: None for b in order}
+    cnt["entry"] = INF
+    work = ["entry"]
+    checked = 0
+    while work:
+        b = work.pop()
+        c = cnt[b]
+        for t, asm in blocks[b]:
+            if asm and t.startswith("global_load_dwordx2"):
+                c = 0
+            elif asm and t.startswith("s_waitcnt vmcnt("):
+                n = int(re.match(r"s_waitcnt vmcnt\((\d+)\)", t).group(1))
+                assert c >= n, "a path reaches `%s` with only %d vector-memory operations behind the payload loads (block %s)" % (t, c, b)
+                checked += 1
+                c = INF
+            elif re.match(r"(global|buffer|flat|scratch)_(load|store|atomic)", t) and c != INF:
+                c += 1
+        for nb in succ[b]:
+            new = c if cnt[nb] is None else min(cnt[nb], c)
+            if new != cnt[nb]:
+                cnt[nb] = new
+                work.append(nb)
+    assert checked >= 2
