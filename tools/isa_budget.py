@@ -146,7 +146,7 @@ def main():
     # sub-ranges of fit_search_strip by markers in the source
     e0, e1 = fk["fit_search_strip"]
     m_stage = marker(K, "// ---- stage: the strip's pixel rows into LDS")
-    m_prefit = marker(K, "// records of the wave's 8 blocks as k_fit_tpb left them")
+    m_prefit = marker(K, "the records of the wave's 8 blocks as k_fit_tpb left them")
     m_float = marker(K, "// The float stage runs in batches of kBatch blocks per wave")
     m_view = marker(K, "// phase-E view (overlays the dead float-stage fields)")
     m_phaseE = marker(K, "// ---- phase E: per-pixel factors (a8) + shift search (a10-a12)")
