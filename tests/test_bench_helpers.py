@@ -91,3 +91,15 @@ def test_profiles_index_is_current():
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "profiles_index.py"), "--check"])
     assert r.returncode == 0, "profiles/README.md's round-5 index is out of date: run python tools/profiles_index.py"
+
+
+def test_isa_budget_tool_runs():
+    """tools/isa_budget.py attributes the compiler's assembly to phases through markers in the kernel source; a reworded comment broke it silently in round 4.
+    It must run on the committed sources and find both kernels (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    if not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        import pytest
+        pytest.skip("needs hipcc")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_budget.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-500:]
+    assert "k_encode_persistent<4, false, true, false>" in r.stdout and "k_fit_tpb<4, false, true>" in r.stdout and "**sum**" in r.stdout
