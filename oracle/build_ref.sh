@@ -57,3 +57,18 @@ FLAGS="-std=c++17 -O3 -msse4.1 -maes -fno-exceptions -fno-rtti -DNDEBUG -w -fPIC
 $CXX $FLAGS -shared -o "$OUT/liblimg_ref.so" "$HERE/ref_harness.cpp" "$TMP/limg_simd.cpp" "$TMP/limg_threading.cpp" -lpthread
 $CXX $FLAGS -ffast-math -shared -o "$OUT/liblimg_ref_fastmath.so" "$HERE/ref_harness.cpp" "$TMP/limg_simd.cpp" "$TMP/limg_threading.cpp" -lpthread
 echo "built $OUT/liblimg_ref.so $OUT/liblimg_ref_fastmath.so"
+
+# The reference's own CALLER on the HIP library: src/main.cpp, unmodified, compiled next to a one-line `limg.h` that forwards to include/limg_hip_shim.hpp and
+# linked against limg_amd/liblimg_hip.so (what tests/test_shim_ref_main.py does in a temp dir -- here the binary is kept, in oracle/_ref like the reference's
+# libraries above, so that it travels to the GPU box, which has no /root/reference: tests/test_gpu_ref_main.py runs it there).  main.cpp is copied into the
+# throw-away directory only because its `#include "limg.h"` would otherwise find the reference's own header beside it.
+LIB="$HERE/../limg_amd/liblimg_hip.so"
+if [ -f "$LIB" ] && [ -f "$REF/src/main.cpp" ]; then
+  mkdir -p "$TMP/main"
+  cp "$REF/src/main.cpp" "$TMP/main/main.cpp"
+  echo '#include "limg_hip_shim.hpp"' > "$TMP/main/limg.h"
+  ROCM_LIB=${ROCM_LIB:-/opt/rocm/lib}
+  $CXX -std=c++17 -O1 -w -I"$TMP/main" -I"$HERE/../include" -I"$REF/3rdParty/stb/include" "$TMP/main/main.cpp" -o "$OUT/limg_ref_main_on_hip" \
+      -L"$HERE/../limg_amd" -llimg_hip -lpthread '-Wl,-rpath,$ORIGIN/../../limg_amd' -Wl,-rpath-link,"$ROCM_LIB" -Wl,-rpath,"$ROCM_LIB"
+  echo "built $OUT/limg_ref_main_on_hip (the reference's src/main.cpp on the shim)"
+fi

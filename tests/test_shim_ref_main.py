@@ -59,7 +59,8 @@ def test_reference_main_runs_and_fails_loudly_without_gpu(ref_main, tmp_path):
 
 @pytest.mark.gpu
 def test_reference_main_on_gpu(ref_main, tmp_path):
-    """Where both the reference and a GPU exist: upstream's tool on the HIP library prints upstream's PSNR for config #1 (40.23 dB)."""
+    """Where both the reference and a GPU exist: upstream's tool on the HIP library prints upstream's PSNR for config #1 (40.23 dB).  (No box has both:
+    tests/test_gpu_ref_main.py runs the same caller, prebuilt by oracle/build_ref.sh, on the GPU box.)"""
     r = subprocess.run([ref_main, PNG, "--no-output"], capture_output=True, text=True, cwd=tmp_path)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "PSNR: 40.23 dB" in r.stdout
