@@ -103,3 +103,20 @@ def test_isa_budget_tool_runs():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_budget.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-500:]
     assert "k_encode_persistent<4, false, true, false>" in r.stdout and "k_fit_tpb<4, false, true>" in r.stdout and "**sum**" in r.stdout
+
+
+def test_sum64_checksum_matches_the_golden_generator():
+    """bench.py --verify-golden compares a position-sensitive 64-bit checksum computed with torch on the device against the one tools/make_golden_fullsize.py computed
+    with numpy from the real reference's planes: the two implementations must agree (uint32 words with the top bit set, bytes, lengths that cross the piece size)."""
+    import importlib.util
+    import numpy as np
+    import torch
+    spec = importlib.util.spec_from_file_location("mgf", os.path.join(ROOT, "tools", "make_golden_fullsize.py"))
+    src = open(spec.origin).read()
+    ns = {}
+    exec(src[src.index("def sum64(a):"):src.index("def make_input(")], ns)  # (the module's import of oracle._ref is not wanted here)
+    rng = np.random.default_rng(5)
+    for n, dt in ((1, np.uint32), (1000, np.uint32), ((1 << 24) + 77, np.uint32), (4097, np.uint8), ((1 << 24) + 5, np.uint8)):
+        a = rng.integers(0, 256 if dt == np.uint8 else (1 << 32), n, dtype=np.uint64).astype(dt)
+        t = torch.from_numpy(a.view(np.int32) if dt == np.uint32 else a)
+        assert bench.sum64_device(t) == ns["sum64"](a), (n, dt)
