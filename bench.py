@@ -1075,7 +1075,7 @@ def main():
         dist.destroy_process_group()
 
 
-def collective_evidence(g, dist, rank, world):
+def collective_evidence(g, dist, rank, world, timeout_s=120.0):
     """--gpus N > 1: what RCCL itself says about the job, so that a SCALE record shows the N ranks RCCL saw: torch.distributed's backend and world size, and -- through
     the library's own communicator (limg_hip_comm_init over the id rank 0 made; ncclCommCount / ncclGetVersion behind limg_hip_comm_info) -- every rank's view, all-gathered:
     the line is refused unless all ranks report the same `comm_ranks` == N.  Outside the timed region."""
@@ -1090,9 +1090,13 @@ def collective_evidence(g, dist, rank, world):
     # must neither hang nor fail the measurement it decorates -- a failure here is a `warning` on the line, the timed numbers stand.
     import threading
     res = {}
+    have_gpu = torch.cuda.is_available()  # (false only under tests/test_bench_helpers.py, which drives this function with stand-ins)
+    cur_dev = torch.cuda.current_device() if have_gpu else None  # the current device is per thread: the helper must select this rank's GPU itself, or its tensors land on device 0
 
     def work():
         try:
+            if have_gpu:
+                torch.cuda.set_device(cur_dev)
             g.comm_init_from_torch(dist)
             res["info"] = g.comm_info()
             g.comm_destroy()
@@ -1101,15 +1105,15 @@ def collective_evidence(g, dist, rank, world):
 
     th = threading.Thread(target=work, daemon=True)
     th.start()
-    th.join(timeout=120.0)
+    th.join(timeout=timeout_s)
     if th.is_alive():
-        res["error"] = "the library's communicator did not come up within 120 s"
+        res["error"] = "the library's communicator did not come up within %.0f s" % timeout_s
         HUNG_THREAD.append(th)
     info = res.get("info") or {"ranks": -1, "rank": rank, "rccl_version": -1}
     if "error" in res:
         ev["error"] = res["error"]
         leg_warned("collective_evidence", res["error"])
-    t = torch.tensor([info["ranks"], info["rank"], info["rccl_version"]], dtype=torch.int64, device="cuda")
+    t = torch.tensor([info["ranks"], info["rank"], info["rccl_version"]], dtype=torch.int64, device="cuda" if have_gpu else "cpu")
     allv = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(allv, t)
     views = [[int(v) for v in a.tolist()] for a in allv]

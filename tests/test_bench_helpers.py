@@ -120,3 +120,56 @@ def test_sum64_checksum_matches_the_golden_generator():
         a = rng.integers(0, 256 if dt == np.uint8 else (1 << 32), n, dtype=np.uint64).astype(dt)
         t = torch.from_numpy(a.view(np.int32) if dt == np.uint32 else a)
         assert bench.sum64_device(t) == ns["sum64"](a), (n, dt)
+
+
+class _FakeDist:
+    """torch.distributed as one rank of a world of one sees it (backend "nccl"): enough for bench.collective_evidence"""
+
+    def __init__(self, world=1):
+        self.world = world
+
+    def get_backend(self):
+        return "nccl"
+
+    def get_world_size(self):
+        return self.world
+
+    def get_rank(self):
+        return 0
+
+    def all_gather(self, out, t):
+        for o in out:
+            o.copy_(t)
+
+
+class _FakeCtx:
+    def __init__(self, mode):
+        self.mode = mode
+
+    def comm_init_from_torch(self, dist):
+        import time
+        if self.mode == "raise":
+            raise RuntimeError("ncclCommInitRank failed")
+        if self.mode == "hang":
+            time.sleep(30)
+
+    def comm_info(self):
+        return {"ranks": 1, "rank": 0, "rccl_version": 22605}
+
+    def comm_destroy(self):
+        pass
+
+
+def test_collective_evidence_never_sinks_the_measurement(monkeypatch):
+    """The evidence leg of --gpus N (the library's own RCCL communicator, first spanned over several GPUs on the driver's node) runs on a helper thread with a time
+    limit: success fills `comm_ranks`; an exception or a hang becomes a WARNING on the line -- not an error, not a crash, not a wait."""
+    import time
+    monkeypatch.setattr(bench, "WARNINGS", [])
+    monkeypatch.setattr(bench, "HUNG_THREAD", [])
+    ev = bench.collective_evidence(_FakeCtx("ok"), _FakeDist(), 0, 1)
+    assert ev["comm_ranks"] == 1 and ev["rccl_version"] == 22605 and not bench.WARNINGS
+    ev = bench.collective_evidence(_FakeCtx("raise"), _FakeDist(), 0, 1)
+    assert "ncclCommInitRank failed" in ev["error"] and ev["comm_ranks"] is None and len(bench.WARNINGS) == 1 and not bench.ERRORS
+    t0 = time.time()
+    ev = bench.collective_evidence(_FakeCtx("hang"), _FakeDist(), 0, 1, timeout_s=0.5)
+    assert time.time() - t0 < 5 and "did not come up" in ev["error"] and len(bench.HUNG_THREAD) == 1
