@@ -863,7 +863,17 @@ def main():
             # rehearsal on a box with fewer GPUs than ranks (ranks share cards): RCCL refuses duplicate devices, use gloo
             dev = local_rank % max(ndev, 1)
             torch.cuda.set_device(dev)
-            dist.init_process_group("gloo")
+            # gloo announces its connections on STDOUT ("[Gloo] Rank 0 is connected to 1 peer ranks"), where the one JSON line belongs: while it connects, fd 1 is fd 2
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("gloo")
+                dist.barrier()  # (the connections are made lazily: by the first collective)
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
         else:
             if rank == 0:
                 print("bench.py: WORLD_SIZE %d but only %d GPU(s) visible: refusing (pass --share-gpus for a gloo rehearsal)" % (world, ndev), file=sys.stderr, flush=True)

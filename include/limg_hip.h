@@ -195,7 +195,9 @@ int limg_hip_profile_end(limg_hip_context *pCtx, float *pMs, int maxEncodes);
  *  limg_hip_host_partition   : src/limg.cpp:2114-2134 in block rows: chain c < count-1 owns rows [c*rows, (c+1)*rows), the last the rest. */
 limg_hip_result limg_hip_host_noise_table(uint8_t *pOut, size_t calls);
 /*  limg_hip_noise_table_device: the same stream written by the GPU (what a context does for itself on the first encode of a size class): `calls` x 64 bytes into a
- *                              DEVICE buffer (16-byte aligned), asynchronous on `stream`; at most 16 Mi calls (the reach of the embedded checkpoints). */
+ *                              DEVICE buffer (16-byte aligned), asynchronous on `stream`; at most 2^27 calls (the reach of the embedded checkpoints: dense ones -- every
+ *                              1024 calls -- through 16 Mi calls, far ones -- every 65536 -- beyond, which the context makes dense on host threads when an image of
+ *                              more than 5.59 M blocks needs them). */
 limg_hip_result limg_hip_noise_table_device(limg_hip_context *pCtx, uint8_t *pOutDevice, size_t calls, void *stream);
 uint64_t limg_hip_host_chain_call(uint64_t chainValue, size_t pixelCount, uint8_t *pNoise64, int forceSoftwareAes);
 limg_hip_result limg_hip_host_partition(size_t sizeY, int poolThreads, uint32_t *pChainCount, uint32_t *pChainBlockRows);
@@ -203,6 +205,10 @@ limg_hip_result limg_hip_host_partition(size_t sizeY, int poolThreads, uint32_t 
  *                              i * every starts from to pOut[i] (may be NULL); returns the value after the last call.  The library's embedded checkpoint
  *                              table (one value every 1024 calls, from which the GPU fills the noise table in parallel) is generated and checked with it. */
 uint64_t limg_hip_host_chain_checkpoints(size_t calls, size_t every, uint64_t *pOut, int pcg);
+/*  limg_hip_host_dense_checkpoints: the chain values that calls number (first + k) * 1024, k < count, start from -- what the GPU's noise-table fill is given -- from the
+ *                              embedded tables alone: the dense one where it reaches, the far one + 65536 calls on foot per far value (host threads) beyond;
+ *                              limg_hip_error_OutOfBounds beyond 2^27 calls.  Equal to limg_hip_host_chain_checkpoints' serial walk (tests/test_host.py). */
+limg_hip_result limg_hip_host_dense_checkpoints(size_t first, size_t count, uint64_t *pOut);
 
 /* ---- merged-block encoder ----------------------------------------------------------------------------------------------------------
  * Replaces `limg_blocked_encode3d_test` (src/limg.h:46, src/limg.cpp:2329-2453), what the reference's CLI runs on a single file

@@ -22,7 +22,7 @@ ABI_SYMBOLS = (
     "limg_hip_encode3d_stats", "limg_hip_blocked_encode3d_stats",
     "limg_hip_encode3d_device", "limg_hip_encode3d_batch_device", "limg_hip_last_stats", "limg_hip_compare", "limg_hip_compare_device", "limg_hip_synth_random_gradient_device",
     "limg_hip_synth_photo_noise_device", "limg_hip_context_device_bytes", "limg_hip_version", "limg_hip_profile_begin", "limg_hip_profile_end",
-    "limg_hip_host_noise_table", "limg_hip_noise_table_device", "limg_hip_host_chain_call", "limg_hip_host_chain_checkpoints", "limg_hip_host_partition", "limg_hip_check_device_status",
+    "limg_hip_host_noise_table", "limg_hip_noise_table_device", "limg_hip_host_chain_call", "limg_hip_host_chain_checkpoints", "limg_hip_host_dense_checkpoints", "limg_hip_host_partition", "limg_hip_check_device_status",
     "limg_hip_stream_bound", "limg_hip_encode_stream_device", "limg_hip_decode_stream_device", "limg_hip_encode_stream", "limg_hip_decode_stream",
     "limg_hip_stream_info",
     "limg_hip_blocked_encode3d", "limg_hip_blocked_encode3d_device", "limg_hip_blocked_regions", "limg_hip_blocked_timing", "limg_hip_blocked_kernel_timing", "limg_hip_blocked_match_bits", "limg_hip_host_blocked_matches",
@@ -124,6 +124,8 @@ def load_library(path=None):
     L.limg_hip_host_chain_call.argtypes = [C.c_uint64, C.c_size_t, C.c_void_p, C.c_int]
     L.limg_hip_host_chain_checkpoints.restype = C.c_uint64
     L.limg_hip_host_chain_checkpoints.argtypes = [C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]
+    L.limg_hip_host_dense_checkpoints.restype = C.c_int
+    L.limg_hip_host_dense_checkpoints.argtypes = [C.c_size_t, C.c_size_t, C.c_void_p]
     L.limg_hip_host_partition.restype = C.c_int
     L.limg_hip_host_partition.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.limg_hip_context_device_bytes.restype = C.c_size_t

@@ -92,6 +92,8 @@ struct limg_hip_context
   DevBuf noiseDyn;                               // data-dependent chains (images with partial blocks)
   DevBuf noiseStates;                            // ... their per-call chain values + pixel counts as the host uploads them (k_noise_expand -> noiseDyn)
   DevBuf noiseCk;                                // the chain checkpoints (limg_noise_checkpoints.h) on the device: the GPU fills the noise table from them
+  size_t noiseCkCount = 0;                       // ... how many dense values (every 1024th call) are there: the embedded ones, or more (ensure_checkpoints)
+  std::vector<uint64_t> noiseCkHost;             // ... and, once an image has reached beyond the embedded dense values, the host copy they were uploaded from
   DevBuf park;                                   // persistent kernel: 2 x 8 KiB per workgroup
   DevBuf batchTable;                             // batched encode: one ImageIO per image
   hipStream_t fitStream = nullptr;               // batched encode in sub-batches: k_fit_tpb of sub-batch k + 1 runs here, next to the persistent kernel of sub-batch k
@@ -204,18 +206,93 @@ namespace
     return limg_hip_success;
   }
 
-  // The chain checkpoints go to the device once per context, with a blocking copy: whichever stream fills a noise table later finds them there (an asynchronous
-  // copy on the first caller's stream would order nothing for a second stream), and a failed copy leaves no buffer behind that later encodes would trust.
-  limg_hip_result upload_checkpoints(limg_hip_context *c, const uint64_t *ck, size_t ckCount)
+  // How far the GPU-filled noise table reaches: the far checkpoints' last value + one far stretch (2^27 calls).
+  size_t checkpoint_reach()
   {
+    size_t farCount = 0, farEvery = 0;
+    (void)noise_checkpoints_far_host(&farCount, &farEvery);
+    return farCount * farEvery;
+  }
+
+  // Dense chain values (every LIMG_NOISE_CHECKPOINT_EVERY = 1024 calls) number first .. first + count - 1 into pOut: the embedded dense table where it reaches (16 Mi
+  // calls), beyond it the embedded FAR values (every 65536 calls) walked on foot -- 65536 calls of 8 AES rounds per far value = 0.5 ms, far values independent of each
+  // other: on up to 16 host threads.  false beyond the far table's reach.
+  bool dense_checkpoints_host(size_t first, size_t count, uint64_t *pOut)
+  {
+    size_t ckCount = 0, ckEvery = 0, farCount = 0, farEvery = 0;
+    const uint64_t *ck = noise_checkpoints_host(&ckCount, &ckEvery);
+    const uint64_t *far = noise_checkpoints_far_host(&farCount, &farEvery);
+    const size_t perFar = farEvery / ckEvery;
+    if (count == 0) return true;
+    if (first + count > farCount * perFar) return false;
+    size_t k = 0;
+    for (; k < count && first + k < ckCount; k++) pOut[k] = ck[first + k];
+    if (k == count) return true;
+    const size_t j0 = (first + k) / perFar, j1 = (first + count - 1) / perFar + 1; // far stretches touched
+    unsigned threads = std::thread::hardware_concurrency();
+    if (threads == 0 || threads > 16) threads = 16;
+    if (threads > j1 - j0) threads = (unsigned)(j1 - j0);
+    auto work = [&](unsigned t) {
+      std::vector<uint64_t> tmp(perFar);
+      for (size_t j = j0 + t; j < j1; j += threads)
+      {
+        (void)chain_checkpoints(far[j], farEvery, ckEvery, tmp.data(), false);
+        for (size_t q = 0; q < perFar; q++)
+        {
+          const size_t idx = j * perFar + q;
+          if (idx >= first + k && idx < first + count) pOut[idx - first] = tmp[q];
+        }
+      }
+    };
+    if (threads <= 1) work(0);
+    else
+    {
+      std::vector<std::thread> pool;
+      for (unsigned t = 0; t < threads; t++) pool.emplace_back(work, t);
+      for (std::thread &th : pool) th.join();
+    }
+    return true;
+  }
+
+  // Dense chain checkpoints covering dither calls [0, calls) on the device (c->noiseCk): the embedded table once per context, more when an image reaches beyond it
+  // (more than 5.59 M blocks: the missing values come from the far table, dense_checkpoints_host).  Blocking copies: whichever stream fills a noise table later
+  // finds them there (an asynchronous copy on the first caller's stream would order nothing for a second stream), and a failed copy leaves no buffer behind that
+  // later encodes would trust.  (A buffer that grows is freed first: hipFree waits for the fill kernels that may still read it.)
+  limg_hip_result ensure_checkpoints(limg_hip_context *c, size_t calls)
+  {
+    size_t ckCount = 0, ckEvery = 0;
+    const uint64_t *ck = noise_checkpoints_host(&ckCount, &ckEvery);
+    size_t need = (calls + ckEvery - 1) / ckEvery;
+    if (need < ckCount) need = ckCount;
+    if (c->noiseCk.p && need <= c->noiseCkCount) return limg_hip_success;
+    if (calls > checkpoint_reach()) return limg_hip_error_InvalidParameter;
+    const uint64_t *src = ck;
+    if (need > ckCount)
+    {
+      try
+      {
+        std::vector<uint64_t> &v = c->noiseCkHost;
+        if (v.empty()) v.assign(ck, ck + ckCount);
+        const size_t have = v.size();
+        if (need > have)
+        {
+          v.resize(need);
+          if (!dense_checkpoints_host(have, need - have, v.data() + have)) { v.resize(have); return limg_hip_error_InvalidParameter; }
+        }
+        src = v.data();
+      }
+      catch (...) { c->noiseCkHost.clear(); return limg_hip_error_MemoryAllocationFailure; }
+    }
     limg_hip_result r;
-    if ((r = c->noiseCk.ensure(ckCount * 8)) != limg_hip_success) return r;
-    if (hipMemcpy(c->noiseCk.p, ck, ckCount * 8, hipMemcpyHostToDevice) != hipSuccess)
+    c->noiseCkCount = 0;
+    if ((r = c->noiseCk.ensure(need * 8)) != limg_hip_success) return r;
+    if (hipMemcpy(c->noiseCk.p, src, need * 8, hipMemcpyHostToDevice) != hipSuccess)
     {
       c->noiseCk.release();
       fprintf(stderr, "limg_hip: upload of the dither chain checkpoints failed\n");
       return limg_hip_error_Generic;
     }
+    c->noiseCkCount = need;
     return limg_hip_success;
   }
 
@@ -225,16 +302,13 @@ namespace
     if (pcg != c->noisePcg) c->noiseCount = 0;
     if (entries <= c->noiseCount) return limg_hip_success;
     const size_t want = ((entries + kNoiseChunk - 1) / kNoiseChunk) * kNoiseChunk;
-    size_t ckCount = 0, ckEvery = 0;
-    const uint64_t *ck = noise_checkpoints_host(&ckCount, &ckEvery);
-    if (!pcg && want <= ckCount * ckEvery && c->opt.host_noise_table == 0)
+    if (!pcg && want <= checkpoint_reach() && c->opt.host_noise_table == 0)
     { // the AES stream, on the GPU from the embedded chain checkpoints (limg_hip_noise_gpu.hip): stream-ordered, ~1 ms, nothing crosses PCIe but the 128 KiB of
-      // checkpoints, once per context.  A larger table than the one at hand is filled from scratch (its prefix is the same stream).
+      // checkpoints, once per context (images of more than 5.59 M blocks: 8 bytes more per 1024 calls beyond the embedded dense table's 16 Mi, made from the far
+      // table on host threads -- ~20 ms for the 50 M calls of a 32768^2 image, where walking the whole chain on one host thread and uploading 3.2 GB took 1.5 s).
+      // A larger table than the one at hand is filled from scratch (its prefix is the same stream).
       limg_hip_result r;
-      if (!c->noiseCk.p)
-      {
-        if ((r = upload_checkpoints(c, ck, ckCount)) != limg_hip_success) return r;
-      }
+      if ((r = ensure_checkpoints(c, want)) != limg_hip_success) return r;
       HIP_TRY(hipStreamSynchronize(stream)); // earlier encodes on this stream may still read the table that is about to be replaced
       if ((r = c->noise.ensure(want * 64)) != limg_hip_success) return r;
       launch_noise_fill((uint8_t *)c->noise.p, (const uint64_t *)c->noiseCk.p, want, stream);
@@ -243,7 +317,7 @@ namespace
       c->noisePcg = false;
       return limg_hip_success;
     }
-    // PCG dither (a test / fallback mode), tables beyond the checkpoints' reach (images of more than 5.59 M blocks) or limg_hip_options.host_noise_table:
+    // PCG dither (a test / fallback mode), tables beyond the far checkpoints' reach (2^27 calls: images of more than 44.7 M blocks) or limg_hip_options.host_noise_table:
     // (re)generate on the host; one-time cost per context and image size class
     std::vector<uint8_t> host(want * 64);
     uint64_t h = kDitherSeed;
@@ -332,11 +406,14 @@ namespace
   // The chain value the dither call number `calls` of a chain of full 8x8 blocks starts from: the nearest embedded checkpoint, then at most 1023 calls on foot.
   bool chain_value_at(uint64_t calls, uint64_t *pValue)
   {
-    size_t ckCount = 0, ckEvery = 0;
+    size_t ckCount = 0, ckEvery = 0, farCount = 0, farEvery = 0;
     const uint64_t *ck = noise_checkpoints_host(&ckCount, &ckEvery);
-    if (calls / ckEvery >= ckCount) return false;
-    uint64_t h = ck[calls / ckEvery];
-    for (uint64_t i = 0; i < calls % ckEvery; i++) h = chain_call(h, 64, nullptr, false, false);
+    const uint64_t *far = noise_checkpoints_far_host(&farCount, &farEvery);
+    uint64_t h, onFoot;
+    if (calls / ckEvery < ckCount) { h = ck[calls / ckEvery]; onFoot = calls % ckEvery; }
+    else if (calls / farEvery < farCount) { h = far[calls / farEvery]; onFoot = calls % farEvery; } // beyond the dense table: at most 65535 calls on foot (0.5 ms)
+    else return false;
+    for (uint64_t i = 0; i < onFoot; i++) h = chain_call(h, 64, nullptr, false, false);
     *pValue = h;
     return true;
   }
@@ -381,9 +458,7 @@ namespace
     if (ragged && sizeX % kBlock == 0 && sizeY > (size_t)kBlock && dInfo && chainPhase == 0 && batchCount == 1 && !x.inner && !x.fitOnly && !c->forceSplit &&
         c->opt.legacy_float_stage == 0 && c->opt.dither_pcg == 0 && c->opt.test_whole_image_ragged == 0)
     {
-      size_t ckCount = 0, ckEvery = 0;
-      (void)noise_checkpoints_host(&ckCount, &ckEvery);
-      if (((sizeX / kBlock) * ((sizeY + kBlock - 1) / kBlock)) * 3 <= ckCount * ckEvery)
+      if (((sizeX / kBlock) * ((sizeY + kBlock - 1) / kBlock)) * 3 <= checkpoint_reach())
         return encode_height_ragged(c, dIn, sizeX, sizeY, hasAlpha, dInfo, compact, errorFactor, poolThreads, fast, stream, x);
     }
     auto mark_if = [&](int level) { if (x.marks >= level) mark(c, stream); };
@@ -1026,15 +1101,10 @@ extern "C"
   limg_hip_result limg_hip_noise_table_device(limg_hip_context *c, uint8_t *pOutDevice, size_t calls, void *stream)
   {
     if (!c || !pOutDevice) return limg_hip_error_ArgumentNull;
-    size_t ckCount = 0, ckEvery = 0;
-    const uint64_t *ck = noise_checkpoints_host(&ckCount, &ckEvery);
-    if (calls > ckCount * ckEvery || ((uintptr_t)pOutDevice & 15u) != 0) return limg_hip_error_InvalidParameter;
+    if (calls > checkpoint_reach() || ((uintptr_t)pOutDevice & 15u) != 0) return limg_hip_error_InvalidParameter;
     HIP_TRY(hipSetDevice(c->device));
-    if (!c->noiseCk.p)
-    {
-      limg_hip_result r;
-      if ((r = upload_checkpoints(c, ck, ckCount)) != limg_hip_success) return r;
-    }
+    limg_hip_result r;
+    if ((r = ensure_checkpoints(c, calls)) != limg_hip_success) return r;
     launch_noise_fill(pOutDevice, (const uint64_t *)c->noiseCk.p, calls, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return limg_hip_success;
@@ -1056,6 +1126,13 @@ extern "C"
   uint64_t limg_hip_host_chain_checkpoints(size_t calls, size_t every, uint64_t *pOut, int pcg)
   {
     return chain_checkpoints(kDitherSeed, calls, every, pOut, pcg != 0);
+  }
+
+  limg_hip_result limg_hip_host_dense_checkpoints(size_t first, size_t count, uint64_t *pOut)
+  {
+    if (!pOut) return limg_hip_error_ArgumentNull;
+    try { return dense_checkpoints_host(first, count, pOut) ? limg_hip_success : limg_hip_error_OutOfBounds; }
+    catch (...) { return limg_hip_error_MemoryAllocationFailure; }
   }
 
   limg_hip_result limg_hip_host_partition(size_t sizeY, int poolThreads, uint32_t *pChainCount, uint32_t *pChainBlockRows)

@@ -103,6 +103,7 @@ namespace limg_hip
   };
 
   const uint64_t *noise_checkpoints_host(size_t *pCount, size_t *pEvery);
+  const uint64_t *noise_checkpoints_far_host(size_t *pCount, size_t *pEvery);
   void launch_noise_fill(uint8_t *noise, const uint64_t *dCheckpoints, size_t count, hipStream_t s);
   void launch_noise_expand(uint8_t *noise, const unsigned long long *dStates, const uint8_t *dPixels, size_t calls, bool pcg, hipStream_t s);
   void launch_noise_expand_calls(uint8_t *noise, const unsigned long long *dStates, const unsigned long long *dOffsets, const uint32_t *dPixels, size_t calls, bool pcg, hipStream_t s);

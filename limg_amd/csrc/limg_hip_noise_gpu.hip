@@ -204,7 +204,17 @@ namespace limg_hip
     return table;
   }
 
-  // entries [0, count) of the AES noise stream into `noise` (device); dCheckpoints = the table above on the device.  count <= COUNT * EVERY.
+  // the chain value every LIMG_NOISE_FAR_EVERY calls, through 2^27 calls: what reaches beyond the dense table (limg_hip_api.hip ensure_checkpoints turns the far values an
+  // image needs into dense ones: LIMG_NOISE_FAR_EVERY calls on foot per far value, on host threads)
+  const uint64_t *noise_checkpoints_far_host(size_t *pCount, size_t *pEvery)
+  {
+    static const uint64_t table[LIMG_NOISE_FAR_COUNT] = LIMG_NOISE_FAR_INIT;
+    if (pCount) *pCount = LIMG_NOISE_FAR_COUNT;
+    if (pEvery) *pEvery = LIMG_NOISE_FAR_EVERY;
+    return table;
+  }
+
+  // entries [0, count) of the AES noise stream into `noise` (device); dCheckpoints = dense checkpoints (every LIMG_NOISE_CHECKPOINT_EVERY calls) covering them, on the device.
   void launch_noise_fill(uint8_t *noise, const uint64_t *dCheckpoints, size_t count, hipStream_t s)
   {
     const uint32_t segments = (uint32_t)((count + LIMG_NOISE_CHECKPOINT_EVERY - 1) / LIMG_NOISE_CHECKPOINT_EVERY);

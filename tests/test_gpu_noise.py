@@ -37,10 +37,18 @@ def test_gpu_noise_table_equals_host_walk():
         host = _host_table(g, calls)
         assert np.array_equal(dev[-65536 * 64:], host[-65536 * 64:])
         assert np.array_equal(dev[::4099], host[::4099])
-        # refused beyond the reach of the checkpoints
+        del dev, host
+        # beyond the embedded dense checkpoints (16 Mi calls: images of more than 5.59 M blocks): the context makes the missing dense values from the far table
+        calls = 16 * 1024 * 1024 + 3 * 65536 + 12345
+        dev = _device_table(g, calls)
+        host = _host_table(g, calls)
+        assert np.array_equal(dev[-(4 * 65536) * 64:], host[-(4 * 65536) * 64:])
+        assert np.array_equal(dev[::4099], host[::4099])
+        del dev, host
+        # refused beyond the reach of the far checkpoints
         import torch
         buf = torch.zeros(64, dtype=torch.uint8, device="cuda")
-        assert g.lib.limg_hip_noise_table_device(g.ctx, C.c_void_p(buf.data_ptr()), 16 * 1024 * 1024 + 1, None) == 101
+        assert g.lib.limg_hip_noise_table_device(g.ctx, C.c_void_p(buf.data_ptr()), 2 ** 27 + 1, None) == 101
     finally:
         g.check()
         g.close()

@@ -291,7 +291,8 @@ def test_gather_offsets_and_chain_bases():
 
 def test_noise_checkpoints_are_the_chain():
     """limg_amd/csrc/limg_noise_checkpoints.h (what the GPU fills the noise table from) against a fresh serial walk of the dither chain by the host implementation
-    that tests/golden/chain.json pins to the reference: every one of the 16384 values, and the walk's known answers of SURVEY 8(c) on the way."""
+    that tests/golden/chain.json pins to the reference: every one of the 16384 dense values (every 1024th call) and of the 2048 far values (every 65536th call, through
+    2^27 calls), and the walk's known answers of SURVEY 8(c) on the way."""
     import ctypes as C
     import re
     import limg_amd
@@ -299,11 +300,42 @@ def test_noise_checkpoints_are_the_chain():
     text = open(os.path.join(ROOT, "limg_amd", "csrc", "limg_noise_checkpoints.h")).read()
     every = int(re.search(r"LIMG_NOISE_CHECKPOINT_EVERY (\d+)", text).group(1))
     count = int(re.search(r"LIMG_NOISE_CHECKPOINT_COUNT (\d+)", text).group(1))
-    vals = np.array([int(x, 16) for x in re.findall(r"0x([0-9a-f]{16})ull", text)], dtype=np.uint64)
+    far_every = int(re.search(r"LIMG_NOISE_FAR_EVERY (\d+)", text).group(1))
+    far_count = int(re.search(r"LIMG_NOISE_FAR_COUNT (\d+)", text).group(1))
+    dense_text, far_text = text.split("#define LIMG_NOISE_FAR_INIT")
+    vals = np.array([int(x, 16) for x in re.findall(r"0x([0-9a-f]{16})ull", dense_text)], dtype=np.uint64)
+    far = np.array([int(x, 16) for x in re.findall(r"0x([0-9a-f]{16})ull", far_text)], dtype=np.uint64)
     assert every == 1024 and count == 16384 and vals.size == count
+    assert far_every == 65536 and far_count == 2048 and far.size == far_count
+    walked = np.zeros(far_count, dtype=np.uint64)
+    L.limg_hip_host_chain_checkpoints(far_every * far_count, far_every, walked.ctypes.data_as(C.c_void_p), 0)  # 2^27 calls, serial: a few seconds
+    assert np.array_equal(far, walked)
     walked = np.zeros(count, dtype=np.uint64)
     L.limg_hip_host_chain_checkpoints(every * count, every, walked.ctypes.data_as(C.c_void_p), 0)
     assert np.array_equal(vals, walked)
+    assert np.array_equal(far[:every * count // far_every], vals[::far_every // every])
     first = np.zeros(5, dtype=np.uint64)
     L.limg_hip_host_chain_checkpoints(5, 1, first.ctypes.data_as(C.c_void_p), 0)
     assert [hex(int(v)) for v in first] == ["0xca7f00d15badf00d", "0x4ae914d5e23b0473", "0x1db0e1e7cd750f32", "0x13d534ac987485a9", "0xd82d4ba61c55878b"]  # SURVEY 8(c) chain KAT
+
+
+def test_dense_checkpoints_beyond_the_embedded_table():
+    """What a context uploads for an image of more than 5.59 M blocks (limg_hip_api.hip ensure_checkpoints): dense chain values beyond the embedded table's 16 Mi calls,
+    made from the far table on host threads (limg_hip_host_dense_checkpoints) == the serial walk; across the boundary, over whole and partial far stretches; refused
+    beyond the far table's reach."""
+    import ctypes as C
+    import limg_amd
+    L = limg_amd.load_library()
+    first, count = 16384 - 3, 64 * 3 + 10  # three dense values, then three far stretches and a bit
+    got = np.zeros(count, dtype=np.uint64)
+    assert L.limg_hip_host_dense_checkpoints(first, count, got.ctypes.data_as(C.c_void_p)) == 0
+    walked = np.zeros(first + count, dtype=np.uint64)
+    L.limg_hip_host_chain_checkpoints((first + count) * 1024, 1024, walked.ctypes.data_as(C.c_void_p), 0)
+    assert np.array_equal(got, walked[first:])
+    got = np.zeros(7, dtype=np.uint64)  # inside one far stretch, not at its start
+    assert L.limg_hip_host_dense_checkpoints(16384 + 64 + 17, 7, got.ctypes.data_as(C.c_void_p)) == 0
+    assert np.array_equal(got, walked[16384 + 64 + 17: 16384 + 64 + 24])
+    assert L.limg_hip_host_dense_checkpoints(0, 0, got.ctypes.data_as(C.c_void_p)) == 0
+    assert L.limg_hip_host_dense_checkpoints(2048 * 64 - 7, 7, got.ctypes.data_as(C.c_void_p)) == 0
+    assert L.limg_hip_host_dense_checkpoints(2048 * 64 - 6, 7, got.ctypes.data_as(C.c_void_p)) == 103  # limg_hip_error_OutOfBounds
+    assert L.limg_hip_host_dense_checkpoints(0, 1, None) == 102
