@@ -1,11 +1,19 @@
 """Maximum sizes (the reference has no size limit but memory, src/limg.cpp:2175-2265): an image of more than 5.59 M blocks, whose dither chain is longer than the embedded dense
 checkpoints reach (16 Mi calls) -- the context then makes the dense values it lacks from the embedded FAR checkpoints (limg_hip_api.hip ensure_checkpoints) -- and whose planes'
 byte offsets pass 2^32.  24576^2 = 604 Mpixels, 9.4 M blocks, up to 28 M dither calls, ~22 GiB of device memory at a time (tools/huge_image_check.py is the same at 32768^2 = 1 Gpixel).
-Size-independent properties instead of a CPU run of the whole image; every comparison of whole planes happens on the device."""
+The whole image IS pinned against the real reference: tests/golden/fullsize.json `pn24576_strips` holds, per strip of 3072 rows, the position-sensitive 64-bit checksums of the
+eleven planes the reference (oracle/_ref, one chain, one thread, 5 minutes in the build container: tools/make_golden_fullsize.py) wrote -- computed here on the device.  Around it,
+size-independent properties; every comparison of whole planes happens on the device."""
+import json
+import os
+import sys
+
 import numpy as np
 import pytest
 
 from oracle.bind import PLANES
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -44,6 +52,16 @@ def test_image_beyond_the_dense_checkpoints(gpu, oracle):
         gpu.check()
         psnr, _ = gpu.compare_device(img, planes["pDecoded"], True)
         assert abs(psnr - 38.87) < 0.1, psnr
+        # every plane of every strip against the REAL reference's checksums: the chain is right 28 M calls deep (far checkpoints), the stores are right past 2^32
+        sys.path.insert(0, ROOT)
+        import bench
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize.json")))["pn24576_strips"]
+        assert (gold["w"], gold["h"], gold["seed"], gold["kw"]) == (N, N, 1, {})
+        assert abs(psnr - gold["psnr"]) < 1e-6, (psnr, gold["psnr"])
+        sr = gold["strip_rows"]
+        for si, strip in enumerate(gold["strips"]):
+            for name, want in strip["sum64"].items():
+                assert bench.sum64_device(planes[name][si * sr:(si + 1) * sr]) == want, (si, name)
         _band_equals_oracle(oracle, img, planes, 0, PLANES)            # the chain starts at the seed: every plane
         _band_equals_oracle(oracle, img, planes, N // 2, UNIFORM)       # chain-independent planes in the middle ...
         _band_equals_oracle(oracle, img, planes, N - 64, UNIFORM)       # ... and at the far end (byte offset 2.4e9 in the 32-bit planes)

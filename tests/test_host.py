@@ -339,3 +339,15 @@ def test_dense_checkpoints_beyond_the_embedded_table():
     assert L.limg_hip_host_dense_checkpoints(2048 * 64 - 7, 7, got.ctypes.data_as(C.c_void_p)) == 0
     assert L.limg_hip_host_dense_checkpoints(2048 * 64 - 6, 7, got.ctypes.data_as(C.c_void_p)) == 103  # limg_hip_error_OutOfBounds
     assert L.limg_hip_host_dense_checkpoints(0, 1, None) == 102
+
+
+def test_oracle_sanitizer_script_runs():
+    """tools/oracle_sanitize.sh (the CPU restatements of both encoders under ASan + UBSan on the golden cases; GPU sanitizers are not available on the pool) still builds
+    and passes -- it had rotted once (the merged-block restatement's file missing from its compile line)."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc") or subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip() == "libasan.so":
+        pytest.skip("no gcc / libasan here")
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "oracle_sanitize.sh")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "oracle clean under ASan+UBSan" in r.stdout

@@ -37,6 +37,9 @@ CASES = {
 STRIPPED = {
     "pn16384_strips": ("pn", 16384, 16384, 1, {}),
     "pn16384_pool2_strips": ("pn", 16384, 16384, 1, {"pool_threads": 2}),
+    # beyond the embedded dense chain checkpoints (9.4 M blocks, up to 28 M dither calls; 24 GB of host memory and a minute of the reference's single thread): pins the
+    # far checkpoints and the plane offsets past 2^32 against the real reference (tests/test_gpu_huge.py)
+    "pn24576_strips": ("pn", 24576, 24576, 1, {}),
 }
 # merged-block encoder: (generator, size, seed)
 BLOCKED = {
