@@ -232,11 +232,13 @@ namespace
     unsigned threads = std::thread::hardware_concurrency();
     if (threads == 0 || threads > 16) threads = 16;
     if (threads > j1 - j0) threads = (unsigned)(j1 - j0);
+    uint64_t scratch[16][64]; // one far stretch's dense values per thread (nothing may throw inside the threads)
+    if (perFar > 64) return false;
     auto work = [&](unsigned t) {
-      std::vector<uint64_t> tmp(perFar);
+      uint64_t *tmp = scratch[t];
       for (size_t j = j0 + t; j < j1; j += threads)
       {
-        (void)chain_checkpoints(far[j], farEvery, ckEvery, tmp.data(), false);
+        (void)chain_checkpoints(far[j], farEvery, ckEvery, tmp, false);
         for (size_t q = 0; q < perFar; q++)
         {
           const size_t idx = j * perFar + q;
