@@ -56,14 +56,17 @@ typedef struct limg_hip_compact_out
   uint32_t *pShifts;               /* blocksX*blocksY: shiftA | shiftB << 8 | shiftC << 16 | ditherCalls << 24 */
 } limg_hip_compact_out;
 
-/* Knobs that have no parameter in the reference signature.  Zero-initialise, then set what you need. */
+/* Knobs that have no parameter in the reference signature (the reference has none of these: src/limg.h:27-48).  Fill with limg_hip_default_options, then set what
+ * you need.  The struct is VERSIONED BY ITS SIZE: `struct_size` is sizeof(limg_hip_options) as the caller's compiler saw it (limg_hip_default_options below writes
+ * it); the library reads and writes only that many bytes and gives every member beyond them its default, so members can be appended without breaking a caller
+ * built against an earlier header.  Nothing here changes results except forced_shift, dither_pcg and float_mode; there are no fault-injection or test knobs in this
+ * library (those live in liblimg_hip_test.so, include/limg_hip_test_hooks.h, which the test suite loads instead). */
 typedef struct limg_hip_options
 {
+  uint32_t struct_size;    /* sizeof(limg_hip_options) in the caller's build; limg_hip_set_options rejects 0, anything not a multiple of 4 and anything too short for forced_shift */
   int32_t forced_shift[3]; /* all three in 0..8: bypass the shift search (a10-a12) with this triple; otherwise {-1,-1,-1} */
   int32_t force_split_kernels; /* non-0: use the three-launch path (fit+search, scan, dither+store) even where the persistent kernel applies */
   int32_t dither_pcg;          /* non-0: the reference's PCG dither (src/limg.cpp:799-822, what it runs on hosts without AES-NI) instead of the AES one */
-  int32_t test_record_limit;   /* test hook, 0 = default: blocks with a record value of magnitude >= this take the generic 32-bit trial
-                                  (default 2701 -- up to 2700 the packed 16-bit trial is exact by construction; a fit of byte pixels stays below 2041); 1 sends every block through it */
   int32_t float_mode;          /* 0 (default) = EXACT: the float stage op for op as the reference's strict SSE build (DPPS order, x86 RSQRTPS table, correctly
                                   rounded divisions): every plane bit-identical to the reference.  1 = FAST: hardware v_rsq_f32 / v_rcp_f32 and fused multiply-adds;
                                   contract: the integer stage stays bit-exact given the same records, extrema within +-2 LSB on >= 99.9 % of blocks, perceptual PSNR
@@ -73,29 +76,15 @@ typedef struct limg_hip_options
   int32_t collect_stats;       /* non-0: every encode (8x8 path and merged-block encoder) also leaves the reference's bit statistics for limg_hip_last_stats */
   int32_t host_noise_table;    /* non-0: build the context's dither noise table on the host (one serial AES walk + upload, ~100 ms per new size class: what rounds 1-2 did)
                                   instead of filling it on the GPU from the embedded chain checkpoints.  Same bytes; A/B switch for tests */
-  int32_t test_batch_chunk;    /* test hook, 0 = default: limg_hip_encode3d_batch_device puts at most this many images into one launch pair (default: as many as 1 GiB
-                                  of per-block scratch holds) */
   int32_t batch_sub_images;    /* limg_hip_encode3d_batch_device runs a long list as a PIPELINE of sub-batches: the float-stage kernel of sub-batch k + 1 on a stream of
                                   the context's own next to the persistent kernel of sub-batch k (which leaves it a residency slot: 5 workgroups per CU instead of 6).
                                   0 = automatic (sub-batches of 8 for lists of 32 images and more, of 4 from 16 images, none below); > 0 = sub-batches of this many
                                   images; < 0 = never: one launch pair for the whole list.  Same planes in every case */
-  int32_t test_wg_per_cu;      /* A/B hook, 0 = default: workgroups per CU of the persistent kernel's launch, 1 .. its launch bound (6; values above are ignored) */
-  int32_t test_whole_image_ragged; /* test hook, non-0: an image whose width is whole 8x8 blocks but whose last block row is partial goes through the whole-image
-                                  ragged path (host chain walk over every dither call) instead of fast path + last row; same planes either way */
-  int32_t test_pipeline;       /* A/B hook of the sub-batch pipeline, 0 = defaults (see limg_hip_api.hip) */
-  int32_t test_fail_chain_phase1; /* test hook, non-0: limg_hip_encode3d_single_chain_device behaves as if this rank's E step had failed (abort rule below) */
-  int32_t test_blocked_no_bound; /* test / A-B hook, non-0: the merged-block encoder's similarity kernel evaluates the 27-colour loop for every pair its early exits leave
-                                  open, without the certain-match / certain-failure bounds in front of it (limg_hip_blocked.hip).  Same bits either way */
   int32_t ragged_bands;        /* images with a partial last block COLUMN and one dither chain (poolThreads == 0): the host's chain walk -- the floor of this class -- is
                                   pipelined with the GPU in this many bands of block rows (E step band by band, the walk under it, every band's F step under the next band's
                                   walk).  0 = automatic (16 bands from 64 block rows x 32 block columns on), N > 0 = N bands, < 0 = off (one E launch, walk, one F launch) */
   int32_t ragged_walk_threads; /* ... with several chains (poolThreads > 0) the chains are independent, as on the reference's thread pool (src/limg.cpp:2114-2134): they are
                                   walked on this many host threads (0 = one per chain, at most 16 and the host's hardware threads; 1 = serial) */
-  int32_t test_lookback_spins; /* test hook, 0 = default (2^22 polls, seconds): bound of one look-back wait of the persistent kernel */
-  int32_t test_base_error_strip; /* test hook, N > 0: work strip N - 1 of the persistent kernel dithers from a chain position that is off by one dither call (every other
-                                  strip is unaffected): the smallest possible look-back error, which the full-size reference hashes must catch (tests/test_gpu_fullsize.py) */
-  int32_t test_skip_publish_strip; /* test hook, N > 0: work strip N - 1 of the persistent kernel never publishes its dither-call count, i.e. the look-back of every
-                                  later strip of its chain times out (see limg_hip_check_device_status: such strips store nothing that depends on the chain) */
 } limg_hip_options;
 
 typedef struct limg_hip_context limg_hip_context;
@@ -112,9 +101,14 @@ typedef struct limg_hip_context limg_hip_context;
  * (the reference keeps no state besides CPUID flags, src/limg_simd.cpp:57-60). */
 limg_hip_result limg_hip_init(int device, limg_hip_context **ppCtx);
 void limg_hip_shutdown(limg_hip_context **ppCtx);
-void limg_hip_default_options(limg_hip_options *pOptions);
+/* Defaults into the first `structSize` bytes of *pOptions (struct_size = structSize).  Call it through limg_hip_default_options, which passes the size of the struct
+ * as the CALLER was compiled. */
+void limg_hip_default_options_sized(limg_hip_options *pOptions, size_t structSize);
+static inline void limg_hip_default_options(limg_hip_options *pOptions) { limg_hip_default_options_sized(pOptions, sizeof(limg_hip_options)); }
+/* Takes pOptions->struct_size bytes; members beyond them get their defaults. */
 limg_hip_result limg_hip_set_options(limg_hip_context *pCtx, const limg_hip_options *pOptions);
-limg_hip_result limg_hip_get_options(const limg_hip_context *pCtx, limg_hip_options *pOptions); /* read, change one field, set: nothing else is reset */
+/* pOptions->struct_size must be set on entry (= the room the caller has); that many bytes are written.  Read, change one member, set: nothing else is reset. */
+limg_hip_result limg_hip_get_options(const limg_hip_context *pCtx, limg_hip_options *pOptions);
 
 /* Replaces `limg_encode3d_test` (src/limg.h:35, src/limg.cpp:2175-2265).  HOST pointers; blocking.
  * poolThreads: 0 == `pThreadPool = nullptr` (one dither chain over the image); T > 0 == a pool of T threads, i.e. T*4

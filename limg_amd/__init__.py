@@ -10,7 +10,10 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("LIMG_HIP_LIB") or os.path.join(HERE, "liblimg_hip.so")  # LIMG_HIP_LIB: A/B runs against another build of the same ABI
+TEST_LIB_PATH = os.path.join(HERE, "liblimg_hip_test.so")  # the -DLIMG_HIP_TEST_HOOKS build (include/limg_hip_test_hooks.h): what tests/conftest.py selects
+LIB_PATH = os.environ.get("LIMG_HIP_LIB") or os.path.join(HERE, "liblimg_hip.so")  # LIMG_HIP_LIB: A/B runs against another build of the same ABI ("test" = TEST_LIB_PATH)
+if LIB_PATH == "test":
+    LIB_PATH = TEST_LIB_PATH
 
 P32 = ("pDecoded", "pShiftABCX", "pColAMin", "pColAMax", "pColBMin", "pColBMax", "pColCMin", "pColCMax")
 P8 = ("pFactorsA", "pFactorsB", "pFactorsC")
@@ -18,7 +21,7 @@ PLANES = P32 + P8
 
 # every symbol include/limg_hip.h declares (checked by tests/test_host.py without a GPU)
 ABI_SYMBOLS = (
-    "limg_hip_init", "limg_hip_shutdown", "limg_hip_default_options", "limg_hip_set_options", "limg_hip_get_options", "limg_hip_encode3d", "limg_hip_encode3d_perf",
+    "limg_hip_init", "limg_hip_shutdown", "limg_hip_default_options_sized", "limg_hip_set_options", "limg_hip_get_options", "limg_hip_encode3d", "limg_hip_encode3d_perf",
     "limg_hip_encode3d_stats", "limg_hip_blocked_encode3d_stats",
     "limg_hip_encode3d_device", "limg_hip_encode3d_batch_device", "limg_hip_last_stats", "limg_hip_compare", "limg_hip_compare_device", "limg_hip_synth_random_gradient_device",
     "limg_hip_synth_photo_noise_device", "limg_hip_context_device_bytes", "limg_hip_version", "limg_hip_profile_begin", "limg_hip_profile_end",
@@ -30,6 +33,7 @@ ABI_SYMBOLS = (
     "limg_hip_comm_unique_id", "limg_hip_comm_init", "limg_hip_comm_destroy", "limg_hip_comm_info", "limg_hip_gather_stream", "limg_hip_encode3d_single_chain_device",
     "limg_hip_encode3d_chain_device", "limg_hip_host_gather_offsets", "limg_hip_host_chain_bases",
 )
+TEST_ABI_SYMBOLS = ("limg_hip_default_test_options_sized", "limg_hip_set_test_options")  # include/limg_hip_test_hooks.h: exported by liblimg_hip_test.so only
 COMM_ID_BYTES = 128
 
 # limg_blocked_encode3d_info (src/limg.h:39-44), member order
@@ -60,11 +64,16 @@ class CompactOut(C.Structure):
 
 
 class Options(C.Structure):
-    _fields_ = [("forced_shift", C.c_int32 * 3), ("force_split_kernels", C.c_int32), ("dither_pcg", C.c_int32), ("test_record_limit", C.c_int32), ("float_mode", C.c_int32), ("legacy_float_stage", C.c_int32),
-                ("collect_stats", C.c_int32), ("host_noise_table", C.c_int32), ("test_batch_chunk", C.c_int32), ("batch_sub_images", C.c_int32), ("test_wg_per_cu", C.c_int32),
-                ("test_whole_image_ragged", C.c_int32), ("test_pipeline", C.c_int32), ("test_fail_chain_phase1", C.c_int32),
-                ("test_blocked_no_bound", C.c_int32), ("ragged_bands", C.c_int32), ("ragged_walk_threads", C.c_int32), ("test_lookback_spins", C.c_int32), ("test_base_error_strip", C.c_int32),
-                ("test_skip_publish_strip", C.c_int32)]
+    _fields_ = [("struct_size", C.c_uint32), ("forced_shift", C.c_int32 * 3), ("force_split_kernels", C.c_int32), ("dither_pcg", C.c_int32), ("float_mode", C.c_int32),
+                ("legacy_float_stage", C.c_int32), ("collect_stats", C.c_int32), ("host_noise_table", C.c_int32), ("batch_sub_images", C.c_int32), ("ragged_bands", C.c_int32),
+                ("ragged_walk_threads", C.c_int32)]
+
+
+class TestOptions(C.Structure):
+    """include/limg_hip_test_hooks.h -- liblimg_hip_test.so only"""
+    _fields_ = [("struct_size", C.c_uint32), ("record_limit", C.c_int32), ("batch_chunk", C.c_int32), ("wg_per_cu", C.c_int32), ("whole_image_ragged", C.c_int32),
+                ("pipeline", C.c_int32), ("fail_chain_phase1", C.c_int32), ("blocked_no_bound", C.c_int32), ("lookback_spins", C.c_int32), ("base_error_strip", C.c_int32),
+                ("skip_publish_strip", C.c_int32), ("accurate_mapping", C.c_int32)]
 
 
 def load_library(path=None):
@@ -83,7 +92,11 @@ def load_library(path=None):
     L.limg_hip_init.restype = C.c_int
     L.limg_hip_init.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     L.limg_hip_shutdown.argtypes = [C.POINTER(C.c_void_p)]
-    L.limg_hip_default_options.argtypes = [C.c_void_p]
+    L.limg_hip_default_options_sized.argtypes = [C.c_void_p, C.c_size_t]
+    if hasattr(L, "limg_hip_set_test_options"):
+        L.limg_hip_default_test_options_sized.argtypes = [C.c_void_p, C.c_size_t]
+        L.limg_hip_set_test_options.restype = C.c_int
+        L.limg_hip_set_test_options.argtypes = [C.c_void_p, C.c_void_p]
     L.limg_hip_set_options.restype = C.c_int
     L.limg_hip_set_options.argtypes = [C.c_void_p, C.c_void_p]
     L.limg_hip_get_options.restype = C.c_int
@@ -247,8 +260,8 @@ class LimgHip:
     """One context on one GPU.  Host-array methods mirror the reference API (src/limg.h:35,37,48); *_device methods take
     torch CUDA tensors (used only as device memory) and run asynchronously on torch's current stream."""
 
-    def __init__(self, device=-1):
-        self.lib = load_library()
+    def __init__(self, device=-1, lib_path=None):
+        self.lib = load_library(lib_path)
         self.ctx = C.c_void_p()
         self.comm_rank, self.comm_world = 0, 1
         _check(self.lib.limg_hip_init(device, C.byref(self.ctx)), "limg_hip_init")
@@ -264,37 +277,46 @@ class LimgHip:
         except Exception:
             pass
 
-    def set_options(self, forced_shift=None, force_split=False, dither_pcg=False, test_record_limit=0, float_fast=False, legacy_float_stage=False, test_batch_chunk=0, host_noise_table=False, collect_stats=False,
-                    batch_sub_images=0, test_wg_per_cu=0, test_whole_image_ragged=False, test_fail_chain_phase1=False, test_pipeline=0, test_blocked_no_bound=False,
-                    test_lookback_spins=0, test_skip_publish_strip=0, test_base_error_strip=0, ragged_bands=0, ragged_walk_threads=0):
+    def set_options(self, forced_shift=None, force_split=False, dither_pcg=False, float_fast=False, legacy_float_stage=False, host_noise_table=False, collect_stats=False,
+                    batch_sub_images=0, ragged_bands=0, ragged_walk_threads=0, **test_hooks):
+        """Every call sets ALL options (unnamed ones to their defaults).  Keywords starting with `test_` are the hooks of include/limg_hip_test_hooks.h
+        (test_base_error_strip=N -> limg_hip_test_options.base_error_strip): they need liblimg_hip_test.so and raise on the product library."""
         o = Options()
-        self.lib.limg_hip_default_options(C.byref(o))
+        self.lib.limg_hip_default_options_sized(C.byref(o), C.sizeof(o))
         if forced_shift is not None:
             for i in range(3):
                 o.forced_shift[i] = int(forced_shift[i])
         o.force_split_kernels = int(force_split)
         o.dither_pcg = int(dither_pcg)
-        o.test_record_limit = int(test_record_limit)
         o.float_mode = 1 if float_fast else 0
         o.legacy_float_stage = int(legacy_float_stage)
-        o.test_batch_chunk = int(test_batch_chunk)
         o.host_noise_table = int(host_noise_table)
         o.collect_stats = int(collect_stats)
         o.batch_sub_images = int(batch_sub_images)
-        o.test_wg_per_cu = int(test_wg_per_cu)
-        o.test_whole_image_ragged = int(test_whole_image_ragged)
-        o.test_fail_chain_phase1 = int(test_fail_chain_phase1)
-        o.test_pipeline = int(test_pipeline)
-        o.test_blocked_no_bound = int(test_blocked_no_bound)
-        o.test_lookback_spins = int(test_lookback_spins)
-        o.test_skip_publish_strip = int(test_skip_publish_strip)
-        o.test_base_error_strip = int(test_base_error_strip)
         o.ragged_bands = int(ragged_bands)
         o.ragged_walk_threads = int(ragged_walk_threads)
         _check(self.lib.limg_hip_set_options(self.ctx, C.byref(o)), "limg_hip_set_options")
+        hooks = {}
+        for k, v in test_hooks.items():
+            if not k.startswith("test_") or k[5:] not in dict(TestOptions._fields_):
+                raise TypeError("set_options: unknown option %r" % k)
+            hooks[k[5:]] = int(v)
+        if self.has_test_hooks:
+            t = TestOptions()
+            self.lib.limg_hip_default_test_options_sized(C.byref(t), C.sizeof(t))
+            for k, v in hooks.items():
+                setattr(t, k, v)
+            _check(self.lib.limg_hip_set_test_options(self.ctx, C.byref(t)), "limg_hip_set_test_options")
+        elif any(hooks.values()):
+            raise LimgHipError("test hooks %s need liblimg_hip_test.so (LIMG_HIP_LIB=test); the product library has none" % sorted(k for k, v in hooks.items() if v))
+
+    @property
+    def has_test_hooks(self):
+        return hasattr(self.lib, "limg_hip_set_test_options")
 
     def get_options(self):
         o = Options()
+        o.struct_size = C.sizeof(o)
         _check(self.lib.limg_hip_get_options(self.ctx, C.byref(o)), "limg_hip_get_options")
         return o
 

@@ -1,4 +1,5 @@
-"""Build liblimg_hip.so (hipcc, gfx950 only) in-tree: limg_amd/liblimg_hip.so.
+"""Build liblimg_hip.so (hipcc, gfx950 only) in-tree: limg_amd/liblimg_hip.so -- the product -- and, from the same sources with -DLIMG_HIP_TEST_HOOKS,
+limg_amd/liblimg_hip_test.so: the build with the fault-injection / A-B hooks of include/limg_hip_test_hooks.h that the test suite loads (tests/conftest.py).
 
 Numerics-critical flags: -ffp-contract=off (hipcc's default is fast contraction; the float stage must round every
 multiply and add separately, like the reference's SSE code) and no fast-math of any kind.  f32 division stays
@@ -10,6 +11,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liblimg_hip.so")
+TEST_OUT = os.path.join(HERE, "liblimg_hip_test.so")
+TEST_FLAGS = ["-DLIMG_HIP_TEST_HOOKS"]
 SOURCES = ["limg_hip_kernels.hip", "limg_hip_fit_tpb.hip", "limg_hip_stream.hip", "limg_hip_blocked.hip", "limg_hip_synth.hip", "limg_hip_noise_gpu.hip", "limg_hip_api.hip", "limg_hip_noise.cpp", "limg_hip_blocked_host.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 # per-source extras.  limg_hip_kernels.hip: every atomic in it is issued by one lane (block queue, ticket, look-back descriptors); LLVM's atomic optimizer would still
@@ -27,29 +30,46 @@ def _newer(target, deps):
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force=False, verbose=False, extra_flags=(), out_dir=None):
-    """out_dir: build objects and the library THERE from the sources (nothing reused, nothing in-tree touched) -- the from-scratch check of tests/test_build_from_source.py."""
+def build(force=False, verbose=False, extra_flags=(), out_dir=None, test_hooks=False):
+    """out_dir: build objects and the library THERE from the sources (nothing reused, nothing in-tree touched) -- the from-scratch check of tests/test_build_from_source.py.
+    test_hooks: the -DLIMG_HIP_TEST_HOOKS build (liblimg_hip_test.so; objects *.test.o)."""
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "limg_hip.h"), os.path.abspath(__file__)]
-    out = OUT if out_dir is None else os.path.join(out_dir, "liblimg_hip.so")
-    if out_dir is None and not force and _newer(OUT, deps):
-        return OUT
-    objs = []
+    inc = os.path.join(HERE, "..", "include")
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith(".o") and not f.startswith("__")] + [os.path.join(inc, "limg_hip.h"), os.path.join(inc, "limg_hip_test_hooks.h"), os.path.abspath(__file__)]
+    name = "liblimg_hip_test.so" if test_hooks else "liblimg_hip.so"
+    target = os.path.join(HERE, name)
+    out = target if out_dir is None else os.path.join(out_dir, name)
+    if out_dir is None and not force and _newer(target, deps):
+        return target
+    extra = list(extra_flags) + (TEST_FLAGS if test_hooks else [])
+    jobs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC if out_dir is None else out_dir, src.rsplit(".", 1)[0] + ".o")
-        cmd = [hipcc] + FLAGS + SOURCE_FLAGS.get(src, []) + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(CSRC if out_dir is None else out_dir, src.rsplit(".", 1)[0] + (".test.o" if test_hooks else ".o"))
+        cmd = [hipcc] + FLAGS + SOURCE_FLAGS.get(src, []) + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if src.endswith(".cpp"):
             # host-only translation units; the merge's similarity predicate is float code that must round like the kernels: no contraction
-            cmd = [hipcc, "-O3", "-fPIC", "-std=c++17", "-Wall", "-ffp-contract=off", "-fno-fast-math", "-x", "c++"] + [f for f in extra_flags if f.startswith("-D")] + ["-c", os.path.join(CSRC, src), "-o", obj]
+            cmd = [hipcc, "-O3", "-fPIC", "-std=c++17", "-Wall", "-ffp-contract=off", "-fno-fast-math", "-x", "c++"] + [f for f in extra if f.startswith("-D")] + ["-c", os.path.join(CSRC, src), "-o", obj]
+        jobs.append((cmd, obj))
+
+    def run(job):
         if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-        objs.append(obj)
+            print(" ".join(job[0]), flush=True)
+        subprocess.check_call(job[0])
+        return job[1]
+
+    with ThreadPoolExecutor(max_workers=int(os.environ.get("LIMG_BUILD_JOBS", "4"))) as ex:
+        objs = list(ex.map(run, jobs))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return out
+
+
+def build_all(force=False, verbose=False):
+    """both libraries: the product and the test-hooks build"""
+    return build(force=force, verbose=verbose), build(force=force, verbose=verbose, test_hooks=True)
 
 
 CLI_SRC = os.path.join(HERE, "..", "tools", "limg_hip_cli.cpp")
@@ -72,5 +92,5 @@ def build_cli(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build_all(force="--force" in sys.argv, verbose=True))
     print(build_cli(force="--force" in sys.argv, verbose=True))

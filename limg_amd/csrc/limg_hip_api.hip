@@ -1,11 +1,18 @@
 // limg_hip_api.hip -- host side of liblimg_hip.so: context, buffers, launch sequencing, the C ABI of include/limg_hip.h.
 // Mirrors the reference's driver (src/limg.cpp:2175-2265 threshold/flag setup, :2105-2138 strip partition).
 #include "limg_hip_internal.h"
+#ifdef LIMG_HIP_TEST_HOOKS
+#include "../../include/limg_hip_test_hooks.h"
+#define TOPT(c, member) ((c)->topt.member)
+#else
+#define TOPT(c, member) 0 /* the product has no test hooks: every use folds to the default */
+#endif
 #include "limg_hip_rccl.h"
 #include "limg_search_table_accurate.h"
 
 #include <math.h>
 #include <stdio.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 #include <new>
@@ -83,6 +90,9 @@ struct limg_hip_context
   std::recursive_mutex hostEntry;
   int device = 0;
   limg_hip_options opt;
+#ifdef LIMG_HIP_TEST_HOOKS
+  limg_hip_test_options topt; // liblimg_hip_test.so only (include/limg_hip_test_hooks.h)
+#endif
   DevBuf records, shifts, stripCalls, stripBase; // per-block / per-strip scratch
   DevBuf invN;                                   // per block 1 / |normal|^2 of the three factors (k_fit_tpb -> E step)
   DevBuf noise;                                  // static dither noise table (full-block chains)
@@ -458,7 +468,7 @@ namespace
     // An image whose WIDTH is whole blocks but whose last block row is partial (BASELINE config 1's shape class: 1024 x 618): every block row but the last
     // is on the fast path (its dither chain is the seed's orbit, the noise table applies); only the last row needs the host to walk its chain.
     if (ragged && sizeX % kBlock == 0 && sizeY > (size_t)kBlock && dInfo && chainPhase == 0 && batchCount == 1 && !x.inner && !x.fitOnly && !c->forceSplit &&
-        c->opt.legacy_float_stage == 0 && c->opt.dither_pcg == 0 && c->opt.test_whole_image_ragged == 0)
+        c->opt.legacy_float_stage == 0 && c->opt.dither_pcg == 0 && TOPT(c, whole_image_ragged) == 0)
     {
       if (((sizeX / kBlock) * ((sizeY + kBlock - 1) / kBlock)) * 3 <= checkpoint_reach())
         return encode_height_ragged(c, dIn, sizeX, sizeY, hasAlpha, dInfo, compact, errorFactor, poolThreads, fast, stream, x);
@@ -490,7 +500,7 @@ namespace
                         c->opt.forced_shift[2] >= 0 && c->opt.forced_shift[2] <= 8;
     for (int i = 0; i < 3; i++) p.forced[i] = forced ? c->opt.forced_shift[i] : -1;
     p.floatFast = (c->opt.float_mode == 1 && !x.fitOnly) ? 1 : 0;
-    p.recordLimit = c->opt.test_record_limit > 0 ? c->opt.test_record_limit - 1 : 2700; // see kTermBias in limg_hip_kernels.hip: 3 * 2700 + 1 < 0x2000
+    p.recordLimit = TOPT(c, record_limit) > 0 ? TOPT(c, record_limit) - 1 : 2700; // see kTermBias in limg_hip_kernels.hip: 3 * 2700 + 1 < 0x2000
     const Partition pt = x.part ? *x.part : partition(sizeY, poolThreads);
     p.chainCount = pt.chainCount; p.chainRows = pt.chainRows;
 
@@ -593,16 +603,18 @@ namespace
         HIP_TRY(hipMemsetAsync(c->devStatus.p, 0, 16, stream));
       }
       p.timeout = (uint32_t *)c->devStatus.p;
-      p.lookbackSpins = c->opt.test_lookback_spins > 0 ? (uint32_t)c->opt.test_lookback_spins : (1u << 22);
-      p.testSkipStrip = c->opt.test_skip_publish_strip > 0 ? (uint32_t)c->opt.test_skip_publish_strip - 1u : ~0u;
-      p.testBaseErrStrip = c->opt.test_base_error_strip > 0 ? (uint32_t)c->opt.test_base_error_strip - 1u : ~0u;
+#ifdef LIMG_HIP_TEST_HOOKS
+      p.lookbackSpins = c->topt.lookback_spins > 0 ? (uint32_t)c->topt.lookback_spins : (1u << 22);
+      p.testSkipStrip = c->topt.skip_publish_strip > 0 ? (uint32_t)c->topt.skip_publish_strip - 1u : ~0u;
+      p.testBaseErrStrip = c->topt.base_error_strip > 0 ? (uint32_t)c->topt.base_error_strip - 1u : ~0u;
+#endif
       p.compactOut = compact != nullptr || wantStats; // the statistics are reduced from the raster-order shift words
       if ((r = c->park.ensure((size_t)(c->persistentWorkgroups / 5 * 6) * 2 * 8192)) != limg_hip_success) return r; // 6 workgroups per CU: the kernel's launch bound
       p.park = (uint8_t *)c->park.p;
     }
     // workgroups per CU of the persistent kernel: 6 once the float stage is out (7 fit and were measured: no faster, the kernel is issue-bound), 5 with it inside;
     // limg_hip_options.test_wg_per_cu lowers it (A/B runs), never above the launch bound the park slots are sized for
-    auto wg_per_cu = [&](int deflt) { const int t = c->opt.test_wg_per_cu; return (t >= 1 && t < deflt) ? t : deflt; };
+    auto wg_per_cu = [&](int deflt) { const int t = TOPT(c, wg_per_cu); return (t >= 1 && t < deflt) ? t : deflt; };
 
     // A list of images as a PIPELINE of launch pairs (limg_hip_options.batch_sub_images): k_fit_tpb of sub-batch k + 1 runs on a stream of the context's own next to
     // the persistent kernel of sub-batch k.  On content with short searches (BASELINE configs 2 / 4: ~2 trials per block) the persistent kernel waits for its plane
@@ -620,7 +632,7 @@ namespace
     {
       // A/B hook (limg_hip_options.test_pipeline): bits 0..3 = 1 + k_fit_tpb's wave priority, bits 4..7 = workgroups per CU of the overlapped persistent launches,
       // bits 8..15 = images of the first sub-batch (whose float stage runs alone)
-      const uint32_t knobs = (uint32_t)c->opt.test_pipeline;
+      const uint32_t knobs = (uint32_t)TOPT(c, pipeline);
       const int fitPrio = (knobs & 15u) ? (int)(knobs & 15u) - 1 : 0, wgOverlapRaw = ((knobs >> 4) & 15u) ? (int)((knobs >> 4) & 15u) : 5,
                 wgOverlap = wgOverlapRaw > 6 ? 6 : wgOverlapRaw; // never above the launch bound the park slots are sized for
       const size_t firstSub = ((knobs >> 8) & 255u) && ((knobs >> 8) & 255u) < subImages ? (size_t)((knobs >> 8) & 255u) : subImages;
@@ -939,12 +951,42 @@ extern "C"
 {
   const char *limg_hip_version(void) { return "limg_hip 0.1 (gfx950)"; }
 
-  void limg_hip_default_options(limg_hip_options *o)
+  // limg_hip_options is versioned by its size (limg_hip.h): a caller compiled against an earlier, shorter header hands over fewer bytes
+  void limg_hip_default_options_sized(limg_hip_options *o, size_t structSize)
   {
-    if (!o) return;
-    memset(o, 0, sizeof(*o));
-    o->forced_shift[0] = o->forced_shift[1] = o->forced_shift[2] = -1;
+    if (!o || structSize < sizeof(uint32_t)) return;
+    limg_hip_options d;
+    memset(&d, 0, sizeof(d));
+    d.forced_shift[0] = d.forced_shift[1] = d.forced_shift[2] = -1;
+    const size_t n = structSize < sizeof(d) ? structSize : sizeof(d);
+    d.struct_size = (uint32_t)n;
+    memcpy(o, &d, n);
   }
+
+#ifdef LIMG_HIP_TEST_HOOKS
+  void limg_hip_default_test_options_sized(limg_hip_test_options *o, size_t structSize)
+  {
+    if (!o || structSize < sizeof(uint32_t)) return;
+    limg_hip_test_options d;
+    memset(&d, 0, sizeof(d));
+    const size_t n = structSize < sizeof(d) ? structSize : sizeof(d);
+    d.struct_size = (uint32_t)n;
+    memcpy(o, &d, n);
+  }
+
+  limg_hip_result limg_hip_set_test_options(limg_hip_context *c, const limg_hip_test_options *o)
+  {
+    if (!c || !o) return limg_hip_error_ArgumentNull;
+    const size_t n = o->struct_size;
+    if (n < sizeof(uint32_t) || (n & 3u) != 0) return limg_hip_error_InvalidParameter;
+    limg_hip_test_options full;
+    limg_hip_default_test_options_sized(&full, sizeof(full));
+    memcpy(&full, o, n < sizeof(full) ? n : sizeof(full));
+    full.struct_size = (uint32_t)sizeof(full);
+    c->topt = full;
+    return limg_hip_success;
+  }
+#endif
 
   limg_hip_result limg_hip_init(int device, limg_hip_context **ppCtx)
   {
@@ -964,7 +1006,10 @@ extern "C"
     c->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->persistentWorkgroups = 5 * prop.multiProcessorCount;
-    limg_hip_default_options(&c->opt);
+    limg_hip_default_options_sized(&c->opt, sizeof(c->opt));
+#ifdef LIMG_HIP_TEST_HOOKS
+    limg_hip_default_test_options_sized(&c->topt, sizeof(c->topt));
+#endif
     *ppCtx = c;
     return limg_hip_success;
   }
@@ -1003,15 +1048,25 @@ extern "C"
   limg_hip_result limg_hip_set_options(limg_hip_context *c, const limg_hip_options *o)
   {
     if (!c || !o) return limg_hip_error_ArgumentNull;
-    c->opt = *o;
-    c->forceSplit = o->force_split_kernels != 0;
+    const size_t n = o->struct_size;
+    if (n < offsetof(limg_hip_options, forced_shift) + sizeof(o->forced_shift) || (n & 3u) != 0) return limg_hip_error_InvalidParameter;
+    limg_hip_options full;
+    limg_hip_default_options_sized(&full, sizeof(full)); // members the caller's header did not have keep their defaults
+    memcpy(&full, o, n < sizeof(full) ? n : sizeof(full));
+    full.struct_size = (uint32_t)sizeof(full);
+    c->opt = full;
+    c->forceSplit = full.force_split_kernels != 0;
     return limg_hip_success;
   }
 
   limg_hip_result limg_hip_get_options(const limg_hip_context *c, limg_hip_options *o)
   {
     if (!c || !o) return limg_hip_error_ArgumentNull;
-    *o = c->opt;
+    size_t n = o->struct_size; // the room the caller has
+    if (n < sizeof(uint32_t) || (n & 3u) != 0) return limg_hip_error_InvalidParameter;
+    if (n > sizeof(c->opt)) n = sizeof(c->opt);
+    memcpy(o, &c->opt, n);
+    o->struct_size = (uint32_t)n;
     return limg_hip_success;
   }
 
@@ -1191,7 +1246,7 @@ extern "C"
     size_t chunk = (size_t)(1ull << 30) / (blocks * sizeof(limg_hip_block_record));
     if (chunk * strips > 0x7FFFFFFFull) chunk = 0x7FFFFFFFull / strips; // strip ids are 32 bits
     if (chunk < 1) chunk = 1;
-    if (c->opt.test_batch_chunk > 0) chunk = (size_t)c->opt.test_batch_chunk;
+    if (TOPT(c, batch_chunk) > 0) chunk = (size_t)TOPT(c, batch_chunk);
     const bool oneByOne = count == 1 || ragged || !full || c->opt.legacy_float_stage != 0 || c->forceSplit;
     std::vector<ImageIO> table;
     limg_hip_result r = limg_hip_success;
@@ -1591,7 +1646,7 @@ extern "C"
     if ((r = c->bFlags.ensure(blocks)) != limg_hip_success) return r;
     if ((r = c->hFlags.ensure(blocks + 16)) != limg_hip_success) return r; // (+ 16: the merge's scan reads 16 flags at a time)
     bp.matchFlags = (uint8_t *)c->bFlags.p;
-    if (c->opt.test_blocked_no_bound == 0)
+    if (TOPT(c, blocked_no_bound) == 0)
     {
       if ((r = c->bBound.ensure(blocks * 16)) != limg_hip_success) return r;
       bp.matchBound = (float *)c->bBound.p;
@@ -2139,7 +2194,7 @@ extern "C"
     limg_hip_result r;
     // E step + scan: this strip's dither calls land in words[0] ...  (bad arguments on this rank are a phase-1 failure like any other: see the abort rule)
     if (!pIn || !pInfo) r = limg_hip_error_ArgumentNull;
-    else if (c->opt.test_fail_chain_phase1 != 0) r = limg_hip_error_Generic;
+    else if (TOPT(c, fail_chain_phase1) != 0) r = limg_hip_error_Generic;
     else r = limg_hip_encode3d_chain_device(c, pIn, sizeX, stripRows, hasAlpha, pInfo, errorFactor, fastBitCrushing, 1, (uint64_t *)words, nullptr, blocksBefore, s);
     // Abort rule: a rank whose phase 1 failed must STILL join the exchange -- its peers are (about to be) inside ncclAllGather and would wait for it forever -- and
     // joins it with a poison value instead of a call count.  Every rank's k_chain_base then sees the poison: it hands the F step a poisoned base (k_dither_store

@@ -40,7 +40,7 @@ namespace limg_hip
     int32_t crushBits, fast; // reference: src/limg.cpp:2192-2197
     const uint32_t *accTable; // !fast: the accurate search's automaton, 8 dwords per state (limg_search_table_accurate.h expanded by the context)
     int32_t forced[3];       // -1 or forced shift
-    int32_t recordLimit;     // |record value| above which a block takes the generic 32-bit trial (2700: the bound the packed trial's 16-bit terms are proven for; tests lower it to exercise the generic path)
+    int32_t recordLimit;     // |record value| above which a block takes the generic 32-bit trial (2700: the bound the packed trial's 16-bit terms are proven for; the test build lowers it to exercise the generic path)
     // chain partition (reference: src/limg.cpp:2114-2134), in block rows
     uint32_t chainCount, chainRows; // chain c (< chainCount-1) owns block rows [c*chainRows, (c+1)*chainRows); the last owns the rest
     // per-block scratch / compact outputs
@@ -60,9 +60,11 @@ namespace limg_hip
     uint32_t *ticket;   // [0] = next strip id
     int32_t zeroLookback; // k_fit_tpb clears `ticket` (16 bytes) and the descriptors of the strips its waves cover (the persistent launch follows it on the stream)
     uint32_t *timeout;  // sticky: set when a look-back spin gave up; lives outside the per-launch words, cleared only by limg_hip_check_device_status
-    uint32_t lookbackSpins; // bound of one look-back wait, in polls (2^22 ~ seconds; limg_hip_options.test_lookback_spins lowers it)
+#ifdef LIMG_HIP_TEST_HOOKS // liblimg_hip_test.so only (include/limg_hip_test_hooks.h): the product's kernels carry none of this
+    uint32_t lookbackSpins; // bound of one look-back wait, in polls (the product: kLookbackSpins)
     uint32_t testBaseErrStrip; // test hook: the strip with this id dithers from a chain position that is off by one call (~0: none); its published count stays right
     uint32_t testSkipStrip; // test hook: the strip with this id never publishes its dither-call count (~0: none) -- what a lost predecessor looks like to the look-back
+#endif
     uint8_t *park;      // persistent kernel: per workgroup two 8 KiB slots holding a strip's parked results between its E and F steps
     int32_t compactOut; // persistent kernel: also write records / shift words to the raster-order arrays
     int32_t streamRaw;  // compact mode only: factors with shift 8 store their raw byte instead of 0 (input of the stream packer)

@@ -916,6 +916,28 @@ namespace limg_hip
       return __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
+    // bound of one look-back wait, in polls (~seconds); fault injection (a shorter bound, a strip that never publishes) exists in the test build only
+    template <class P>
+    __device__ __forceinline__ uint32_t lookback_spin_bound(const P &p)
+    {
+#ifdef LIMG_HIP_TEST_HOOKS
+      return p.lookbackSpins;
+#else
+      (void)p;
+      return 1u << 22;
+#endif
+    }
+    template <class P>
+    __device__ __forceinline__ bool publishes(const P &p, uint32_t id)
+    {
+#ifdef LIMG_HIP_TEST_HOOKS
+      return id != p.testSkipStrip;
+#else
+      (void)p; (void)id;
+      return true;
+#endif
+    }
+
     // called by all 64 lanes of one wave; returns the number of dither calls of the chain before strip `id`, or kBasePoison
     template <class P>
     __device__ __forceinline__ uint32_t lookback_base(const P &p, uint32_t id, uint32_t headId, uint32_t agg, int lane)
@@ -949,7 +971,7 @@ namespace limg_hip
             base += wave_sum(v);
             break;
           }
-          if (++spins > p.lookbackSpins)
+          if (++spins > lookback_spin_bound(p))
           {
             if (lane == 0) atomicExch(p.timeout, 1u);
             return kBasePoison;
@@ -1516,8 +1538,11 @@ namespace limg_hip
             c = c < p.chainCount - 1 ? c : p.chainCount - 1;
             headId = head0 + c * p.chainRows * p.stripsX;
           }
-          if (id == p.testSkipStrip) {} // (test hook: a strip that never publishes)
-          else if (id == headId) desc_store(p.desc + id, kDescInclusive, agg);
+#ifdef LIMG_HIP_TEST_HOOKS
+          if (id == p.testSkipStrip) {} // (test build: a strip that never publishes)
+          else
+#endif
+          if (id == headId) desc_store(p.desc + id, kDescInclusive, agg);
           else
           {
             const unsigned long long d = desc_load(p.desc + id - 1);
@@ -1693,9 +1718,11 @@ namespace limg_hip
           else
           {
             base = lookback_base(p, id, headId, agg, lane);
-            if (lane == 0 && id != p.testSkipStrip) desc_store(p.desc + id, kDescInclusive, base == kBasePoison ? kBasePoison : base + agg);
+            if (lane == 0 && publishes(p, id)) desc_store(p.desc + id, kDescInclusive, base == kBasePoison ? kBasePoison : base + agg);
           }
-          if (id == p.testBaseErrStrip) base += 1u; // (test hook: this strip alone dithers from the wrong place)
+#ifdef LIMG_HIP_TEST_HOOKS
+          if (id == p.testBaseErrStrip) base += 1u; // (test build: this strip alone dithers from the wrong place)
+#endif
         }
         else
         {

@@ -224,6 +224,9 @@ class Ref:
         L.ref_dither.restype = C.c_uint64
         L.ref_dither.argtypes = [C.c_int, C.c_size_t, C.c_uint64, C.c_void_p, C.c_int]
         L.ref_block_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int] + [C.c_void_p] * 5
+        if hasattr(L, "ref_encode3d_forced_shift"):
+            L.ref_encode3d_forced_shift.restype = C.c_int
+            L.ref_encode3d_forced_shift.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         if hasattr(L, "ref_blocked_encode3d"):
             L.ref_blocked_encode3d.restype = C.c_int
             L.ref_blocked_encode3d.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int]
@@ -256,6 +259,19 @@ class Ref:
         p32 = (C.c_void_p * 8)(*[out[k].ctypes.data for k in P32])
         p8 = (C.c_void_p * 3)(*[out[k].ctypes.data for k in P8])
         r = self.lib.ref_encode3d(_ptr(img), w, h, int(has_alpha), p32, p8, error_factor, pool_threads, int(fast), dither_mode)
+        assert r == 0, r
+        return out
+
+    def encode3d_forced_shift(self, img, has_alpha, shift):
+        """The reference's block functions in limg_encode3d_test's order with the search replaced by `shift` (oracle/ref_harness.cpp): the shift-dependent planes
+        pDecoded, pFactorsA/B/C of one dither chain."""
+        img = np.ascontiguousarray(img, dtype=np.uint32)
+        h, w = img.shape
+        out = {"pDecoded": np.zeros((h, w), dtype=np.uint32)}
+        out.update({k: np.zeros((h, w), dtype=np.uint8) for k in P8})
+        p8 = (C.c_void_p * 3)(*[out[k].ctypes.data for k in P8])
+        sh = np.asarray(shift, dtype=np.uint8)
+        r = self.lib.ref_encode3d_forced_shift(_ptr(img), w, h, int(has_alpha), _ptr(out["pDecoded"]), p8, _ptr(sh))
         assert r == 0, r
         return out
 

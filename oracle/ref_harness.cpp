@@ -4,7 +4,7 @@
 // of /root/reference/src (see that script).  It `#include`s the reference's limg.cpp so that the `static` block
 // functions of the hot path are reachable, and re-exports them with plain C signatures so that tests and the golden
 // fixture generator can drive them through ctypes.  Nothing here restates any arithmetic: every function below is a
-// thin call-through.  Only tests/, tools/make_golden.py, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+// thin call-through (ref_encode3d_forced_shift sequences the reference's own block functions with the search left out: see there).  Only tests/, tools/make_golden.py, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
 // load the resulting oracle/_ref/liblimg_ref.so.
 
 #include "limg.cpp" // reference: src/limg.cpp (patched temp copy on the include path)
@@ -62,6 +62,42 @@ namespace
     ctx.errorPixelRetainingBitCrush = !fast;
     ctx.coarseFineBitCrush = fast;
   }
+
+  // BASELINE config 3's forced-shift sweep has no switch upstream ("the reference has no bits/factor knob"): this drives the reference's OWN block
+  // functions in the order limg_encode3d_test_y_range calls them (src/limg.cpp:1895-2100) with the search (a10-a12, :1922-1945) left out and `shift` a constant:
+  // gather -> sums -> fit -> colour-error state -> factor bytes -> limg_encode_dither per factor whose shift is neither 0 nor 8 (:1947-1958) -> the factor planes
+  // (byte << shift, :2064-2074) -> limg_decode_block_from_factors_3d.  Only the planes that depend on the shift are produced (pDecoded, pFactorsA/B/C); the six
+  // colour planes do not (they equal those of the adaptive encode of the same image) and pShiftABCX is one constant.  One dither chain (pThreadPool == nullptr).
+  template <size_t channels>
+  void forced_rows(limg_encode_context &ctx, const uint32_t *pIn, const size_t sizeX, const size_t sizeY, const uint8_t shift[3], uint32_t *pDecoded, uint8_t *pFA, uint8_t *pFB, uint8_t *pFC)
+  {
+    float scratch[limg_MinBlockSize * limg_MinBlockSize * 4];
+    uint32_t px[limg_MinBlockSize * limg_MinBlockSize];
+    uint64_t chain = 0xCA7F00D15BADF00D; // src/limg.cpp:1893
+    uint8_t *f[3] = { reinterpret_cast<uint8_t *>(scratch), nullptr, nullptr };
+    uint8_t *planes[3] = { pFA, pFB, pFC };
+    for (size_t by = 0; by < sizeY; by += limg_MinBlockSize)
+      for (size_t bx = 0; bx < sizeX; bx += limg_MinBlockSize)
+      {
+        const size_t w = limgMin(sizeX - bx, limg_MinBlockSize), h = limgMin(sizeY - by, limg_MinBlockSize), n = w * h;
+        for (size_t r = 0; r < h; r++) memcpy(px + r * w, pIn + (by + r) * sizeX + bx, w * sizeof(uint32_t));
+        limg_encode_decomposition_state st;
+        limg_encode_sum_to_decomposition_state<channels>(&ctx, px, n, st);
+        limg_encode_3d_output<channels> rec;
+        limg_encode_get_block_factors_accurate_from_state_3d<channels>(&ctx, px, n, rec, st, scratch);
+        limg_color_error_state_3d<channels> ces;
+        limg_init_color_error_state_3d<channels>(rec, ces);
+        f[1] = f[0] + n; f[2] = f[1] + n;
+        limg_color_error_state_3d_get_all_factors(&ctx, rec, ces, px, n, f[0], f[1], f[2]);
+        for (int k = 0; k < 3; k++)
+          if (shift[k] != 0 && shift[k] != 8) chain = limg_encode_dither(shift[k], n, chain, f[k]);
+        for (int k = 0; k < 3; k++)
+          for (size_t r = 0; r < h; r++)
+            for (size_t c = 0; c < w; c++) planes[k][(by + r) * sizeX + bx + c] = (uint8_t)(f[k][r * w + c] << shift[k]);
+        limg_decode_block_from_factors_3d<channels>(pDecoded + by * sizeX + bx, sizeX, w, h, f[0], f[1], f[2], rec, shift);
+      }
+  }
+
 }
 
 extern "C"
@@ -122,6 +158,16 @@ extern "C"
     const int r = (int)limg_encode3d_test_perf(pIn, sizeX, sizeY, hasAlpha != 0, errorFactor, pPool, fast != 0);
     if (pPool) limg_thread_pool_destroy(&pPool);
     return r;
+  }
+
+  int ref_encode3d_forced_shift(const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, uint32_t *pDecoded, uint8_t **p8 /* A,B,C */, const uint8_t *shift /* 3, each 0..8 */)
+  {
+    set_features(0);
+    limg_encode_context ctx; fill_ctx(ctx, 100, true, hasAlpha != 0);
+    ctx.pSourceImage = pIn; ctx.sizeX = sizeX; ctx.sizeY = sizeY;
+    if (hasAlpha) forced_rows<4>(ctx, pIn, sizeX, sizeY, shift, pDecoded, p8[0], p8[1], p8[2]);
+    else forced_rows<3>(ctx, pIn, sizeX, sizeY, shift, pDecoded, p8[0], p8[1], p8[2]);
+    return 0;
   }
 
   double ref_compare(const uint32_t *pA, const uint32_t *pB, size_t sizeX, size_t sizeY, int hasAlpha, double *pMse, double *pMax)

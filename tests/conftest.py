@@ -8,6 +8,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The suite runs on the -DLIMG_HIP_TEST_HOOKS build (limg_amd/liblimg_hip_test.so: the product's sources + the fault-injection / A-B hooks of
+# include/limg_hip_test_hooks.h); the product library carries none of them.  Only THIS process is redirected: bench.py, the CLI, the shim binaries and the
+# rank scripts a test starts load the product unless the test hands them LIMG_HIP_LIB itself.  tests/test_product_library.py runs on the product library.
+import limg_amd  # noqa: E402
+
+if not os.environ.get("LIMG_HIP_LIB"):
+    limg_amd.LIB_PATH = limg_amd.TEST_LIB_PATH
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "ref: needs oracle/_ref (the real reference build; only where /root/reference exists)")

@@ -18,16 +18,24 @@ def lib():
     import limg_amd
     if not os.path.exists(limg_amd.LIB_PATH):
         from limg_amd import build
-        build.build()
+        build.build_all()
     return limg_amd.load_library()
 
 
 def test_abi_exports_every_declared_symbol(lib):
     import limg_amd
     hdr = open(os.path.join(ROOT, "include", "limg_hip.h")).read()
-    declared = set(re.findall(r"\b(limg_hip_[a-z0-9_]+)\s*\(", hdr))
+    inline = set(re.findall(r"static inline \w+ (limg_hip_[a-z0-9_]+)\s*\(", hdr))  # header-only wrappers (limg_hip_default_options): not exports
+    declared = set(re.findall(r"\b(limg_hip_[a-z0-9_]+)\s*\(", hdr)) - inline
     assert declared, "no declarations parsed"
     assert declared == set(limg_amd.ABI_SYMBOLS), declared ^ set(limg_amd.ABI_SYMBOLS)
+    for s in declared:
+        assert getattr(lib, s) is not None
+    # the test-hooks header: declared there, exported by the test build (what this suite loads), absent from the product (tests/test_product_library.py)
+    hooks = open(os.path.join(ROOT, "include", "limg_hip_test_hooks.h")).read()
+    inline = set(re.findall(r"static inline \w+ (limg_hip_[a-z0-9_]+)\s*\(", hooks))
+    declared = set(re.findall(r"\b(limg_hip_[a-z0-9_]+)\s*\(", hooks)) - inline
+    assert declared == set(limg_amd.TEST_ABI_SYMBOLS), declared ^ set(limg_amd.TEST_ABI_SYMBOLS)
     for s in declared:
         assert getattr(lib, s) is not None
     assert lib.limg_hip_version().decode().startswith("limg_hip")

@@ -30,7 +30,21 @@ CASES = {
     "rg4096_pool2": ("rg", 4096, 4096, 1, {"pool_threads": 2}),
     "pn16384x2048": ("pn", 16384, 2048, 1, {}),                            # strip 0 of BASELINE config 5 (rows 0..2047 of the 16384^2 image)
     "pn16384x2048_pool2": ("pn", 16384, 2048, 1, {"pool_threads": 2}),
+    # round 6: config 3 IS the sweep -- the rest of its adaptive settings whole (ef 25 / 100 above), and the accurate search (src/limg_bit_crush.h:668-830:
+    # the persistent kernel's ACC template, 4 ms launches with their own look-back timing) at both bench sizes
+    "pn8192_ef0": ("pn", 8192, 8192, 1, {"error_factor": 0}),
+    "pn8192_ef50": ("pn", 8192, 8192, 1, {"error_factor": 50}),
+    "pn8192_ef200": ("pn", 8192, 8192, 1, {"error_factor": 200}),
+    "pn8192_ef400": ("pn", 8192, 8192, 1, {"error_factor": 400}),
+    "pn8192_accurate": ("pn", 8192, 8192, 1, {"fast": False}),
+    "rg4096_accurate": ("rg", 4096, 4096, 1, {"fast": False}),
 }
+# config 3's forced-shift half (bits = 8 .. 2 on all three factors = shift 0 .. 6): the planes that depend on the shift, from the reference's own block functions with
+# the search left out (oracle/ref_harness.cpp ref_encode3d_forced_shift; upstream has no such switch).  The six colour planes must equal those of "pn8192".
+FORCED = {"pn8192_forced%d" % s: ("pn", 8192, 8192, 1, (s, s, s)) for s in range(7)}
+# config 4: the batch of 64 x 4096^2 random-gradient images, seeds 1 .. 64 (image i of the batch = seed 1 + i): per image the position-sensitive sum64 pair of every
+# plane (what bench.py --config 4 --verify-golden and the GPU suite compute on the device) + the PSNR
+BATCH = {"rg4096_batch64": ("rg", 4096, 4096, list(range(1, 65)), {})}
 # BASELINE config 5 whole (16384^2 photo-noise), hashed PER STRIP of 2048 rows (the 8 strips of src/limg.cpp:2114-2134 for a pool of 2 threads = what the ranks of a
 # multi-GPU job hold): with one chain through all strips (pThreadPool == nullptr) and with the chain restarted per strip (pool of 2).  A rank -- whatever the world
 # size that divides 8 -- can check the rows it produced without the other ranks' planes.
@@ -80,6 +94,32 @@ def main():
         print(name, "%.4f dB" % psnr, "%.1f s" % (time.time() - t0), flush=True)
         del r, img
         json.dump(out, open(OUT, "w"), indent=1)
+    for name, (gen, w, h, seed, shift) in FORCED.items():
+        if args.only is not None and name not in args.only:
+            continue
+        t0 = time.time()
+        img = make_input(orc, gen, w, h, seed)
+        r = ref.encode3d_forced_shift(img, True, shift)
+        psnr, mse = ref.compare(img, r["pDecoded"], True)
+        out[name] = {"kind": "forced", "gen": gen, "w": w, "h": h, "seed": seed, "alpha": True, "shift": list(shift), "colour_planes_of": "pn8192", "input": orc.fnv(img),
+                     "psnr": psnr, "mse": mse, "planes": {k: orc.fnv(r[k]) for k in r}}
+        print(name, "%.4f dB" % psnr, "%.1f s" % (time.time() - t0), flush=True)
+        del r, img
+        json.dump(out, open(OUT, "w"), indent=1)
+    for name, (gen, w, h, seeds, kw) in BATCH.items():
+        if args.only is not None and name not in args.only:
+            continue
+        images = out.get(name, {}).get("images", [])
+        for seed in seeds[len(images):]:
+            t0 = time.time()
+            img = make_input(orc, gen, w, h, seed)
+            r = ref.encode3d(img, True, **kw)
+            psnr, mse = ref.compare(img, r["pDecoded"], True)
+            images.append({"seed": seed, "input_sum64": sum64(img), "psnr": psnr, "mse": mse, "sum64": {k: sum64(r[k]) for k in PLANES}})
+            out[name] = {"kind": "batch", "gen": gen, "w": w, "h": h, "alpha": True, "kw": kw, "images": images}
+            print(name, seed, "%.4f dB" % psnr, "%.1f s" % (time.time() - t0), flush=True)
+            del r, img
+            json.dump(out, open(OUT, "w"), indent=1)
     for name, (gen, w, h, seed, kw) in STRIPPED.items():
         if args.only is not None and name not in args.only:
             continue
