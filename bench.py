@@ -501,23 +501,7 @@ def run_sharded(args, g, dist, rank, world):
         emit(line)
 
 
-def sum64_device(t):
-    """[sum e_i, sum (i + 1) e_i] over the tensor's elements (uint32 words / bytes) as unsigned 64-bit wrap-around sums: the parallel checksum
-    tools/make_golden_fullsize.py records per strip next to the FNV hashes (computed there from the real reference's planes with numpy)."""
-    import torch
-    v = t.reshape(-1)
-    if v.dtype == torch.int32:
-        v = v.to(torch.int64) & 0xFFFFFFFF
-    else:
-        v = v.to(torch.int64)
-    s1 = int(v.sum().item()) & 0xFFFFFFFFFFFFFFFF
-    s2 = 0
-    step = 1 << 24  # in pieces: the int64 temporaries of a 16384 x 2048 plane stay small
-    for o in range(0, v.numel(), step):
-        part = v[o:o + step]
-        idx = torch.arange(o + 1, o + 1 + part.numel(), dtype=torch.int64, device=v.device)
-        s2 = (s2 + int((part * idx).sum().item())) & 0xFFFFFFFFFFFFFFFF
-    return [s1, s2]
+from limg_amd.shard import sum64_device  # noqa: E402  (the parallel checksum of tests/golden/fullsize.json, computed on the device)
 
 
 def verify_golden(args, units, rows, rank, world, dist, single_chain, W, H, kind):

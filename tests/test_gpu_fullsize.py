@@ -51,6 +51,71 @@ def test_encode3d_reference_hashes(gpu, oracle, name):
     torch.cuda.empty_cache()
 
 
+PATTERN = (0, 0x22, 0x44, 0x66, 0x88, 0xAA, 0xCC, 0xEE, 0xFF)  # src/limg.cpp:2006: what pShiftABCX shows for a shift
+
+
+@pytest.mark.parametrize("name", sorted(k for k, e in GOLD.items() if e["kind"] == "forced"))
+def test_forced_shift_reference_hashes(gpu, oracle, name):
+    """BASELINE config 3's forced-shift half WHOLE (8192^2, bits 8 .. 2 on all three factors): the planes that depend on the shift against the reference's own block
+    functions run with the search left out (oracle/ref_harness.cpp ref_encode3d_forced_shift: upstream has no such switch); the six colour planes against the
+    adaptive encode of the same image (they do not depend on the shift); pShiftABCX is one constant."""
+    import torch
+    e = GOLD[name]
+    base = GOLD[e["colour_planes_of"]]
+    img = gpu.synth_device(KIND[e["gen"]], e["w"], e["h"], seed=e["seed"])
+    assert oracle.fnv(_host(img)) == e["input"] == base["input"]
+    planes = gpu.alloc_planes_device(e["w"], e["h"])
+    gpu.set_options(forced_shift=tuple(e["shift"]))
+    try:
+        gpu.encode3d_device(img, e["alpha"], planes)
+        torch.cuda.synchronize()
+        gpu.check()
+    finally:
+        gpu.set_options()
+    bad = [k for k in e["planes"] if oracle.fnv(_host(planes[k])) != e["planes"][k]]
+    bad += [k for k in PLANES if k.startswith("pCol") and oracle.fnv(_host(planes[k])) != base["planes"][k]]
+    assert not bad, (name, bad)
+    a, b, c = e["shift"]
+    word = 0xFF000000 | PATTERN[a] << 16 | PATTERN[b] << 8 | PATTERN[c]
+    assert bool((planes["pShiftABCX"] == (word - (1 << 32))).all())
+    psnr, mse = gpu.compare_device(img, planes["pDecoded"], e["alpha"])
+    assert psnr == pytest.approx(e["psnr"], abs=1e-9) and mse == pytest.approx(e["mse"], rel=1e-12)
+    del planes, img
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("name", sorted(k for k, e in GOLD.items() if e["kind"] == "batch"))
+def test_batch_reference_checksums(gpu, name):
+    """BASELINE config 4 WHOLE as one GPU's context sees it: all 64 images (4096^2 random-gradient, seeds 1 .. 64) through ONE limg_hip_encode3d_batch_device call
+    (the sub-batch pipeline: k_fit_tpb of sub-batch k + 1 beside the persistent kernel of sub-batch k), every plane of every image against the real reference's
+    position-sensitive checksums, computed on the device; then the first eight one by one through limg_hip_encode3d_device (the rank of an 8-GPU job: 8 images)."""
+    import torch
+    from limg_amd.shard import sum64_device
+    e = GOLD[name]
+    W, H = e["w"], e["h"]
+    imgs = [gpu.synth_device(KIND[e["gen"]], W, H, seed=im["seed"]) for im in e["images"]]
+    for im, t in zip(e["images"], imgs):
+        assert sum64_device(t) == im["input_sum64"], ("input", im["seed"])
+    outs = [gpu.alloc_planes_device(W, H) for _ in imgs]
+    gpu.encode3d_batch_device(imgs, e["alpha"], outs, **e["kw"])
+    torch.cuda.synchronize()
+    gpu.check()
+    bad = [(im["seed"], k) for im, pl in zip(e["images"], outs) for k in PLANES if sum64_device(pl[k]) != im["sum64"][k]]
+    assert not bad, bad[:8]
+    for im, t, pl in zip(e["images"][:8], imgs, outs):
+        psnr, mse = gpu.compare_device(t, pl["pDecoded"], e["alpha"])
+        assert psnr == pytest.approx(im["psnr"], abs=1e-9) and mse == pytest.approx(im["mse"], rel=1e-12), im["seed"]
+    one = gpu.alloc_planes_device(W, H)
+    for im, t in list(zip(e["images"], imgs))[:8]:
+        gpu.encode3d_device(t, e["alpha"], one, **e["kw"])
+        torch.cuda.synchronize()
+        bad = [k for k in PLANES if sum64_device(one[k]) != im["sum64"][k]]
+        assert not bad, (im["seed"], bad)
+    gpu.check()
+    del imgs, outs, one
+    torch.cuda.empty_cache()
+
+
 def test_one_strip_base_error_is_caught(gpu, oracle):
     """Sensitivity of the pin: ONE work strip (of 32 768) that dithers from a chain position off by one call -- the smallest error a look-back can make
     (limg_hip_options.test_base_error_strip) -- changes the hashes of the chain-dependent planes, while everything a band-limited check looks at (the first 256

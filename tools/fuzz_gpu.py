@@ -11,6 +11,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("LIMG_HIP_LIB", "test")  # the options this sweep randomises include hooks of the test build (include/limg_hip_test_hooks.h); LIMG_HIP_LIB=<path> to fuzz the product
 
 
 def main():

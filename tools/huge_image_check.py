@@ -4,11 +4,13 @@ run of the whole image: (1) status clean, PSNR of the generator; (2) the first 6
 64-row band equal the oracle on the chain-independent planes; (4) strip-restart encode (pool of 2 = 8 strips): strips 0 and 7 equal their standalone encodes on every plane
 (strip 7 lies behind the 4 GiB offset in every 32-bit plane); (5) N x (N - 2), a partial last block row ~50 M calls into the chain: the fast path (the chain value there from
 the far checkpoints + at most 65535 calls on foot) equals the whole-image ragged path (host walk over every call) on every plane; (6) the compact stream's round trip.  usage: python tools/huge_image_check.py [N]"""
+import os
 import sys
 import time
 sys.path.insert(0, '.')
 import numpy as np
 import torch
+os.environ.setdefault("LIMG_HIP_LIB", "test")  # property (5) uses a hook of the test build
 import limg_amd
 from oracle.bind import Oracle, PLANES
 
