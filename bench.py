@@ -733,6 +733,115 @@ def run_stream(args, g, dist, rank, world, W, H):
         emit(line)
 
 
+def other_workloads(g, dev, args):
+    """One driver-timed entry for every BASELINE config besides the headline (the `--gpus 1` line is the only independent clock this project gets).
+    Each: {ms, Mpixels_per_s, frac, verified}; `verified` = every plane the leg wrote equals the REAL reference's (position-sensitive sum64 checksums of
+    tests/golden/fullsize.json, computed on the device after the timed loop); a leg that raises or does not verify is a failed leg (non-zero exit).
+    frac = the leg's algorithmic bytes / (wall time per step) / 8 TB/s -- wall clock around the enqueue + one synchronize, like `value` (not kernel-only)."""
+    import torch
+    import limg_amd
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize.json")))
+    out = {}
+
+    def wall(fn, warm, reps):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3 / reps
+
+    def entry(ms, px, bytes_per_px, verified, **more):
+        e = {"ms": round(ms, 4), "Mpixels_per_s": round(px / ms / 1e3, 1), "frac": round(bytes_per_px * px / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "verified": bool(verified)}
+        e.update(more)
+        if not verified:
+            raise RuntimeError("planes differ from the real reference's checksums: %s" % (more.get("mismatch"),))
+        return e
+
+    def check(planes, want, names):
+        return [k for k in names if sum64_device(planes[k]) != want[k]]
+
+    def leg(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:  # noqa: BLE001
+            out[name] = leg_failed("other_workloads." + name, e)
+        torch.cuda.empty_cache()
+
+    def config2():  # BASELINE configs[1]: one 4096^2 random-gradient image
+        e = gold["rg4096_batch64"]["images"][0]
+        img = g.synth_device("random_gradient", 4096, 4096, seed=1)
+        planes = g.alloc_planes_device(4096, 4096)
+        ms = wall(lambda: g.encode3d_device(img, True, planes), 3, 20)
+        g.check()
+        bad = check(planes, e["sum64"], limg_amd.PLANES)
+        return entry(ms, 4096 * 4096, ALGO_BYTES_PER_PX, not bad, mismatch=bad, workload="4096x4096 RGBA random_gradient seed 1, one image per call", golden="rg4096_batch64[0]")
+
+    def config4():  # BASELINE configs[3] as one GPU holds it: all 64 images through ONE limg_hip_encode3d_batch_device call (the sub-batch pipeline)
+        e = gold["rg4096_batch64"]
+        imgs = [g.synth_device("random_gradient", 4096, 4096, seed=im["seed"]) for im in e["images"]]
+        outs = [g.alloc_planes_device(4096, 4096) for _ in imgs]
+        ms = wall(lambda: g.encode3d_batch_device(imgs, True, outs), 1, 3)
+        g.check()
+        bad = [(im["seed"], k) for im, pl in zip(e["images"], outs) for k in check(pl, im["sum64"], limg_amd.PLANES)]
+        return entry(ms, len(imgs) * 4096 * 4096, ALGO_BYTES_PER_PX, not bad, mismatch=bad[:6], workload="64 x 4096x4096 RGBA random_gradient seeds 1..64, one batched call",
+                     golden="rg4096_batch64 (all 64 images x 11 planes)")
+
+    def config5(pool):  # BASELINE configs[4] as one of 8 GPUs sees it: its 16384 x 2048 strip (rows 0..2047), one chain / the reference's pool of 2 = 8 chains
+        name = "pn16384x2048" + ("_pool2" if pool else "")
+        e = gold[name]
+        img = g.synth_device("photo_noise", 16384, 2048, seed=1)
+        planes = g.alloc_planes_device(16384, 2048)
+        ms = wall(lambda: g.encode3d_device(img, True, planes, pool_threads=pool), 3, 20)
+        g.check()
+        bad = check(planes, e["sum64"], limg_amd.PLANES)
+        return entry(ms, 16384 * 2048, ALGO_BYTES_PER_PX, not bad, mismatch=bad, workload="16384x2048 RGBA photo_noise seed 1 (strip 0 of the 16384^2 image), poolThreads %d" % pool, golden=name)
+
+    def stream():  # limg_encode / limg_decode: the headline image to the compact stream and back
+        e = gold["pn8192"]
+        img = g.synth_device("photo_noise", 8192, 8192, seed=1)
+        st, nbytes = g.encode_stream_device(img, True)
+        dec = g.decode_stream_device(st, nbytes, 8192, 8192)
+        enc_ms = wall(lambda: g.encode_stream_device(img, True, out=st, want_size=False), 2, 10)
+        g.profile_begin()
+        g.encode_stream_device(img, True, out=st, want_size=False)
+        torch.cuda.synchronize()
+        k = g.profile_end(2)
+        dec_ms = wall(lambda: g.decode_stream_device(st, nbytes, 8192, 8192, out=dec), 2, 20)
+        g.check()
+        bad = check({"pDecoded": dec}, e["sum64"], ("pDecoded",))
+        px = 8192 * 8192
+        return entry(enc_ms, px, 4 + nbytes / px, not bad, mismatch=bad, workload="8192x8192 RGBA photo_noise seed 1 -> LMG3 stream -> pDecoded", golden="pn8192.pDecoded (decode(encode) against the reference)",
+                     stream_bytes=int(nbytes), pack_ms=None if len(k) < 2 else round(float(k[1, 0]), 4), decode_ms=round(dec_ms, 4), decode_Mpixels_per_s=round(px / dec_ms / 1e3, 1),
+                     decode_frac=round((nbytes + 4 * px) / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                     note="ms / Mpixels_per_s / frac = encode to the stream (k_fit_tpb + persistent kernel with compact outputs + the packer; 4 B/px read + the stream written); decode_* = k_stream_decode")
+
+    def blocked():  # limg_blocked_encode3d_test: what the reference's CLI runs on a single file (src/main.cpp:255)
+        e = gold["blocked_pn8192"]
+        img = g.synth_device("photo_noise", 8192, 8192, seed=1)
+        planes = g.alloc_blocked_planes_device(8192, 8192)
+        ms = wall(lambda: g.blocked_encode3d_device(img, True, planes), 1, 4)
+        g.check()
+        names = [k for k, _ in limg_amd.BLOCKED_PLANES if k != "pBlockError"]
+        bad = check(planes, e["sum64"], names)
+        if len(g.blocked_regions()) != e["regions"]:
+            bad.append("rectangle count")
+        return entry(ms, 8192 * 8192, BLOCKED_BYTES_PER_PIXEL, not bad, mismatch=bad, workload="8192x8192 RGBA photo_noise seed 1, merged-block encoder, host stages included", golden="blocked_pn8192 (13 planes + rectangle count)",
+                     rectangles=e["regions"])
+
+    t0 = time.perf_counter()
+    leg("config2_rg4096", config2)
+    leg("config4_batch64_rg4096", config4)
+    leg("config5_strip_pool0", lambda: config5(0))
+    leg("config5_strip_pool2", lambda: config5(2))
+    leg("stream_pn8192", stream)
+    leg("blocked_pn8192", blocked)
+    out["seconds"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
 def limg_planes():
     import limg_amd
     return limg_amd.PLANES
@@ -774,6 +883,7 @@ def main():
     ap.add_argument("--workload", default="photo_noise", choices=["photo_noise", "random_gradient"])
     ap.add_argument("--error-factor", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--other-workloads", action="store_true", help="add config.other_workloads (one verified entry per BASELINE config) to a non-default line too")
     ap.add_argument("--no-host-rate", action="store_true", help="skip the PCIe-inclusive timing of the host-pointer entry (config.host_entry)")
     ap.add_argument("--split", action="store_true", help="three-launch path instead of the fused kernel")
     ap.add_argument("--compact", action="store_true", help="compact mode: factor planes + records + shift words only (8.05 B/px)")
@@ -1057,6 +1167,22 @@ def main():
                 line["config"]["host_entry"] = host_entry_rate(g, W, H, args)
             except Exception as e:
                 line["config"]["host_entry"] = leg_failed("host_entry", e)
+        default_line = (n_gpus == 1 and not args.no_host_rate and (W, H) == (8192, 8192) and args.workload == "photo_noise" and args.error_factor == 100 and args.pool_threads == 0 and
+                        args.float_mode == "exact" and not (args.split or args.compact or args.accurate or args.rgb or args.graph or args.legacy_float_stage or args.forced_shift >= 0))
+        if default_line or args.other_workloads:
+            # the headline image itself against the real reference, then every other BASELINE config once (never part of `value`)
+            try:
+                gold = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize.json")))["pn8192"]
+                bad = [k for k in limg_amd.PLANES if sum64_device(planes[k]) != gold["sum64"][k]] if default_line else None
+                line["config"]["verified"] = None if bad is None else not bad
+                if bad:
+                    raise RuntimeError("the headline encode's planes differ from the real reference's checksums: %s" % bad)
+            except Exception as e:
+                line["config"]["verified"] = False
+                leg_failed("verify_headline", e)
+            del planes, img
+            torch.cuda.empty_cache()
+            line["config"]["other_workloads"] = other_workloads(g, dev, args)
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(W, 1, height=H)

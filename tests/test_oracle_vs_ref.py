@@ -113,3 +113,17 @@ def test_compare(oracle, ref):
     b = oracle.photo_noise(64, 32, seed=2)
     for alpha in (True, False):
         assert ref.compare(a, b, alpha) == oracle.compare(a, b, alpha)
+
+
+@pytest.mark.parametrize("shape", [(256, 128, True), (250, 131, True), (200, 77, False), (13, 9, True)])
+def test_forced_shift_composition(oracle, ref, shape):
+    """BASELINE config 3's forced-shift sweep has no switch upstream; oracle/ref_harness.cpp's ref_encode3d_forced_shift drives the reference's own block functions
+    in limg_encode3d_test's order with the search left out (what tests/golden/fullsize.json's pn8192_forced* entries were made with).  The oracle's forced_shift
+    option must give the same shift-dependent planes, ragged shapes and 3-channel input included."""
+    w, h, alpha = shape
+    img = oracle.photo_noise(w, h, 3)
+    for s in ((0, 0, 0), (1, 1, 1), (3, 3, 3), (6, 6, 6), (7, 7, 7), (8, 8, 8), (2, 5, 8), (8, 0, 4)):
+        a = oracle.encode3d(img, alpha, forced_shift=s)
+        b = ref.encode3d_forced_shift(img, alpha, s)
+        for k in b:
+            assert np.array_equal(a[k], b[k]), (shape, s, k)

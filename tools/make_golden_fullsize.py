@@ -90,7 +90,7 @@ def main():
         r = ref.encode3d(img, True, **kw)
         psnr, mse = ref.compare(img, r["pDecoded"], True)
         out[name] = {"kind": "encode3d", "gen": gen, "w": w, "h": h, "seed": seed, "alpha": True, "kw": kw, "input": orc.fnv(img), "psnr": psnr, "mse": mse,
-                     "planes": {k: orc.fnv(r[k]) for k in PLANES}}
+                     "planes": {k: orc.fnv(r[k]) for k in PLANES}, "sum64": {k: sum64(r[k]) for k in PLANES}}
         print(name, "%.4f dB" % psnr, "%.1f s" % (time.time() - t0), flush=True)
         del r, img
         json.dump(out, open(OUT, "w"), indent=1)
@@ -142,7 +142,8 @@ def main():
         r = ref.blocked_encode3d(img, True)
         psnr, mse = ref.compare(img, r["pDecoded"], True)
         out[name] = {"kind": "blocked", "gen": gen, "w": n, "h": n, "seed": seed, "alpha": True, "kw": {}, "input": orc.fnv(img), "psnr": psnr, "mse": mse,
-                     "regions": int(r["pBlockIndex"].max() & 0xFFFFFF), "planes": {k: orc.fnv(r[k]) for k in BLOCKED_WRITTEN}}
+                     "regions": int(r["pBlockIndex"].max() & 0xFFFFFF), "planes": {k: orc.fnv(r[k]) for k in BLOCKED_WRITTEN},
+                     "sum64": {k: sum64(r[k]) for k in BLOCKED_WRITTEN}}
         print(name, out[name]["regions"], "%.4f dB" % psnr, "%.1f s" % (time.time() - t0), flush=True)
         del r, img
         json.dump(out, open(OUT, "w"), indent=1)
