@@ -151,7 +151,7 @@ struct limg_hip_context
   int chainAlpha = 0, chainFast = 0;
   uint32_t chainEf = 0;
   DevBuf commWords; // [0] this rank's value, [1] its chain base, [8 ...] the all-gathered values
-  DevBuf streamFac, streamTiles, streamStatus, streamBuf; // stream packer: 3 factor planes, per-tile payload words; decode status word; host-entry staging
+  DevBuf streamFac, streamTiles, streamUnits, streamStatus, streamBuf; // stream packer: 3 factor planes, per-tile payload words; decode status word; host-entry staging
   // optional per-kernel timing (bench): 4 events per encode, recorded on the caller's stream, read back in one go
   int persistentWorkgroups = 1280; // 5 x the device's CU count (set at init): the unit the launches scale (x 6 / 5 with the float stage in its own kernel)
   bool forceSplit = false; // options: run the three-kernel path even where the fused kernel applies (A/B, tests)
@@ -387,6 +387,7 @@ namespace
   struct EncodeExtra
   {
     bool streamRaw = false, fitOnly = false;
+    uint32_t *stripWords = nullptr; // stream mode, images of whole blocks: per work strip the payload words of its blocks (EncodeParams::stripWords)
     int chainPhase = 0; // 0 = whole encode; 1 = E step + scan only (writes *dChainCalls); 2 = F step only (reads *dChainBase).  1 and 2 always take the split path.
     unsigned long long *dChainCalls = nullptr;
     const unsigned long long *dChainBase = nullptr;
@@ -524,6 +525,7 @@ namespace
     p.storePlanes = dInfo != nullptr;
     p.fullPlanes = fullPlanes;
     p.streamRaw = x.streamRaw && !fullPlanes;
+    p.stripWords = (x.streamRaw && !fullPlanes) ? x.stripWords : nullptr;
     p.fitOnly = x.fitOnly && !dInfo;
     if (dInfo) p.io.info = *dInfo;
     // 16-byte vector access straight on caller pointers only where the address is 16-byte aligned for every row: sliced or offset
@@ -1021,7 +1023,7 @@ extern "C"
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     DevBuf *bufs[] = { &c->noiseStates, &c->invN, &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->noiseCk, &c->stats, &c->lookback, &c->devStatus, &c->accTable, &c->commWords, &c->park, &c->batchTable, &c->in, &c->planes, &c->cmp,
-                       &c->streamFac, &c->streamTiles, &c->streamStatus, &c->streamBuf,
+                       &c->streamFac, &c->streamTiles, &c->streamUnits, &c->streamStatus, &c->streamBuf,
                        &c->bFlags, &c->bBound, &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bFac, &c->bNoise, &c->bNoiseBase };
     for (DevBuf *b : bufs) b->release();
     HostBuf *hbufs[] = { &c->hFlags, &c->hRec, &c->hBits, &c->hDesc, &c->hOut, &c->hNoise, &c->hNoiseBase };
@@ -1205,7 +1207,7 @@ extern "C"
   {
     if (!c) return 0;
     const DevBuf *bufs[] = { &c->bCalls, &c->noiseStates, &c->records, &c->shifts, &c->invN, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->noiseCk, &c->lookback, &c->park, &c->batchTable, &c->stats,
-                             &c->accTable, &c->devStatus, &c->commWords, &c->in, &c->planes, &c->cmp, &c->streamFac, &c->streamTiles, &c->streamStatus, &c->streamBuf,
+                             &c->accTable, &c->devStatus, &c->commWords, &c->in, &c->planes, &c->cmp, &c->streamFac, &c->streamTiles, &c->streamUnits, &c->streamStatus, &c->streamBuf,
                              &c->bFlags, &c->bBound, &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bFac, &c->bNoise, &c->bNoiseBase };
     size_t sum = 0;
     for (const DevBuf *b : bufs) sum += b->cap;
@@ -1425,7 +1427,11 @@ extern "C"
     const size_t tiles = (blocks + 255) / 256;
     limg_hip_result r;
     if ((r = c->streamFac.ensure(planeStride * 3)) != limg_hip_success) return r;
+    // strip form of the packer (images of whole blocks): the encode kernel leaves one payload-word count per work strip (limg_hip_stream.hip)
+    const size_t stripsX = (blocksX + kStripBlocks - 1) / kStripBlocks, nStrips = stripsX * blocksY;
+    const bool stripForm = (sizeX % kBlock) == 0 && (sizeY % kBlock) == 0 && !c->forceSplit;
     if ((r = c->streamTiles.ensure(tiles * 4)) != limg_hip_success) return r;
+    if (stripForm && (r = c->streamUnits.ensure(nStrips * 4)) != limg_hip_success) return r;
     if ((r = c->records.ensure(blocks * sizeof(limg_hip_block_record))) != limg_hip_success) return r;
     if ((r = c->shifts.ensure(blocks * 4)) != limg_hip_success) return r;
     limg_hip_encode3d_info info;
@@ -1434,6 +1440,7 @@ extern "C"
     limg_hip_compact_out comp = { (limg_hip_block_record *)c->records.p, (uint32_t *)c->shifts.p };
     EncodeExtra xs;
     xs.streamRaw = true;
+    xs.stripWords = stripForm ? (uint32_t *)c->streamUnits.p : nullptr;
     if ((r = encode_device(c, pIn, sizeX, sizeY, hasAlpha, &info, &comp, errorFactor, poolThreads, fastBitCrushing, s, xs)) != limg_hip_success) return r;
 
     StreamParams sp;
@@ -1444,6 +1451,13 @@ extern "C"
     sp.fac[0] = info.pFactorsA; sp.fac[1] = info.pFactorsB; sp.fac[2] = info.pFactorsC;
     sp.records = comp.pRecords; sp.shifts = comp.pShifts;
     sp.stream = pStream; sp.tileBase = (uint32_t *)c->streamTiles.p;
+    if (stripForm)
+    {
+      sp.stripWords = (uint32_t *)c->streamUnits.p;
+      sp.stripsX = (uint32_t)stripsX; sp.nStrips = (uint32_t)nStrips;
+      const size_t slots = (size_t)(c->persistentWorkgroups / 5) * 20; // 20 one-wave workgroups per CU (7.75 KiB of LDS each)
+      sp.nWaves = (uint32_t)(nStrips < slots ? nStrips : slots);
+    }
     mark(c, s);
     launch_stream_pack(sp, s);
     mark(c, s); mark(c, s); mark(c, s);

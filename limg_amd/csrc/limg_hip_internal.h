@@ -49,6 +49,7 @@ namespace limg_hip
     uint32_t *shifts;      // per block: sA | sB<<8 | sC<<16 | calls<<24
     uint32_t *stripCalls;  // per work strip: number of dither calls (blocksY * stripsX, raster order)
     uint32_t *stripBase;   // per work strip: index of its first dither call inside its chain (exclusive scan)
+    uint32_t *stripWords;  // stream mode (or NULL): per work strip the payload words of its blocks in the compact stream -- what the packer's scan starts from
     // (split path: the pre-dither factor bytes live in the caller's factor planes between the two kernels)
     int32_t storePlanes;   // 0: _perf behaviour
     int32_t fullPlanes;    // 0: compact mode -- only the three factor planes (+ records / shift words) are written
@@ -90,7 +91,11 @@ namespace limg_hip
     const limg_hip_block_record *records;
     const uint32_t *shifts;
     uint8_t *stream;
-    uint32_t *tileBase; // per tile of 256 blocks: payload words, then (after the scan) the tile's first payload word
+    uint32_t *tileBase; // three-kernel form (widths that are not whole blocks): per tile of 256 blocks payload words, then (after the scan) the tile's first payload word
+    // strip form (widths in whole blocks): the encode kernel leaves every work strip's payload words (EncodeParams::stripWords); k_stream_scan_strips turns them into
+    // the strips' first payload words in place and writes the header; k_stream_pack_strips packs one strip (<= 32 consecutive blocks of one block row) per wave step
+    uint32_t *stripWords;
+    uint32_t stripsX, nStrips, nWaves;
   };
 
   struct DecodeParams

@@ -1509,6 +1509,19 @@ namespace limg_hip
         // a shift of 1..7 dithers (one call), 0 and 8 do not; as scalar arithmetic -- ((s & 7) + 7) >> 3 -- because a boolean would go through a lane mask and a vector select
         const uint32_t calls = (((shift[0] & 7u) + 7u) >> 3) + (((shift[1] & 7u) + 7u) >> 3) + (((shift[2] & 7u) + 7u) >> 3);
         waveCalls += calls;
+        if (p.stripWords)
+        { // stream mode: the block's payload size in 8-byte words rides in bits 8.. of the same per-wave counter (calls of a strip stay below 256): a field of 8 - shift
+          // bits per pixel is that many words; a factor at shift 8 has none unless its alpha normal is non-zero (raw-byte escape, limg_hip_stream.hip)
+          uint32_t words = 0;
+#pragma unroll
+          for (int k = 0; k < 3; k++)
+          {
+            const uint32_t sk = shift[k];
+            if (sk < 8u) words += 8u - sk;
+            else if (CH == 4 && sgpr((int)blkE->rec[8 * k + 3]) != sgpr((int)blkE->rec[8 * k + 7])) words += 8u;
+          }
+          waveCalls += words << 8;
+        }
 
         const size_t bi = (size_t)byS * p.blocksX + bx;
         const uint32_t word = shift[0] | (shift[1] << 8) | (shift[2] << 16) | (calls << 24);
@@ -1528,7 +1541,9 @@ namespace limg_hip
       __syncthreads();
       if (tid == 0)
       {
-        const uint32_t agg = s_calls[0] + s_calls[1] + s_calls[2] + s_calls[3];
+        const uint32_t aggAll = s_calls[0] + s_calls[1] + s_calls[2] + s_calls[3];
+        const uint32_t agg = aggAll & 0xFFu; // (bits 8..: the strip's payload words, stream mode)
+        if (p.stripWords) p.stripWords[id] = aggAll >> 8;
         if (PERSIST)
         { // publish the count; if the predecessor's inclusive count is already there, publish ours as inclusive right away
           uint32_t headId = head0;

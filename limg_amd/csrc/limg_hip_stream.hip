@@ -236,6 +236,195 @@ namespace limg_hip
       }
     }
 
+
+    // ---- pack, strip form (round 6) -------------------------------------------------------------------------------------------
+    // The three kernels above read the records twice and the shift words twice (64 MiB of records for a count), pack with lane = (block, row) on 64-byte row segments, do
+    // the bit packing in 64-bit arithmetic pixel by pixel and store bytes into LDS one at a time.  For images of whole blocks the job is now:
+    //  * nothing to count: the encode kernel's E step, which has every block's shifts in scalar registers, leaves the payload words of each of its work strips
+    //    (<= 32 consecutive blocks of one block row) in EncodeParams::stripWords -- one more add into the counter it keeps for the dither calls;
+    //  * k_stream_scan_strips: exclusive prefix over the strips in place (one workgroup, 8 strips per thread and round) + the header;
+    //  * k_stream_pack_strips: persistent one-wave workgroups striding over the strips; no dependence between strips, so no ticket and no look-back.  lane = (block j
+    //    = lane & 31, row half h = lane >> 5): a (plane, row) of the strip is 256 contiguous bytes, all 12 row loads of a lane are in flight before the first is
+    //    used, and the NEXT strip's shift words and records are requested before this strip's rows are waited for.  A row's 8 values of b bits are squeezed with three
+    //    mask-and-shift steps per dword (4 pixels at a time); the four rows of a lane are 4 b bytes = b dwords, appended to a 64-bit accumulator and flushed to the
+    //    wave's LDS run a dword at a time (the two halves of a block own disjoint dwords); the run -- the strip's contiguous payload -- and the 32 entries leave with
+    //    512-byte stores.
+    // (A one-launch form with a decoupled look-back over per-unit totals was built first and measured: 0.27 ms -- at start-up every wave in flight walks back through
+    // all its predecessors, 64 descriptors per round trip -- against 0.131 ms for the three kernels; `tools/r06/` keeps the numbers.)
+    // Widths or heights that are not whole blocks keep the three-kernel form (byte gathers at the edges).
+    __global__ __launch_bounds__(1024) void k_stream_scan_strips(const StreamParams p)
+    {
+      __shared__ unsigned long long sWave[16];
+      __shared__ unsigned long long sCarry;
+      const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+      if (tid == 0) sCarry = 0;
+      __syncthreads();
+      for (uint32_t base = 0; base < p.nStrips; base += 8192)
+      {
+        const uint32_t i0 = base + (uint32_t)tid * 8u;
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = i0 + k < p.nStrips ? p.stripWords[i0 + k] : 0u;
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) mine += v[k];
+        unsigned long long incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1)
+        {
+          const unsigned long long up = (unsigned long long)__shfl_up((long long)incl, off, 64);
+          if (lane >= off) incl += up;
+        }
+        if (lane == 63) sWave[wave] = incl;
+        __syncthreads();
+        unsigned long long pre = sCarry;
+        for (int w = 0; w < wave; w++) pre += sWave[w];
+        unsigned long long run = pre + incl - mine; // entry.payloadWord is 32 bits: the host refuses images whose worst-case payload would not fit (limg_hip_stream_bound)
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+        {
+          if (i0 + k < p.nStrips) p.stripWords[i0 + k] = (uint32_t)run;
+          run += v[k];
+        }
+        __syncthreads();
+        if (tid == 1023) sCarry = pre + incl;
+        __syncthreads();
+      }
+      if (tid == 0)
+      {
+        limg_hip_stream_header h;
+        h.magic = LIMG_HIP_STREAM_MAGIC; h.version = LIMG_HIP_STREAM_VERSION;
+        h.sizeX = p.sizeX; h.sizeY = p.sizeY; h.channels = p.channels; h.errorFactor = p.errorFactor;
+        h.blocksX = p.blocksX; h.blocksY = p.blocksY;
+        h.payloadWords = sCarry;
+        h.totalBytes = sizeof(limg_hip_stream_header) + (unsigned long long)p.nBlocks * kEntry + sCarry * 8ull;
+        h.flags = p.flags; h.reserved[0] = h.reserved[1] = h.reserved[2] = 0;
+        *reinterpret_cast<limg_hip_stream_header *>(p.stream) = h;
+      }
+    }
+
+    // 8 bytes (lo = pixels 0..3, hi = 4..7), each holding its value in the TOP b bits (sh = 8 - b; raw-escaped fields: b = 8) -> the 8 values in 8 b consecutive bits
+    __device__ __forceinline__ unsigned long long squeeze_row(uint32_t lo, uint32_t hi, uint32_t sh, uint32_t b, uint32_t m4, uint32_t mPair)
+    {
+      uint32_t z[2];
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+      {
+        const uint32_t x = ((h ? hi : lo) >> sh) & m4;                       // v0 | v1 << 8 | v2 << 16 | v3 << 24
+        const uint32_t y = ((x >> sh) & mPair) | (x & 0x00FF00FFu);           // v0 | v1 << b in the low half, v2 | v3 << b in the high half
+        z[h] = (y & 0xFFFFu) | ((y >> 16) << (2u * b));                      // 4 b bits
+      }
+      return (unsigned long long)z[0] | ((unsigned long long)z[1] << (4u * b));
+    }
+
+    struct StripSmall { uint4 r0, r1, r2; uint32_t sw, base; };
+    __device__ __forceinline__ void load_strip_small(const StreamParams &p, uint32_t strip, int j, StripSmall &o)
+    {
+      o.r0 = o.r1 = o.r2 = make_uint4(0, 0, 0, 0); o.sw = 0; o.base = 0;
+      if (strip >= p.nStrips) return;
+      const uint32_t by = strip / p.stripsX, sx = strip - by * p.stripsX, bx = sx * 32u + (uint32_t)j;
+      o.base = p.stripWords[strip];
+      if (bx < p.blocksX)
+      {
+        const size_t g = (size_t)by * p.blocksX + bx;
+        const uint4 *rp = reinterpret_cast<const uint4 *>(p.records + g) + 1; // skip avg[4]
+        o.r0 = rp[0]; o.r1 = rp[1]; o.r2 = rp[2];
+        o.sw = p.shifts[g] & 0xFFFFFFu;
+      }
+    }
+
+    __global__ __launch_bounds__(64) void k_stream_pack_strips(const StreamParams p)
+    {
+      __shared__ __align__(16) uint32_t sRun[32 * 48];   // the strip's payload, worst case (24 words per block)
+      __shared__ __align__(16) uint32_t sEnt[32 * 14];   // its entries
+      const int lane = lane_id(), j = lane & 31, h = lane >> 5;
+      uint2 *const payload = reinterpret_cast<uint2 *>(p.stream + sizeof(limg_hip_stream_header) + (size_t)p.nBlocks * kEntry);
+      StripSmall cur;
+      load_strip_small(p, blockIdx.x, j, cur);
+      for (uint32_t strip = blockIdx.x; strip < p.nStrips; strip += p.nWaves)
+      {
+        const uint32_t by = strip / p.stripsX, sx = strip - by * p.stripsX, bx = sx * 32u + (uint32_t)j;
+        const uint32_t inStrip = min(32u, p.blocksX - sx * 32u);
+        const bool valid = (uint32_t)j < inStrip;
+        const int mn3[3] = { (int)(int16_t)(cur.r0.y >> 16), (int)(int16_t)(cur.r1.y >> 16), (int)(int16_t)(cur.r2.y >> 16) };
+        const int mx3[3] = { (int)(int16_t)(cur.r0.w >> 16), (int)(int16_t)(cur.r1.w >> 16), (int)(int16_t)(cur.r2.w >> 16) };
+        const uint32_t bits = valid ? field_bits(cur.sw, mn3, mx3, (int)p.channels) : 0u;
+        const uint32_t words = words_of(bits);
+        // the four rows of this lane's half, of every field the block has, requested at once
+        uint2 raw[3][4];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+        {
+          const bool has = ((bits >> (8 * k)) & 0xFFu) != 0u;
+          const uint8_t *src = p.fac[k] + (size_t)(by * 8u + (uint32_t)h * 4u) * p.sizeX + bx * 8u;
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+          {
+            raw[k][r] = make_uint2(0u, 0u);
+            if (has) raw[k][r] = *reinterpret_cast<const uint2 *>(src + (size_t)r * p.sizeX);
+          }
+        }
+        // the next strip's small loads go out behind them
+        StripSmall nxt;
+        load_strip_small(p, strip + p.nWaves, j, nxt);
+        // exclusive prefix of the words over the strip's blocks (both halves compute it)
+        uint32_t incl = words;
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1)
+        {
+          const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 32);
+          if (j >= off) incl += up;
+        }
+        const uint32_t total = (uint32_t)__shfl((int)incl, 31, 32);
+        const uint32_t excl = incl - words;
+        if (h == 0)
+        {
+          uint32_t *e = sEnt + j * 14;
+          *reinterpret_cast<uint2 *>(e + 0) = make_uint2(cur.r0.x, cur.r0.y); *reinterpret_cast<uint2 *>(e + 2) = make_uint2(cur.r0.z, cur.r0.w);
+          *reinterpret_cast<uint2 *>(e + 4) = make_uint2(cur.r1.x, cur.r1.y); *reinterpret_cast<uint2 *>(e + 6) = make_uint2(cur.r1.z, cur.r1.w);
+          *reinterpret_cast<uint2 *>(e + 8) = make_uint2(cur.r2.x, cur.r2.y); *reinterpret_cast<uint2 *>(e + 10) = make_uint2(cur.r2.z, cur.r2.w);
+          *reinterpret_cast<uint2 *>(e + 12) = make_uint2(cur.sw | (bits & 0xFF000000u), cur.base + excl);
+        }
+        {
+          uint32_t *field = sRun + 2u * excl; // dwords
+#pragma unroll
+          for (int k = 0; k < 3; k++)
+          {
+            const uint32_t b = (bits >> (8 * k)) & 0xFFu;
+            if (b == 0u) continue;
+            const uint32_t sh = 8u - b, m1 = (1u << b) - 1u, m4 = m1 * 0x01010101u, mPair = (m1 * 0x00010001u) << b;
+            uint32_t *dst = field + (uint32_t)h * b; // rows 4 h .. 4 h + 3 are bytes [4 h b, 4 h b + 4 b) of the field: b dwords
+            const uint32_t len0 = b < 4u ? b : 4u, len1 = b - len0; // a row goes in as its low (up to) 4 bytes, then the rest: never more than 3 + 4 bytes in acc
+            unsigned long long acc = 0;
+            uint32_t fill = 0; // bytes in acc (< 4 between appends)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+            {
+              const unsigned long long v = squeeze_row(raw[k][r].x, raw[k][r].y, sh, b, m4, mPair);
+              acc |= (unsigned long long)(uint32_t)v << (8u * fill);
+              fill += len0;
+              if (fill >= 4u) { *dst++ = (uint32_t)acc; acc >>= 32; fill -= 4u; }
+              acc |= (unsigned long long)(uint32_t)(v >> 32) << (8u * fill);
+              fill += len1;
+              if (fill >= 4u) { *dst++ = (uint32_t)acc; acc >>= 32; fill -= 4u; }
+            }
+            field += 2u * b;
+          }
+        }
+        wave_lds_fence();
+        {
+          uint2 *edst = reinterpret_cast<uint2 *>(p.stream + sizeof(limg_hip_stream_header) + ((size_t)by * p.blocksX + sx * 32u) * kEntry);
+          const uint2 *esrc = reinterpret_cast<const uint2 *>(sEnt);
+          for (uint32_t i = lane; i < inStrip * (kEntry / 8); i += 64) edst[i] = esrc[i];
+          uint2 *pdst = payload + (size_t)cur.base;
+          const uint2 *psrc = reinterpret_cast<const uint2 *>(sRun);
+          for (uint32_t i = lane; i < total; i += 64) pdst[i] = psrc[i];
+        }
+        wave_lds_fence(); // the run is read: the next strip may overwrite it
+        cur = nxt;
+      }
+    }
+
     // ---- decode ----------------------------------------------------------------------------------------------------------
     // PERSISTENT since round 5.  The work unit is what a wave always owned: 64 consecutive blocks (raster order), walked in 8 groups of 8 with lane = (block j = lane & 7,
     // block row r = lane >> 3).  Until round 4 a workgroup was 4 such waves behind one barrier and lived for one tile of 256 blocks: header check, entry loads (56-byte
@@ -576,6 +765,12 @@ namespace limg_hip
 
   void launch_stream_pack(const StreamParams &p, hipStream_t s)
   {
+    if (p.nWaves)
+    { // strip form (images of whole blocks): the encode kernel has left the strips' payload words
+      hipLaunchKernelGGL(k_stream_scan_strips, dim3(1), dim3(1024), 0, s, p);
+      hipLaunchKernelGGL(k_stream_pack_strips, dim3(p.nWaves), dim3(64), 0, s, p);
+      return;
+    }
     hipLaunchKernelGGL(k_stream_count, dim3(p.nTiles), dim3(kTile), 0, s, p);
     hipLaunchKernelGGL(k_stream_scan, dim3(1), dim3(1024), 0, s, p);
     hipLaunchKernelGGL(k_stream_pack, dim3(p.nTiles), dim3(kTile), 0, s, p);
