@@ -66,26 +66,42 @@ def leg_warned(leg, what):
 class known_driver_noise_filtered:
     """While the HIP runtime comes up, libdrm prints "/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory" on this image's boxes (a missing marketing-name
     table: harmless, not ours).  The driver keeps bench.py's stderr as evidence that nothing went wrong -- a look-back time-out would be reported there -- so that one
-    KNOWN line is taken out: stderr (the file descriptor, the message comes from C) goes to a temporary file for the duration and everything else in it is replayed."""
+    KNOWN line is taken out.  stderr (the file descriptor: the message comes from C) goes through a PIPE that a reader thread drains line by line, forwarding everything
+    but that line as it arrives: a crash, abort or hang inside the window loses nothing (a temporary file replayed on exit did)."""
 
     def __enter__(self):
-        import tempfile
+        import threading
         sys.stderr.flush()
-        self.tmp = tempfile.TemporaryFile(mode="w+b")
         self.saved = os.dup(2)
-        os.dup2(self.tmp.fileno(), 2)
+        r, w = os.pipe()
+        os.dup2(w, 2)
+        os.close(w)
+        out = self.saved
+
+        def pump():
+            with os.fdopen(r, "rb", buffering=0) as src:
+                buf = b""
+                while True:
+                    chunk = src.read(4096)
+                    if not chunk:
+                        break
+                    buf += chunk
+                    while b"\n" in buf:
+                        line, buf = buf.split(b"\n", 1)
+                        if b"libdrm/amdgpu.ids: No such file or directory" not in line:
+                            os.write(out, line + b"\n")
+                if buf and b"libdrm/amdgpu.ids: No such file or directory" not in buf:
+                    os.write(out, buf)
+
+        self.thread = threading.Thread(target=pump, daemon=True)
+        self.thread.start()
         return self
 
     def __exit__(self, *exc):
         sys.stderr.flush()
-        os.dup2(self.saved, 2)
+        os.dup2(self.saved, 2)  # closes the pipe's last write end: the reader sees EOF
+        self.thread.join(timeout=5.0)
         os.close(self.saved)
-        self.tmp.seek(0)
-        for raw in self.tmp.read().decode("utf-8", "replace").splitlines():
-            if raw.strip() and "libdrm/amdgpu.ids: No such file or directory" not in raw:
-                print(raw, file=sys.stderr)
-        sys.stderr.flush()
-        self.tmp.close()
         return False
 
 
@@ -100,7 +116,7 @@ def _sha256(paths):
 
 
 def source_sha():
-    """sha256 over the product's sources (limg_amd/csrc/*, include/*, limg_amd/build.py; sorted by name): identifies the code a line was measured on wherever
+    """sha256 over the product's sources (limg_amd/csrc/*, include/*, limg_amd/build.py + isa_check.py; sorted by name): identifies the code a line was measured on wherever
     .git is absent (the GPU box gets a snapshot without it) and can be recomputed from any checkout."""
     files = []
     for d in ("limg_amd/csrc", "include"):
@@ -108,6 +124,7 @@ def source_sha():
             if f.endswith((".hip", ".h", ".hpp", ".cpp")):
                 files.append(os.path.join(ROOT, d, f))
     files.append(os.path.join(ROOT, "limg_amd", "build.py"))
+    files.append(os.path.join(ROOT, "limg_amd", "isa_check.py"))
     return _sha256(files)
 
 
@@ -397,12 +414,14 @@ def run_sharded(args, g, dist, rank, world):
         collective = {"backend": None if dist is None else dist.get_backend(), "world_size": world, "rccl_version": info["rccl_version"], "comm_ranks": info["ranks"]}
     else:
         collective = collective_evidence(g, dist, rank, world)
-    golden = verify_golden(args, units, rows, rank, world, dist, single_chain, W, H, kind) if args.verify_golden else None
+    golden = verify_golden(args, units, rows, rank, world, dist, single_chain, W, H, kind) if (args.verify_golden and not COLLECTIVES_OFF) else None
 
     # reassembly on rank 0 (config 5: the strips of the one image; config 4: every image's planes), timed apart
     gather_ms = None
     gathered_bytes = 0
-    if dist is not None and not args.no_gather:
+    if dist is not None and not args.no_gather and COLLECTIVES_OFF:
+        leg_warned("gather", "skipped: a rank's RCCL evidence helper hung, no further collective is issued")
+    if dist is not None and not args.no_gather and not COLLECTIVES_OFF:
         on_gpu = dist.get_backend() == "nccl"
         dist.barrier()
         torch.cuda.synchronize()
@@ -986,19 +1005,22 @@ def main():
         run_blocked(args, g, dist, rank, n_gpus, W, H)
         g.close()
         if dist is not None:
-            dist.destroy_process_group()
+            if not COLLECTIVES_OFF:
+                dist.destroy_process_group()
         return
     if args.stream:
         run_stream(args, g, dist, rank, n_gpus, W, H)
         g.close()
         if dist is not None:
-            dist.destroy_process_group()
+            if not COLLECTIVES_OFF:
+                dist.destroy_process_group()
         return
     if args.config != 3:
         run_sharded(args, g, dist, rank, n_gpus)
         g.close()
         if dist is not None:
-            dist.destroy_process_group()
+            if not COLLECTIVES_OFF:
+                dist.destroy_process_group()
         return
     g.set_options(forced_shift=(args.forced_shift,) * 3 if args.forced_shift >= 0 else None, force_split=args.split, float_fast=(args.float_mode == "fast"), legacy_float_stage=args.legacy_float_stage,
                   test_wg_per_cu=args.wg_per_cu, test_whole_image_ragged=args.whole_image_ragged, ragged_bands=args.ragged_bands, ragged_walk_threads=args.walk_threads)
@@ -1192,7 +1214,36 @@ def main():
         emit(line)
     g.close()
     if dist is not None:
-        dist.destroy_process_group()
+        if not COLLECTIVES_OFF:
+            dist.destroy_process_group()
+
+
+COLLECTIVES_OFF = False  # set when a rank's evidence helper hung inside RCCL: from then on nothing may issue a collective on the process group
+
+
+def exchange_views(dist, rank, world, mine, timeout_s):
+    """all-gather of a small list over the process group's STORE (no RCCL): [view of rank 0, ...]; a rank that does not answer in time is reported as hung"""
+    import datetime
+    try:
+        store = dist.distributed_c10d._get_default_store()
+    except Exception:  # (stand-ins of tests/test_bench_helpers.py: a world of one)
+        store = None
+    if store is None:
+        return [list(mine) for _ in range(world)]
+    EXCHANGES.append(1)
+    tag = "limg_evidence_%d_" % len(EXCHANGES)
+    store.set(tag + str(rank), json.dumps(mine))
+    views = []
+    for r in range(world):
+        try:
+            store.wait([tag + str(r)], datetime.timedelta(seconds=timeout_s))
+            views.append(json.loads(store.get(tag + str(r))))
+        except Exception:
+            views.append([-1, r, -1, 1])
+    return views
+
+
+EXCHANGES = []
 
 
 def collective_evidence(g, dist, rank, world, timeout_s=120.0):
@@ -1233,11 +1284,16 @@ def collective_evidence(g, dist, rank, world, timeout_s=120.0):
     if "error" in res:
         ev["error"] = res["error"]
         leg_warned("collective_evidence", res["error"])
-    t = torch.tensor([info["ranks"], info["rank"], info["rccl_version"]], dtype=torch.int64, device="cuda" if have_gpu else "cpu")
-    allv = [torch.zeros_like(t) for _ in range(world)]
-    dist.all_gather(allv, t)
-    views = [[int(v) for v in a.tolist()] for a in allv]
-    if any(v[0] < 0 for v in views):
+    # Every rank's view, WITHOUT another collective on the process group: after a time-out a helper thread may still sit inside ncclCommInitRank / the broadcast, and a
+    # collective issued beside it -- by this rank or by the ranks whose helper came back -- can hang the job the time limit was meant to protect.  The
+    # views travel through the process group's store (TCP); a rank that cannot be heard from within the limit counts as hung.
+    mine = [info["ranks"], info["rank"], info["rccl_version"], 1 if th.is_alive() else 0]
+    views = exchange_views(dist, rank, world, mine, timeout_s)
+    if any(v[3] for v in views):
+        global COLLECTIVES_OFF
+        COLLECTIVES_OFF = True  # no RCCL call of this job is safe any more: the callers skip the gather, the process leaves without destroy_process_group
+        ev["hung_ranks"] = [i for i, v in enumerate(views) if v[3]]
+    if any(v[0] < 0 or v[3] for v in views):
         ev["comm_views"] = views  # (a rank could not create or query the library's communicator: reported, not fatal)
         return ev
     if any(v[0] != world for v in views) or sorted(v[1] for v in views) != list(range(world)):
@@ -1346,7 +1402,7 @@ def host_entry_rate(g, W, H, args):
 
 if __name__ == "__main__":
     main()
-    if HUNG_THREAD:  # (a helper thread is stuck inside RCCL: do not wait for it at interpreter exit)
+    if HUNG_THREAD or COLLECTIVES_OFF:  # (a helper thread of this or another rank is stuck inside RCCL: do not wait for it, or tear the group down, at exit)
         sys.stdout.flush()
         sys.stderr.flush()
         os._exit(3 if ERRORS else 0)

@@ -30,6 +30,39 @@ def _newer(target, deps):
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
+def compile_line(src, extra_flags=(), test_hooks=False):
+    """hipcc + the flags `src` is compiled with (without -c / -o): ONE definition, used for the objects and for the ISA check"""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = list(extra_flags) + (TEST_FLAGS if test_hooks else [])
+    if src.endswith(".cpp"):
+        # host-only translation units; the merge's similarity predicate is float code that must round like the kernels: no contraction
+        return [hipcc, "-O3", "-fPIC", "-std=c++17", "-Wall", "-ffp-contract=off", "-fno-fast-math", "-x", "c++"] + [f for f in extra if f.startswith("-D")]
+    return [hipcc] + FLAGS + SOURCE_FLAGS.get(src, []) + extra
+
+
+def device_assembly(src, out_dir, extra_flags=(), test_hooks=False):
+    """the gfx950 assembly of `src` from exactly the object's compile line -> path"""
+    out = os.path.join(out_dir, src.rsplit(".", 1)[0] + (".test.s" if test_hooks else ".s"))
+    subprocess.check_call(compile_line(src, extra_flags, test_hooks) + ["--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", out], stderr=subprocess.DEVNULL)
+    return out
+
+
+def check_isa(out_dir, extra_flags=(), test_hooks=False, verbose=False):
+    """k_stream_decode waits for its inline-assembly loads with a hand-counted s_waitcnt: whether that count holds is a property of the compiler's register allocation and
+    scheduling, so it is verified on every build, on the compile line that ships (limg_amd/isa_check.py); a build whose code object fails it is refused."""
+    import tempfile
+    try:
+        from limg_amd import isa_check
+    except ImportError:  # run as a script: python limg_amd/build.py
+        sys.path.insert(0, os.path.dirname(HERE))
+        from limg_amd import isa_check
+    with tempfile.TemporaryDirectory() as tmp:
+        got = isa_check.check_decode_isa(open(device_assembly("limg_hip_stream.hip", tmp, extra_flags, test_hooks)).read())
+    if verbose:
+        print("isa check (k_stream_decode, %s build): %s" % ("test-hooks" if test_hooks else "product", got), flush=True)
+    return got
+
+
 def build(force=False, verbose=False, extra_flags=(), out_dir=None, test_hooks=False):
     """out_dir: build objects and the library THERE from the sources (nothing reused, nothing in-tree touched) -- the from-scratch check of tests/test_build_from_source.py.
     test_hooks: the -DLIMG_HIP_TEST_HOOKS build (liblimg_hip_test.so; objects *.test.o)."""
@@ -46,11 +79,7 @@ def build(force=False, verbose=False, extra_flags=(), out_dir=None, test_hooks=F
     jobs = []
     for src in SOURCES:
         obj = os.path.join(CSRC if out_dir is None else out_dir, src.rsplit(".", 1)[0] + (".test.o" if test_hooks else ".o"))
-        cmd = [hipcc] + FLAGS + SOURCE_FLAGS.get(src, []) + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
-        if src.endswith(".cpp"):
-            # host-only translation units; the merge's similarity predicate is float code that must round like the kernels: no contraction
-            cmd = [hipcc, "-O3", "-fPIC", "-std=c++17", "-Wall", "-ffp-contract=off", "-fno-fast-math", "-x", "c++"] + [f for f in extra if f.startswith("-D")] + ["-c", os.path.join(CSRC, src), "-o", obj]
-        jobs.append((cmd, obj))
+        jobs.append((compile_line(src, extra_flags, test_hooks) + ["-c", os.path.join(CSRC, src), "-o", obj], obj))
 
     def run(job):
         if verbose:
@@ -60,6 +89,7 @@ def build(force=False, verbose=False, extra_flags=(), out_dir=None, test_hooks=F
 
     with ThreadPoolExecutor(max_workers=int(os.environ.get("LIMG_BUILD_JOBS", "4"))) as ex:
         objs = list(ex.map(run, jobs))
+    check_isa(out_dir, extra_flags, test_hooks, verbose)  # before the link: no library without it
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -224,6 +224,26 @@ namespace
     return farCount * farEvery;
   }
 
+  // work(0) .. work(n - 1), each on a host thread of its own where the host lets us start one.  A thread that cannot be created (EAGAIN under a pid / thread limit) or a
+  // pool that cannot be allocated must neither leave joinable threads behind (their destructor calls std::terminate) nor send an exception across the extern "C"
+  // boundary: whatever did not get a thread runs on the calling thread.  `work` itself must not throw.
+  template <class F>
+  void run_on_threads(unsigned n, F &&work) noexcept
+  {
+    std::thread *pool = n > 1 ? new (std::nothrow) std::thread[n - 1] : nullptr; // default-constructed: not joinable
+    unsigned started = 0;
+    if (pool)
+      for (; started < n - 1; started++)
+      {
+        try { pool[started] = std::thread(work, started + 1); }
+        catch (...) { break; }
+      }
+    work(0u);
+    for (unsigned t = started + 1; t < n; t++) work(t);
+    for (unsigned t = 0; t < started; t++) pool[t].join();
+    delete[] pool;
+  }
+
   // Dense chain values (every LIMG_NOISE_CHECKPOINT_EVERY = 1024 calls) number first .. first + count - 1 into pOut: the embedded dense table where it reaches (16 Mi
   // calls), beyond it the embedded FAR values (every 65536 calls) walked on foot -- 65536 calls of 8 AES rounds per far value = 0.5 ms, far values independent of each
   // other: on up to 16 host threads.  false beyond the far table's reach.
@@ -256,13 +276,7 @@ namespace
         }
       }
     };
-    if (threads <= 1) work(0);
-    else
-    {
-      std::vector<std::thread> pool;
-      for (unsigned t = 0; t < threads; t++) pool.emplace_back(work, t);
-      for (std::thread &th : pool) th.join();
-    }
+    run_on_threads(threads, work);
     return true;
   }
 
@@ -798,14 +812,24 @@ namespace
       uint32_t *hBase = (uint32_t *)((uint8_t *)c->hStage.p + offBase);
       unsigned long long *hStates = (unsigned long long *)((uint8_t *)c->hStage.p + offStates);
       uint8_t *hPixels = (uint8_t *)c->hStage.p + offPixels;
-      // device side: sized for the worst case up front (3 calls per block), so that a band's calls can go up while later bands are still being walked
-      if ((r = c->noiseDyn.ensure((maxCalls + 1) * 64)) != limg_hip_success) return r;
-      if ((r = c->noiseStates.ensure(maxCalls * 9 + 16)) != limg_hip_success) return r;
-      unsigned long long *dStates = (unsigned long long *)c->noiseStates.p;
-      uint8_t *dPixels = (uint8_t *)c->noiseStates.p + maxCalls * 8;
+      // device side: per dither call 64 noise bytes + the 9 bytes they are expanded from.  A banded encode sends a band's calls up while later bands are still being
+      // walked, so it sizes for the worst case up front (3 calls per block); everything else knows its call count before anything goes up (the shift words are down)
+      // and sizes for that -- a 32766 x 32768 image would otherwise hold 3.6 GB of the GPU for nothing
+      unsigned long long *dStates = nullptr;
+      uint8_t *dPixels = nullptr;
+      auto size_device_side = [&](size_t calls) -> limg_hip_result
+      {
+        limg_hip_result rr;
+        if ((rr = c->noiseDyn.ensure((calls + 1) * 64)) != limg_hip_success) return rr;
+        if ((rr = c->noiseStates.ensure(calls * 9 + 16)) != limg_hip_success) return rr;
+        dStates = (unsigned long long *)c->noiseStates.p;
+        dPixels = (uint8_t *)c->noiseStates.p + calls * 8;
+        p.noise = (const uint8_t *)c->noiseDyn.p;
+        p.noiseLast = (uint32_t)calls; // (entry `calls` exists: the clamp of a call index cannot land outside the buffer)
+        return limg_hip_success;
+      };
+      if (nBands > 1 && (r = size_device_side(maxCalls)) != limg_hip_success) return r;
       const bool pcg = c->opt.dither_pcg != 0;
-      p.noise = (const uint8_t *)c->noiseDyn.p;
-      p.noiseLast = (uint32_t)maxCalls;
       auto upload_calls = [&](size_t call0, size_t n) -> limg_hip_result
       {
         if (!n) return limg_hip_success;
@@ -841,6 +865,11 @@ namespace
       HIP_TRY(hipMemcpyAsync(hShifts, p.shifts, blocks * 4, hipMemcpyDeviceToHost, stream));
       if (x.dPrevDesc) HIP_TRY(hipMemcpyAsync(hPrev, x.dPrevDesc, 8, hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
+      {
+        size_t sumCalls = 0;
+        for (size_t i = 0; i < blocks; i++) sumCalls += hShifts[i] >> 24;
+        if ((r = size_device_side(sumCalls < maxCalls ? sumCalls : maxCalls)) != limg_hip_success) return r;
+      }
       uint64_t h0 = kDitherSeed;
       if (x.dPrevDesc)
       { // the block rows above this sub-image ran through the persistent kernel: every strip's descriptor ends as the inclusive call count of its chain
@@ -863,8 +892,10 @@ namespace
       }
       if (threads > 1)
       {
-        std::vector<size_t> first(pt.chainCount + 1, 0);
-        std::vector<uint32_t> row0(pt.chainCount + 1, 0);
+        size_t *first = new (std::nothrow) size_t[pt.chainCount + 1];
+        uint32_t *row0 = new (std::nothrow) uint32_t[pt.chainCount + 1];
+        if (!first || !row0) { delete[] first; delete[] row0; return limg_hip_error_MemoryAllocationFailure; }
+        first[0] = 0;
         for (uint32_t k = 0; k < pt.chainCount; k++)
         {
           row0[k] = k * pt.chainRows;
@@ -874,18 +905,17 @@ namespace
           first[k + 1] = first[k] + n;
         }
         row0[pt.chainCount] = p.blocksY;
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < threads; t++)
-          pool.emplace_back([&, t]() {
-            for (uint32_t k = t; k < pt.chainCount; k += threads)
-            {
-              uint64_t h = kDitherSeed;
-              size_t call = first[k];
-              chain_walk_rows(h, call, row0[k], row0[k + 1], p.blocksX, p.stripsX, sizeX, sizeY, pt.chainCount, pt.chainRows, hShifts, hBase, hStates, hPixels, maxCalls, pcg);
-            }
-          });
-        for (std::thread &t : pool) t.join();
-        totalCalls = first[pt.chainCount] < maxCalls ? first[pt.chainCount] : maxCalls;
+        run_on_threads(threads, [&](unsigned t) {
+          for (uint32_t k = t; k < pt.chainCount; k += threads)
+          {
+            uint64_t h = kDitherSeed;
+            size_t call = first[k];
+            chain_walk_rows(h, call, row0[k], row0[k + 1], p.blocksX, p.stripsX, sizeX, sizeY, pt.chainCount, pt.chainRows, hShifts, hBase, hStates, hPixels, maxCalls, pcg);
+          }
+        });
+        const size_t allCalls = first[pt.chainCount];
+        delete[] first; delete[] row0;
+        totalCalls = allCalls < maxCalls ? allCalls : maxCalls;
       }
       else totalCalls = chain_walk_blocks(h0, p.blocksX, p.blocksY, p.stripsX, sizeX, sizeY, pt.chainCount, pt.chainRows, hShifts, hBase, hStates, hPixels, maxCalls, pcg);
       if ((r = upload_calls(0, totalCalls)) != limg_hip_success) return r;
@@ -1455,7 +1485,7 @@ extern "C"
     {
       sp.stripWords = (uint32_t *)c->streamUnits.p;
       sp.stripsX = (uint32_t)stripsX; sp.nStrips = (uint32_t)nStrips;
-      const size_t slots = (size_t)(c->persistentWorkgroups / 5) * 20; // 20 one-wave workgroups per CU (7.75 KiB of LDS each)
+      const size_t slots = (size_t)(c->persistentWorkgroups / 5) * 16; // 16 one-wave workgroups per CU (128 vector registers each: 4 per SIMD)
       sp.nWaves = (uint32_t)(nStrips < slots ? nStrips : slots);
     }
     mark(c, s);

@@ -252,6 +252,8 @@ namespace limg_hip
     // (A one-launch form with a decoupled look-back over per-unit totals was built first and measured: 0.27 ms -- at start-up every wave in flight walks back through
     // all its predecessors, 64 descriptors per round trip -- against 0.131 ms for the three kernels; `tools/r06/` keeps the numbers.)
     // Widths or heights that are not whole blocks keep the three-kernel form (byte gathers at the edges).
+    // one workgroup; a thread owns 32 consecutive strips per round and has all of them requested before it adds any (8 x 16 bytes: the kernel is one memory round
+    // trip + one barrier sequence per 32 K strips -- 8192^2 is one round)
     __global__ __launch_bounds__(1024) void k_stream_scan_strips(const StreamParams p)
     {
       __shared__ unsigned long long sWave[16];
@@ -259,15 +261,29 @@ namespace limg_hip
       const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
       if (tid == 0) sCarry = 0;
       __syncthreads();
-      for (uint32_t base = 0; base < p.nStrips; base += 8192)
+      const bool vec = (p.nStrips & 3u) == 0; // 16-byte accesses need whole groups of 4 (the buffer itself is 256-byte aligned)
+      for (uint32_t base = 0; base < p.nStrips; base += 32768)
       {
-        const uint32_t i0 = base + (uint32_t)tid * 8u;
-        uint32_t v[8];
+        const uint32_t i0 = base + (uint32_t)tid * 32u;
+        uint32_t v[32];
+        if (vec)
+        {
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = i0 + k < p.nStrips ? p.stripWords[i0 + k] : 0u;
+          for (int q = 0; q < 8; q++)
+          {
+            uint4 t = make_uint4(0, 0, 0, 0);
+            if (i0 + 4 * q < p.nStrips) t = *reinterpret_cast<const uint4 *>(p.stripWords + i0 + 4 * q);
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+          }
+        }
+        else
+        {
+#pragma unroll
+          for (int k = 0; k < 32; k++) v[k] = i0 + k < p.nStrips ? p.stripWords[i0 + k] : 0u;
+        }
         unsigned long long mine = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) mine += v[k];
+        for (int k = 0; k < 32; k++) mine += v[k];
         unsigned long long incl = mine;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1)
@@ -279,12 +295,20 @@ namespace limg_hip
         __syncthreads();
         unsigned long long pre = sCarry;
         for (int w = 0; w < wave; w++) pre += sWave[w];
-        unsigned long long run = pre + incl - mine; // entry.payloadWord is 32 bits: the host refuses images whose worst-case payload would not fit (limg_hip_stream_bound)
+        uint32_t run = (uint32_t)(pre + incl - mine); // entry.payloadWord is 32 bits: the host refuses images whose worst-case payload would not fit (limg_hip_stream_bound)
 #pragma unroll
-        for (int k = 0; k < 8; k++)
+        for (int k = 0; k < 32; k++) { const uint32_t t = v[k]; v[k] = run; run += t; }
+        if (vec)
         {
-          if (i0 + k < p.nStrips) p.stripWords[i0 + k] = (uint32_t)run;
-          run += v[k];
+#pragma unroll
+          for (int q = 0; q < 8; q++)
+            if (i0 + 4 * q < p.nStrips) *reinterpret_cast<uint4 *>(p.stripWords + i0 + 4 * q) = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        }
+        else
+        {
+#pragma unroll
+          for (int k = 0; k < 32; k++)
+            if (i0 + k < p.nStrips) p.stripWords[i0 + k] = v[k];
         }
         __syncthreads();
         if (tid == 1023) sCarry = pre + incl;
@@ -333,40 +357,51 @@ namespace limg_hip
       }
     }
 
+    struct StripRows { uint2 raw[3][4]; uint32_t bits; };
+    // field sizes of the lane's block + the request for its four rows of every field the block has
+    __device__ __forceinline__ void issue_strip_rows(const StreamParams &p, uint32_t strip, int j, int h, const StripSmall &sm, StripRows &o)
+    {
+      o.bits = 0;
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) o.raw[k][r] = make_uint2(0u, 0u);
+      if (strip >= p.nStrips) return;
+      const uint32_t by = strip / p.stripsX, sx = strip - by * p.stripsX, bx = sx * 32u + (uint32_t)j;
+      if (bx >= p.blocksX) return;
+      const int mn3[3] = { (int)(int16_t)(sm.r0.y >> 16), (int)(int16_t)(sm.r1.y >> 16), (int)(int16_t)(sm.r2.y >> 16) };
+      const int mx3[3] = { (int)(int16_t)(sm.r0.w >> 16), (int)(int16_t)(sm.r1.w >> 16), (int)(int16_t)(sm.r2.w >> 16) };
+      o.bits = field_bits(sm.sw, mn3, mx3, (int)p.channels);
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+      {
+        if (((o.bits >> (8 * k)) & 0xFFu) == 0u) continue;
+        const uint8_t *src = p.fac[k] + (size_t)(by * 8u + (uint32_t)h * 4u) * p.sizeX + bx * 8u;
+#pragma unroll
+        for (int r = 0; r < 4; r++) o.raw[k][r] = *reinterpret_cast<const uint2 *>(src + (size_t)r * p.sizeX);
+      }
+    }
+
+    // Software pipeline, two strips deep: while strip i is packed, the rows of strip i + 1 and the shift words / records of strip i + 2 are in flight.
     __global__ __launch_bounds__(64) void k_stream_pack_strips(const StreamParams p)
     {
       __shared__ __align__(16) uint32_t sRun[32 * 48];   // the strip's payload, worst case (24 words per block)
       __shared__ __align__(16) uint32_t sEnt[32 * 14];   // its entries
       const int lane = lane_id(), j = lane & 31, h = lane >> 5;
       uint2 *const payload = reinterpret_cast<uint2 *>(p.stream + sizeof(limg_hip_stream_header) + (size_t)p.nBlocks * kEntry);
-      StripSmall cur;
+      StripSmall cur, nxt;
+      StripRows rows, rowsNext;
       load_strip_small(p, blockIdx.x, j, cur);
+      load_strip_small(p, blockIdx.x + p.nWaves, j, nxt);
+      issue_strip_rows(p, blockIdx.x, j, h, cur, rows);
       for (uint32_t strip = blockIdx.x; strip < p.nStrips; strip += p.nWaves)
       {
-        const uint32_t by = strip / p.stripsX, sx = strip - by * p.stripsX, bx = sx * 32u + (uint32_t)j;
+        issue_strip_rows(p, strip + p.nWaves, j, h, nxt, rowsNext); // (waits for `nxt`, requested one iteration ago)
+        StripSmall nxt2;
+        load_strip_small(p, strip + 2u * p.nWaves, j, nxt2);
+        const uint32_t by = strip / p.stripsX, sx = strip - by * p.stripsX;
         const uint32_t inStrip = min(32u, p.blocksX - sx * 32u);
-        const bool valid = (uint32_t)j < inStrip;
-        const int mn3[3] = { (int)(int16_t)(cur.r0.y >> 16), (int)(int16_t)(cur.r1.y >> 16), (int)(int16_t)(cur.r2.y >> 16) };
-        const int mx3[3] = { (int)(int16_t)(cur.r0.w >> 16), (int)(int16_t)(cur.r1.w >> 16), (int)(int16_t)(cur.r2.w >> 16) };
-        const uint32_t bits = valid ? field_bits(cur.sw, mn3, mx3, (int)p.channels) : 0u;
-        const uint32_t words = words_of(bits);
-        // the four rows of this lane's half, of every field the block has, requested at once
-        uint2 raw[3][4];
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-        {
-          const bool has = ((bits >> (8 * k)) & 0xFFu) != 0u;
-          const uint8_t *src = p.fac[k] + (size_t)(by * 8u + (uint32_t)h * 4u) * p.sizeX + bx * 8u;
-#pragma unroll
-          for (int r = 0; r < 4; r++)
-          {
-            raw[k][r] = make_uint2(0u, 0u);
-            if (has) raw[k][r] = *reinterpret_cast<const uint2 *>(src + (size_t)r * p.sizeX);
-          }
-        }
-        // the next strip's small loads go out behind them
-        StripSmall nxt;
-        load_strip_small(p, strip + p.nWaves, j, nxt);
+        const uint32_t bits = rows.bits, words = words_of(bits);
         // exclusive prefix of the words over the strip's blocks (both halves compute it)
         uint32_t incl = words;
 #pragma unroll
@@ -400,7 +435,7 @@ namespace limg_hip
 #pragma unroll
             for (int r = 0; r < 4; r++)
             {
-              const unsigned long long v = squeeze_row(raw[k][r].x, raw[k][r].y, sh, b, m4, mPair);
+              const unsigned long long v = squeeze_row(rows.raw[k][r].x, rows.raw[k][r].y, sh, b, m4, mPair);
               acc |= (unsigned long long)(uint32_t)v << (8u * fill);
               fill += len0;
               if (fill >= 4u) { *dst++ = (uint32_t)acc; acc >>= 32; fill -= 4u; }
@@ -416,12 +451,23 @@ namespace limg_hip
           uint2 *edst = reinterpret_cast<uint2 *>(p.stream + sizeof(limg_hip_stream_header) + ((size_t)by * p.blocksX + sx * 32u) * kEntry);
           const uint2 *esrc = reinterpret_cast<const uint2 *>(sEnt);
           for (uint32_t i = lane; i < inStrip * (kEntry / 8); i += 64) edst[i] = esrc[i];
+          // the run in 16-byte stores: the payload area is 8-byte aligned, so a run that starts on an odd word sends that word ahead (the LDS side is then read at
+          // 8-byte alignment, which ds_read_b128 does not allow: two ds_read_b64)
           uint2 *pdst = payload + (size_t)cur.base;
           const uint2 *psrc = reinterpret_cast<const uint2 *>(sRun);
-          for (uint32_t i = lane; i < total; i += 64) pdst[i] = psrc[i];
+          const uint32_t odd = (uint32_t)((reinterpret_cast<uintptr_t>(pdst) >> 3) & 1u) & (total ? 1u : 0u);
+          if (odd && lane == 0) pdst[0] = psrc[0];
+          const uint32_t pairs = (total - odd) >> 1;
+          uint4 *p4 = reinterpret_cast<uint4 *>(pdst + odd);
+          for (uint32_t i = lane; i < pairs; i += 64)
+          {
+            const uint2 a = psrc[odd + 2u * i], b2 = psrc[odd + 2u * i + 1u];
+            p4[i] = make_uint4(a.x, a.y, b2.x, b2.y);
+          }
+          if (((total - odd) & 1u) && lane == 0) pdst[total - 1u] = psrc[total - 1u];
         }
         wave_lds_fence(); // the run is read: the next strip may overwrite it
-        cur = nxt;
+        cur = nxt; nxt = nxt2; rows = rowsNext;
       }
     }
 
