@@ -19,6 +19,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <atomic>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -122,6 +123,10 @@ struct limg_hip_context
   DevBuf accTable;                               // accurate search: automaton expanded to 32-byte entries (built on the first accurate encode)
   DevBuf devStatus;                              // sticky look-back timeout word: never touched by the per-launch memset, cleared by limg_hip_check_device_status
   DevBuf in, planes;                             // staging for the host-pointer entry points
+  hipStream_t hostCopyStream = nullptr;          // ... the downloads of the finished bands (second host thread)
+  hipStream_t hostStream = nullptr;              // ... in row bands: the bands' kernels run here, their events tell the download thread when a band is done
+  std::vector<hipEvent_t> hostEvents;
+  DevBuf hostWords;                              // ... per band its dither-call total and its chain base (one chain through the bands)
   DevBuf cmp;                                    // 8-byte accumulator of limg_hip_compare
   DevBuf bFlags, bBound;
   DevBuf bMatch, bRegions, bOut, bPx, bFac, bNoise, bNoiseBase; // merged-block encoder: similarity bits, region table / results, scratch (gathered pixels, factor bytes), noise
@@ -1062,6 +1067,10 @@ extern "C"
     if (c->hStageEvent) (void)hipEventDestroy(c->hStageEvent);
     for (hipEvent_t e : c->raggedEvents) (void)hipEventDestroy(e);
     if (c->fitStream) (void)hipStreamDestroy(c->fitStream);
+    if (c->hostStream) (void)hipStreamDestroy(c->hostStream);
+    if (c->hostCopyStream) (void)hipStreamDestroy(c->hostCopyStream);
+    for (hipEvent_t e : c->hostEvents) (void)hipEventDestroy(e);
+    c->hostWords.release();
     for (hipEvent_t e : c->pipeEvents) (void)hipEventDestroy(e);
     if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
     if (c->workStream) (void)hipStreamDestroy(c->workStream);
@@ -1342,6 +1351,153 @@ extern "C"
     return r;
   }
 
+  // The host-pointer entry in ROW BANDS: what every relinked caller of limg_encode3d_test hits moves 4 B/px up and 35 B/px down over PCIe, and
+  // the download alone (2.35 GB for 8192^2) is ~43 ms at wire rate against 1.4 ms of kernels.  Upload, encode and download one after the other: 50.4 ms.  Here the
+  // image goes up and is encoded band by band on the calling thread while a second host thread brings every finished band's rows of the 11 planes down (PCIe is full
+  // duplex; blocking copies from / to the caller's pageable memory already run at wire rate, so no staging copy is added): the upload and the kernels of band k + 1
+  // hide under the download of band k.
+  //   * poolThreads == 0 (one dither chain through the image, src/limg.cpp:2110): bands of whole block rows through the two exchange-free halves of the chain entry
+  //     -- E step + scan of the band, then its F step from the call count of the bands above it (k_chain_base on the device, stream-ordered, no host round trip);
+  //   * poolThreads > 0 (src/limg.cpp:2114-2134): every chain restarts at the seed, so a band is a chain: an independent encode of its rows.
+  // Images with partial edge blocks, small images and encodes that collect statistics take the plain path.
+  static limg_hip_result host_encode_banded(limg_hip_context *c, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, void *const *hp, void *const *dp,
+                                            uint32_t errorFactor, int poolThreads, int fastBitCrushing)
+  {
+    struct Band { size_t y0, y1; };
+    const size_t blocksX = sizeX / kBlock, blocksY = sizeY / kBlock;
+    const Partition pt = partition(sizeY, poolThreads);
+    const bool chains = pt.chainCount > 1 && pt.chainRows != 0;
+    Band bands[64];
+    uint32_t nb = 0;
+    if (chains)
+    {
+      if (pt.chainCount > 64) return limg_hip_error_InvalidParameter; // (the caller falls back to the plain path)
+      for (uint32_t k = 0; k < pt.chainCount; k++)
+      {
+        bands[nb].y0 = (size_t)k * pt.chainRows * kBlock;
+        bands[nb].y1 = k + 1 < pt.chainCount ? (size_t)(k + 1) * pt.chainRows * kBlock : sizeY;
+        nb++;
+      }
+    }
+    else
+    {
+#ifndef LIMG_HOST_BANDS
+#define LIMG_HOST_BANDS 8
+#endif
+      const size_t want = LIMG_HOST_BANDS, rows = ((blocksY + want - 1) / want) * kBlock;
+      for (size_t y = 0; y < sizeY; y += rows) { bands[nb].y0 = y; bands[nb].y1 = y + rows < sizeY ? y + rows : sizeY; nb++; }
+    }
+    limg_hip_result r;
+    if (!c->hostStream) HIP_TRY(hipStreamCreateWithFlags(&c->hostStream, hipStreamNonBlocking));
+    if (!c->hostCopyStream) HIP_TRY(hipStreamCreateWithFlags(&c->hostCopyStream, hipStreamNonBlocking));
+    while (c->hostEvents.size() < nb)
+    {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      c->hostEvents.push_back(e);
+    }
+    if ((r = c->hostWords.ensure((2 * 64 + 2) * 8)) != limg_hip_success) return r;
+    if (!c->devStatus.p)
+    {
+      if ((r = c->devStatus.ensure(16)) != limg_hip_success) return r;
+      HIP_TRY(hipMemset(c->devStatus.p, 0, 16));
+    }
+    unsigned long long *dCalls = (unsigned long long *)c->hostWords.p, *dBase = dCalls + 64;
+    hipStream_t s = c->hostStream;
+    HIP_TRY(hipMemsetAsync(dCalls, 0, 2 * 64 * 8, s));
+
+    // the downloads: a second host thread, band after band, as their events fire
+    std::atomic<uint32_t> ready(0);      // bands whose kernels are enqueued and whose event is recorded
+    std::atomic<int> failed(0);
+    std::mutex m;
+    std::condition_variable cv;
+#ifdef LIMG_HOST_BAND_TIMING
+    const auto t00 = std::chrono::steady_clock::now();
+    auto ms_now = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t00).count(); };
+#endif
+    auto download = [&]() {
+      if (hipSetDevice(c->device) != hipSuccess) { failed = 1; return; }
+      for (uint32_t b = 0; b < nb; b++)
+      {
+#ifdef LIMG_HOST_BAND_TIMING
+        const double tw = ms_now();
+#endif
+        {
+          std::unique_lock<std::mutex> lk(m);
+          cv.wait(lk, [&] { return ready.load() > b || failed.load() != 0; });
+        }
+        if (failed.load() != 0) return;
+        if (hipEventSynchronize(c->hostEvents[b]) != hipSuccess) { failed = 1; return; }
+        const size_t o = bands[b].y0 * sizeX, n = (bands[b].y1 - bands[b].y0) * sizeX;
+        for (int i = 0; i < 11; i++)
+        {
+          const size_t es = i < 8 ? 4 : 1;
+          // (on a stream of its own: blocking hipMemcpy calls of two threads share the null stream and run one after the other -- measured: every upload waited
+          // for the download in front of it)
+          if (hipMemcpyAsync((uint8_t *)hp[i] + o * es, (const uint8_t *)dp[i] + o * es, n * es, hipMemcpyDeviceToHost, c->hostCopyStream) != hipSuccess) { failed = 1; return; }
+        }
+        if (hipStreamSynchronize(c->hostCopyStream) != hipSuccess) { failed = 1; return; }
+#ifdef LIMG_HOST_BAND_TIMING
+        fprintf(stderr, "band %u: download waited from %.2f, ran %.2f .. %.2f ms (%.1f GB/s)\n", b, tw, tw, ms_now(), n * 35 / 1e6 / (ms_now() - tw));
+#endif
+      }
+    };
+    std::thread *copier = nullptr;
+    try { copier = new std::thread(download); }
+    catch (...) { copier = nullptr; }
+
+    limg_hip_result result = limg_hip_success;
+    for (uint32_t b = 0; b < nb && result == limg_hip_success && failed.load() == 0; b++)
+    {
+      const size_t y0 = bands[b].y0, rows = bands[b].y1 - y0, o = y0 * sizeX;
+      const uint32_t *dIn = (const uint32_t *)c->in.p + o;
+      if (hipMemcpyAsync((void *)dIn, pIn + o, rows * sizeX * 4, hipMemcpyHostToDevice, s) != hipSuccess) { result = limg_hip_error_Generic; break; }
+      limg_hip_encode3d_info d;
+      void **q = reinterpret_cast<void **>(&d);
+      for (int i = 0; i < 11; i++) q[i] = (uint8_t *)dp[i] + o * (i < 8 ? 4 : 1);
+      if (chains) result = encode_device(c, dIn, sizeX, rows, hasAlpha, &d, nullptr, errorFactor, 0, fastBitCrushing, s);
+      else
+      {
+        const size_t before = (y0 / kBlock) * blocksX;
+        result = limg_hip_encode3d_chain_device(c, dIn, sizeX, rows, hasAlpha, &d, errorFactor, fastBitCrushing, 1, (uint64_t *)(dCalls + b), nullptr, before, s);
+        if (result == limg_hip_success)
+        {
+          launch_chain_base(dCalls, (int)b, (int)nb, dBase + b, (uint32_t *)c->devStatus.p + 1, s);
+          result = limg_hip_encode3d_chain_device(c, dIn, sizeX, rows, hasAlpha, &d, errorFactor, fastBitCrushing, 2, nullptr, (const uint64_t *)(dBase + b), before, s);
+        }
+      }
+      if (result == limg_hip_success && hipEventRecord(c->hostEvents[b], s) != hipSuccess) result = limg_hip_error_Generic;
+      if (result != limg_hip_success) break;
+#ifdef LIMG_HOST_BAND_TIMING
+      fprintf(stderr, "band %u: uploaded + enqueued at %.2f ms\n", b, ms_now());
+#endif
+      {
+        std::lock_guard<std::mutex> lk(m);
+        ready = b + 1;
+      }
+      cv.notify_all();
+      if (!copier)
+      { // no second thread to be had: this band comes down here and now (the plain order, band-wise)
+        if (hipEventSynchronize(c->hostEvents[b]) != hipSuccess) { result = limg_hip_error_Generic; break; }
+        for (int i = 0; i < 11; i++)
+        {
+          const size_t es = i < 8 ? 4 : 1;
+          if (hipMemcpy((uint8_t *)hp[i] + o * es, (const uint8_t *)dp[i] + o * es, rows * sizeX * es, hipMemcpyDeviceToHost) != hipSuccess) { result = limg_hip_error_Generic; break; }
+        }
+      }
+    }
+    if (result != limg_hip_success)
+    {
+      std::lock_guard<std::mutex> lk(m);
+      failed = 1;
+    }
+    cv.notify_all();
+    if (copier) { copier->join(); delete copier; }
+    if (result == limg_hip_success && failed.load() != 0) result = limg_hip_error_Generic;
+    const limg_hip_result status = limg_hip_check_device_status(c); // (also waits for whatever is still enqueued)
+    return result != limg_hip_success ? result : status;
+  }
+
   limg_hip_result limg_hip_encode3d(limg_hip_context *c, const uint32_t *pIn, size_t sizeX, size_t sizeY, int hasAlpha, limg_hip_encode3d_info *pInfo, uint32_t errorFactor,
                                     int poolThreads, int fastBitCrushing)
   {
@@ -1356,7 +1512,6 @@ extern "C"
     limg_hip_result r;
     if ((r = c->in.ensure(px * 4)) != limg_hip_success) return r;
     if ((r = c->planes.ensure(px * 35 + 11 * 256)) != limg_hip_success) return r;
-    HIP_TRY(hipMemcpy(c->in.p, pIn, px * 4, hipMemcpyHostToDevice));
     limg_hip_encode3d_info d;
     uint8_t *base = (uint8_t *)c->planes.p;
     void **dp = reinterpret_cast<void **>(&d);
@@ -1367,6 +1522,13 @@ extern "C"
       off += (i < 8 ? px * 4 : px);
       off = (off + 255) & ~(size_t)255;
     }
+    // from 4 Mpixels on (below, the whole call is a few milliseconds and the bands' launches would not pay), whole blocks, at least 8 block rows per band
+    const Partition pt = partition(sizeY, poolThreads);
+    const bool chains = pt.chainCount > 1 && pt.chainRows != 0;
+    if (px >= ((size_t)4 << 20) && sizeX % kBlock == 0 && sizeY % kBlock == 0 && sizeY >= 64 * kBlock && c->opt.collect_stats == 0 && !c->forceSplit &&
+        (!chains || (pt.chainCount <= 64 && pt.chainRows >= 8)))
+      return host_encode_banded(c, pIn, sizeX, sizeY, hasAlpha, hp, dp, errorFactor, poolThreads, fastBitCrushing);
+    HIP_TRY(hipMemcpy(c->in.p, pIn, px * 4, hipMemcpyHostToDevice));
     if ((r = encode_device(c, (const uint32_t *)c->in.p, sizeX, sizeY, hasAlpha, &d, nullptr, errorFactor, poolThreads, fastBitCrushing, nullptr)) != limg_hip_success) return r;
     if ((r = limg_hip_check_device_status(c)) != limg_hip_success) return r;
     for (int i = 0; i < 11; i++) HIP_TRY(hipMemcpy(hp[i], dp[i], i < 8 ? px * 4 : px, hipMemcpyDeviceToHost));

@@ -252,66 +252,89 @@ namespace limg_hip
     // (A one-launch form with a decoupled look-back over per-unit totals was built first and measured: 0.27 ms -- at start-up every wave in flight walks back through
     // all its predecessors, 64 descriptors per round trip -- against 0.131 ms for the three kernels; `tools/r06/` keeps the numbers.)
     // Widths or heights that are not whole blocks keep the three-kernel form (byte gathers at the edges).
-    // one workgroup; a thread owns 32 consecutive strips per round and has all of them requested before it adds any (8 x 16 bytes: the kernel is one memory round
-    // trip + one barrier sequence per 32 K strips -- 8192^2 is one round)
+    // One workgroup.  A round covers 32 K strips as 8 slabs of 4096: thread t holds strips 4096 q + 4 t .. + 3 of every slab q -- each load and store is a fully
+    // coalesced 16 bytes per lane (a thread that owned 32 CONSECUTIVE strips asked its CU's address unit for 64 lines per instruction: 11 us; the first form, one
+    // slab per loop iteration with the loads inside the loop: 32 us) -- all 8 requested before anything is added; the 8 slabs' wave scans run side by side, the
+    // 8 x 16 wave totals are turned into their exclusive prefix by one wave, two barriers per round.  8192^2 is one round.
     __global__ __launch_bounds__(1024) void k_stream_scan_strips(const StreamParams p)
     {
-      __shared__ unsigned long long sWave[16];
-      __shared__ unsigned long long sCarry;
+      __shared__ unsigned long long sPart[8 * 16]; // [slab][wave] totals, then their exclusive prefix
+      __shared__ unsigned long long sCarry, sRound;
       const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
       if (tid == 0) sCarry = 0;
       __syncthreads();
       const bool vec = (p.nStrips & 3u) == 0; // 16-byte accesses need whole groups of 4 (the buffer itself is 256-byte aligned)
       for (uint32_t base = 0; base < p.nStrips; base += 32768)
       {
-        const uint32_t i0 = base + (uint32_t)tid * 32u;
-        uint32_t v[32];
-        if (vec)
+        uint32_t v[8][4];
+#pragma unroll
+        for (int q = 0; q < 8; q++)
         {
+          const uint32_t i0 = base + (uint32_t)q * 4096u + (uint32_t)tid * 4u;
+          if (vec)
+          {
+            uint4 t = make_uint4(0, 0, 0, 0);
+            if (i0 < p.nStrips) t = *reinterpret_cast<const uint4 *>(p.stripWords + i0);
+            v[q][0] = t.x; v[q][1] = t.y; v[q][2] = t.z; v[q][3] = t.w;
+          }
+          else
+          {
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[q][k] = i0 + k < p.nStrips ? p.stripWords[i0 + k] : 0u;
+          }
+        }
+        unsigned long long mine[8], incl[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) incl[q] = mine[q] = (unsigned long long)v[q][0] + v[q][1] + v[q][2] + v[q][3];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1)
 #pragma unroll
           for (int q = 0; q < 8; q++)
           {
-            uint4 t = make_uint4(0, 0, 0, 0);
-            if (i0 + 4 * q < p.nStrips) t = *reinterpret_cast<const uint4 *>(p.stripWords + i0 + 4 * q);
-            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            const unsigned long long up = (unsigned long long)__shfl_up((long long)incl[q], off, 64);
+            if (lane >= off) incl[q] += up;
+          }
+        if (lane == 63)
+#pragma unroll
+          for (int q = 0; q < 8; q++) sPart[q * 16 + wave] = incl[q];
+        __syncthreads();
+        if (wave == 0)
+        { // exclusive prefix over the 128 partial sums (slab-major = strip order): a lane owns two neighbours
+          const unsigned long long a0 = sPart[2 * lane], a1 = sPart[2 * lane + 1];
+          unsigned long long in2 = a0 + a1;
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1)
+          {
+            const unsigned long long up = (unsigned long long)__shfl_up((long long)in2, off, 64);
+            if (lane >= off) in2 += up;
+          }
+          const unsigned long long ex = in2 - a0 - a1;
+          sPart[2 * lane] = ex; sPart[2 * lane + 1] = ex + a0;
+          if (lane == 63) sRound = in2;
+        }
+        __syncthreads();
+        const unsigned long long carry = sCarry;
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+        {
+          const uint32_t i0 = base + (uint32_t)q * 4096u + (uint32_t)tid * 4u;
+          // entry.payloadWord is 32 bits: the host refuses images whose worst-case payload would not fit (limg_hip_stream_bound)
+          const uint32_t e0 = (uint32_t)(carry + sPart[q * 16 + wave] + incl[q] - mine[q]);
+          const uint32_t e1 = e0 + v[q][0], e2 = e1 + v[q][1], e3 = e2 + v[q][2];
+          if (vec)
+          {
+            if (i0 < p.nStrips) *reinterpret_cast<uint4 *>(p.stripWords + i0) = make_uint4(e0, e1, e2, e3);
+          }
+          else
+          {
+            const uint32_t e[4] = { e0, e1, e2, e3 };
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+              if (i0 + k < p.nStrips) p.stripWords[i0 + k] = e[k];
           }
         }
-        else
-        {
-#pragma unroll
-          for (int k = 0; k < 32; k++) v[k] = i0 + k < p.nStrips ? p.stripWords[i0 + k] : 0u;
-        }
-        unsigned long long mine = 0;
-#pragma unroll
-        for (int k = 0; k < 32; k++) mine += v[k];
-        unsigned long long incl = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1)
-        {
-          const unsigned long long up = (unsigned long long)__shfl_up((long long)incl, off, 64);
-          if (lane >= off) incl += up;
-        }
-        if (lane == 63) sWave[wave] = incl;
         __syncthreads();
-        unsigned long long pre = sCarry;
-        for (int w = 0; w < wave; w++) pre += sWave[w];
-        uint32_t run = (uint32_t)(pre + incl - mine); // entry.payloadWord is 32 bits: the host refuses images whose worst-case payload would not fit (limg_hip_stream_bound)
-#pragma unroll
-        for (int k = 0; k < 32; k++) { const uint32_t t = v[k]; v[k] = run; run += t; }
-        if (vec)
-        {
-#pragma unroll
-          for (int q = 0; q < 8; q++)
-            if (i0 + 4 * q < p.nStrips) *reinterpret_cast<uint4 *>(p.stripWords + i0 + 4 * q) = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-        }
-        else
-        {
-#pragma unroll
-          for (int k = 0; k < 32; k++)
-            if (i0 + k < p.nStrips) p.stripWords[i0 + k] = v[k];
-        }
-        __syncthreads();
-        if (tid == 1023) sCarry = pre + incl;
+        if (tid == 0) sCarry = carry + sRound;
         __syncthreads();
       }
       if (tid == 0)

@@ -539,6 +539,32 @@ def test_host_entry_at_4096(gpu, oracle):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("pool", [0, 2, 3, 16])
+def test_host_entry_in_bands(gpu, oracle, pool):
+    """limg_hip_encode3d from 4 Mpixels on works in row bands (upload + kernels of band k + 1 under the download of band k; limg_hip_api.hip host_encode_banded): one
+    chain through the bands (poolThreads 0: the chain entry's two halves per band, bases on the device) and a band per restarted chain (poolThreads > 0,
+    src/limg.cpp:2114-2134; 16 threads = 64 chains of 4 block rows: the plain path).  Every plane == the device entry's single encode of the whole image."""
+    import torch
+    W, H = 4096, 2048
+    d_img = gpu.synth_device("photo_noise", W, H, seed=9)
+    img = d_img.cpu().numpy().view(np.uint32)
+    got = gpu.encode3d(img, True, pool_threads=pool)
+    planes = gpu.alloc_planes_device(W, H)
+    gpu.encode3d_device(d_img, True, planes, pool_threads=pool)
+    torch.cuda.synchronize()
+    gpu.check()
+    for k in PLANES:
+        dev = planes[k].cpu().numpy()
+        dev = dev.view(np.uint32) if dev.dtype == np.int32 else dev
+        assert np.array_equal(got[k], dev), (pool, k)
+    want = oracle.encode3d(np.ascontiguousarray(img[:64]), True)
+    if pool == 0:
+        for k in PLANES:
+            assert np.array_equal(got[k][:64], want[k]), k
+    del planes, d_img
+    torch.cuda.empty_cache()
+
+
 def test_repeat_determinism_at_4096(gpu):
     """The same 4096^2 gradient image 32 times through one context: every run must give the same planes.  Fast searches (2 trials per block) and 16 K work
     strips per image are what exposed a lost update in the persistent kernel (a late store zeroing an already parked shift word, about one strip in 500 K):
