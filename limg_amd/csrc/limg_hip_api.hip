@@ -129,6 +129,7 @@ struct limg_hip_context
   DevBuf hostWords;                              // ... per band its dither-call total and its chain base (one chain through the bands)
   DevBuf cmp;                                    // 8-byte accumulator of limg_hip_compare
   DevBuf bFlags, bBound;
+  DevBuf bOrder; // merged-block encoder: per batch the order its workgroups take the rectangles in
   DevBuf bMatch, bRegions, bOut, bPx, bFac, bNoise, bNoiseBase; // merged-block encoder: similarity bits, region table / results, scratch (gathered pixels, factor bytes), noise
   HostBuf hFlags;
   HostBuf hRec, hBits, hDesc, hOut, hNoise, hNoiseBase;
@@ -1059,7 +1060,7 @@ extern "C"
     (void)hipDeviceSynchronize();
     DevBuf *bufs[] = { &c->noiseStates, &c->invN, &c->records, &c->shifts, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->noiseCk, &c->stats, &c->lookback, &c->devStatus, &c->accTable, &c->commWords, &c->park, &c->batchTable, &c->in, &c->planes, &c->cmp,
                        &c->streamFac, &c->streamTiles, &c->streamUnits, &c->streamStatus, &c->streamBuf,
-                       &c->bFlags, &c->bBound, &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bFac, &c->bNoise, &c->bNoiseBase };
+                       &c->bFlags, &c->bBound, &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bFac, &c->bNoise, &c->bNoiseBase, &c->bOrder };
     for (DevBuf *b : bufs) b->release();
     HostBuf *hbufs[] = { &c->hFlags, &c->hRec, &c->hBits, &c->hDesc, &c->hOut, &c->hNoise, &c->hNoiseBase };
     for (HostBuf *b : hbufs) b->release();
@@ -1247,7 +1248,7 @@ extern "C"
     if (!c) return 0;
     const DevBuf *bufs[] = { &c->bCalls, &c->noiseStates, &c->records, &c->shifts, &c->invN, &c->stripCalls, &c->stripBase, &c->noise, &c->noiseDyn, &c->noiseCk, &c->lookback, &c->park, &c->batchTable, &c->stats,
                              &c->accTable, &c->devStatus, &c->commWords, &c->in, &c->planes, &c->cmp, &c->streamFac, &c->streamTiles, &c->streamUnits, &c->streamStatus, &c->streamBuf,
-                             &c->bFlags, &c->bBound, &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bFac, &c->bNoise, &c->bNoiseBase };
+                             &c->bFlags, &c->bBound, &c->bMatch, &c->bRegions, &c->bOut, &c->bPx, &c->bFac, &c->bNoise, &c->bNoiseBase, &c->bOrder };
     size_t sum = 0;
     for (const DevBuf *b : bufs) sum += b->cap;
     return sum;
@@ -1938,6 +1939,7 @@ extern "C"
     if ((r = c->bRegions.ensure(blocks * sizeof(RegionDesc))) != limg_hip_success) return r;
     if ((r = c->bOut.ensure(blocks * sizeof(RegionOut))) != limg_hip_success) return r;
     if ((r = c->bNoiseBase.ensure(blocks * 8 + 8)) != limg_hip_success) return r;
+    if ((r = c->bOrder.ensure(blocks * 4)) != limg_hip_success) return r;
     if ((r = c->bNoise.ensure(3 * px + 64)) != limg_hip_success) return r;
     if ((r = c->bPx.ensure(capMax * 4)) != limg_hip_success) return r;
     if ((r = c->bFac.ensure(capMax * 3)) != limg_hip_success) return r;
@@ -1994,11 +1996,13 @@ extern "C"
       uint64_t chain = kDitherSeed, noiseOff = 0;
       size_t callCount = 0;
       bool fin = false;
+      constexpr size_t kOrderFrom = 512; // batches from this many rectangles on get the device-side "large rectangles first" order (k_blocked_order)
       auto params_of = [&](const Batch &b) {
         BlockedParams q = bp;
         q.regions = (const RegionDesc *)c->bRegions.p + b.r0; q.nRegions = (uint32_t)(b.r1 - b.r0); q.regionBase = (uint32_t)b.r0;
         q.out = (RegionOut *)c->bOut.p + b.r0;
         q.noiseBase = (const unsigned long long *)c->bNoiseBase.p + b.r0;
+        q.order = (b.r1 - b.r0 >= kOrderFrom && TOPT(c, blocked_no_order) == 0) ? (uint32_t *)c->bOrder.p + b.r0 : nullptr; // (a small batch is one round of workgroups anyway)
         return q;
       };
       // Everything the merge has published since the last look goes to the GPU.  mayWait: nothing is left to walk, so wait for the merge.  Called at the top of
@@ -2036,7 +2040,7 @@ extern "C"
           hipStream_t bs = c->workStreams[nb.ev % kWorkStreams];
           bool ok = hipMemcpyAsync((RegionDesc *)c->bRegions.p + r0, desc + r0, n * sizeof(RegionDesc), hipMemcpyHostToDevice, bs) == hipSuccess;
           ok = ok && hipEventRecord(c->workTimers[4 * nb.ev], bs) == hipSuccess;
-          if (ok) { launch_blocked_fit_search(q, bs); ok = hipGetLastError() == hipSuccess; }
+          if (ok) { launch_blocked_order(q, bs); launch_blocked_fit_search(q, bs); ok = hipGetLastError() == hipSuccess; }
           ok = ok && hipEventRecord(c->workTimers[4 * nb.ev + 1], bs) == hipSuccess;
           ok = ok && hipMemcpyAsync(hOut + r0, (RegionOut *)c->bOut.p + r0, n * sizeof(RegionOut), hipMemcpyDeviceToHost, bs) == hipSuccess;
           ok = ok && hipEventRecord(c->workEvents[nb.ev], bs) == hipSuccess;

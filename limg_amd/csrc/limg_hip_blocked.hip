@@ -434,7 +434,7 @@ namespace limg_hip
     __global__ __launch_bounds__(64) void k_blocked_fit_search(const BlockedParams p)
     {
       __shared__ __attribute__((aligned(16))) float s_park[4][64 + 4]; // one chunk's unit vectors, slot-planar; plane stride 68 floats: the four walkers' 16-byte reads hit different banks
-      const uint32_t r = blockIdx.x;
+      const uint32_t r = p.order ? p.order[blockIdx.x] : blockIdx.x;
       const int lane = lane_id();
       const RegionDesc R = p.regions[r];
       const Geo g = region_geo(p, R);
@@ -719,10 +719,68 @@ namespace limg_hip
       }
     }
 
+    // Which rectangle each workgroup of a batch's launches takes: a launch of one wave per rectangle lives as long as its longest wave and workgroups are dispatched
+    // in index order, so the large rectangles -- more than four blocks: their three pixel-order walks are most of such a launch's life -- go FIRST, largest first
+    // (counting sort over the size in blocks), and everything else follows in creation order (raster locality).  Round 5 measured the ordering (k_blocked_fit_search
+    // -11 % on photo-noise) but built it on the worker thread, which is the thread that walks the dither chain: the image took longer, and it was dropped.  Here it is
+    // one small workgroup on the batch's own stream in front of the batch's kernel; the host does nothing.
+    __global__ __launch_bounds__(1024) void k_blocked_order(const BlockedParams p)
+    {
+      __shared__ uint32_t sBins[1024], sWaveSmall[16];
+      __shared__ uint32_t sLarge, sCarry;
+      const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+      const uint32_t n = p.nRegions;
+      sBins[tid] = 0;
+      if (tid == 0) sCarry = 0;
+      __syncthreads();
+      for (uint32_t i = tid; i < n; i += 1024)
+      {
+        const uint32_t nb = p.regions[i].rx * p.regions[i].ry;
+        if (nb > 4u) atomicAdd(&sBins[nb < 1023u ? nb : 1023u], 1u);
+      }
+      __syncthreads();
+      // first slot of every size class, largest class first: exclusive suffix sum over the bins (Hillis-Steele in LDS, the thread of bin b reads bin b + off)
+      uint32_t own = sBins[tid], suf = own;
+      for (int off = 1; off < 1024; off <<= 1)
+      {
+        __syncthreads();
+        sBins[tid] = suf;
+        __syncthreads();
+        if (tid + off < 1024) suf += sBins[tid + off];
+      }
+      __syncthreads();
+      sBins[tid] = suf - own; // rectangles in larger classes
+      if (tid == 0) sLarge = suf; // all large rectangles
+      __syncthreads();
+      const uint32_t nLarge = sLarge;
+      for (uint32_t base = 0; base < n; base += 1024)
+      {
+        const uint32_t i = base + tid;
+        uint32_t nb = 0;
+        if (i < n) nb = p.regions[i].rx * p.regions[i].ry;
+        const bool small = i < n && nb <= 4u;
+        if (i < n && !small) p.order[atomicAdd(&sBins[nb < 1023u ? nb : 1023u], 1u)] = i; // (within a class the order does not matter)
+        const uint64_t m = __builtin_amdgcn_ballot_w64(small);
+        if (lane == 0) sWaveSmall[wave] = (uint32_t)__builtin_popcountll(m);
+        __syncthreads();
+        uint32_t before = sCarry;
+        for (int w = 0; w < wave; w++) before += sWaveSmall[w];
+        if (small) p.order[nLarge + before + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+        if (tid == 0)
+        {
+          uint32_t t = sCarry;
+          for (int w = 0; w < 16; w++) t += sWaveSmall[w];
+          sCarry = t;
+        }
+        __syncthreads();
+      }
+    }
+
     template <int CH>
     __global__ __launch_bounds__(64) void k_blocked_store(const BlockedParams p)
     {
-      const uint32_t r = blockIdx.x;
+      const uint32_t r = p.order ? p.order[blockIdx.x] : blockIdx.x;
       const int lane = lane_id();
       const RegionDesc R = p.regions[r];
       const Geo g = region_geo(p, R);
@@ -846,6 +904,12 @@ namespace limg_hip
     if (p.nRegions == 0) return;
     if (p.channels == 4) hipLaunchKernelGGL(k_blocked_fit_search<4>, dim3(p.nRegions), dim3(64), 0, s, p);
     else hipLaunchKernelGGL(k_blocked_fit_search<3>, dim3(p.nRegions), dim3(64), 0, s, p);
+  }
+
+  void launch_blocked_order(const BlockedParams &p, hipStream_t s)
+  {
+    if (p.nRegions == 0 || !p.order) return;
+    hipLaunchKernelGGL(k_blocked_order, dim3(1), dim3(1024), 0, s, p);
   }
 
   void launch_blocked_store(const BlockedParams &p, hipStream_t s)

@@ -161,6 +161,7 @@ namespace limg_hip
     uint32_t nRegions;
     uint32_t regionBase;       // index of regions[0] in creation order (block index = regionBase + r + 1)
     RegionOut *out;
+    uint32_t *order;           // per launch (or NULL): the rectangle each workgroup takes -- large ones first (k_blocked_order)
     uint32_t *scratchPx; // gathered pixels, region-major (src/limg.cpp:1747-1748)
     uint8_t *scratchFac; // 3 planes of scratchCap bytes: pre-dither factor bytes
     uint32_t scratchCap;
@@ -173,6 +174,7 @@ namespace limg_hip
   void launch_blocked_match(const BlockedParams &p, hipStream_t s);
   void launch_blocked_fit_search(const BlockedParams &p, hipStream_t s);
   void launch_blocked_store(const BlockedParams &p, hipStream_t s);
+  void launch_blocked_order(const BlockedParams &p, hipStream_t s);
 
   // host side of the merged-block encoder (limg_hip_blocked_host.cpp): the greedy raster merge and the dither chain walk
   struct HostRegion { uint32_t ox, oy, rx, ry, keep; };

@@ -283,17 +283,23 @@ namespace limg_hip
             for (int k = 0; k < 4; k++) v[q][k] = i0 + k < p.nStrips ? p.stripWords[i0 + k] : 0u;
           }
         }
-        unsigned long long mine[8], incl[8];
+        // (a slab's 4096 strips hold at most 4096 x 32 x 24 words: 32 bits, and the wave scans are DPP adds -- eight 64-bit shuffle scans per wave went through the
+        // one LDS of the CU this kernel runs on and cost as much as everything else in it)
+        uint32_t mine[8], incl[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) incl[q] = mine[q] = (unsigned long long)v[q][0] + v[q][1] + v[q][2] + v[q][3];
+        for (int q = 0; q < 8; q++) incl[q] = mine[q] = v[q][0] + v[q][1] + v[q][2] + v[q][3];
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1)
-#pragma unroll
-          for (int q = 0; q < 8; q++)
-          {
-            const unsigned long long up = (unsigned long long)__shfl_up((long long)incl[q], off, 64);
-            if (lane >= off) incl[q] += up;
-          }
+        for (int q = 0; q < 8; q++)
+        {
+          int x = (int)incl[q];
+          x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false); // row_shr:1
+          x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false); // row_shr:2
+          x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false); // row_shr:4
+          x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false); // row_shr:8
+          x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false); // row_bcast:15 into rows 1 and 3
+          x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false); // row_bcast:31 into rows 2 and 3
+          incl[q] = (uint32_t)x;
+        }
         if (lane == 63)
 #pragma unroll
           for (int q = 0; q < 8; q++) sPart[q * 16 + wave] = incl[q];

@@ -171,3 +171,28 @@ def test_giant_rectangle(gpu, oracle):
     got = gpu.blocked_encode3d(img, True)
     bad = [(k, int((got[k] != want[k]).sum())) for k in BLOCKED_WRITTEN if not np.array_equal(got[k], want[k])]
     assert not bad, bad
+
+
+def test_large_first_order_changes_nothing(gpu, oracle):
+    """k_blocked_order (batches from 512 rectangles on: large rectangles first, counting sort by size, the rest in creation order) only changes which workgroup takes
+    which rectangle: a 2048 x 1024 image of noise with flat and gradient patches (tens of thousands of rectangles of every size) with and without it (test hook
+    blocked_no_order) -- every plane equal, and equal to the oracle."""
+    import torch
+    W, H = 2048, 1024
+    img = oracle.photo_noise(W, H, 5)
+    img[128:640, 256:1280] = oracle.random_gradient(1024, 512, 6, True)
+    img[700:900, 1400:2000] = np.uint32(0xFF406080)
+    want = oracle.blocked_encode3d(img, True)
+    sizes = want["regions"]["rx"] * want["regions"]["ry"]
+    assert len(want["regions"]) > 4096 and int(sizes.max()) > 16 and int((sizes > 4).sum()) > 50
+    outs = {}
+    for no_order in (False, True):
+        gpu.set_options(test_blocked_no_order=no_order)
+        try:
+            outs[no_order] = gpu.blocked_encode3d(img, True)
+        finally:
+            gpu.set_options()
+    for k in BLOCKED_WRITTEN:
+        assert np.array_equal(outs[False][k], want[k]), ("ordered", k)
+        assert np.array_equal(outs[True][k], want[k]), ("creation order", k)
+    gpu.check()
