@@ -33,13 +33,13 @@ HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 
 # Counter-derived figures (HBM traffic, VALU instructions per block) come from profiles/pmc_by_workload.json, keyed by workload and written by
 # tools/prof_summary.py from separate rocprofv3 --pmc passes of this very command; a workload without an entry prints null -- never a stale number.
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_by_workload.json")
-# Measured VALU issue ceilings of the chip, wave64 instructions per second (profiles/r02_valu_ceiling.md, tools/valu_ceiling.hip, 5 waves per SIMD):
+# Measured VALU issue ceilings of the chip, wave64 instructions per second (profiles/archive/r02_valu_ceiling.md, tools/valu_ceiling.hip, 5 waves per SIMD):
 # full-rate class (v_add/mul/fma_f32, v_add_u32, logic ops ...) and half-rate class (v_mad_i32_i24, v_pk_*, VOP3-only, DPP, v_cvt_* ... -- what this path is made of)
 VALU_FULL_RATE_PER_S = 960e9
 VALU_HALF_RATE_PER_S = 578e9
 
 
-PMC_ROUND = "r05"   # the round whose kernels this file benches: a counter entry measured on another round's build is refused (lines that quoted round-2 counters for round-3 kernels)
+PMC_ROUND = "r06"   # the round whose kernels this file benches: a counter entry measured on another round's build is refused (lines that quoted round-2 counters for round-3 kernels)
 
 
 # Every leg that fails is recorded here, printed on the line (`errors`) and turns the exit status non-zero: a bench line must not look healthy while one of its
@@ -179,7 +179,7 @@ def pmc_stale_source(key):
 
 def instruction_floor(pmc, algo_bytes):
     """The fraction of the HBM roofline this instruction count could reach if the kernels issued at the chip's measured rate for their instruction class
-    (profiles/r02_valu_ceiling.md): algorithmic bytes / (VALU instructions per launch / ceiling) / peak.  The distance between `frac` and this number is what
+    (profiles/archive/r02_valu_ceiling.md): algorithmic bytes / (VALU instructions per launch / ceiling) / peak.  The distance between `frac` and this number is what
     scheduling can still recover; the distance between this number and 1 only fewer instructions can."""
     if not pmc or not pmc.get("valu_instr_per_launch"):
         return None
@@ -1136,7 +1136,7 @@ def main():
                     "issue_peak_half_rate_class": VALU_HALF_RATE_PER_S / 1e9, "issue_peak_full_rate_class": VALU_FULL_RATE_PER_S / 1e9,
                     "frac": round(rate / VALU_HALF_RATE_PER_S, 4), "valu_busy": pmc.get("valu_busy"), "source": pmc.get("source"),
                     "note": "frac = issued wave64 VALU instructions per second / the measured chip-wide rate of the half-rate instruction class (v_mad_i32_i24, v_pk_*, "
-                            "VOP3-only, DPP, v_cvt_*: profiles/r02_valu_ceiling.md); the kernel's mix holds some full-rate f32 adds, so frac can approach but not pass "
+                            "VOP3-only, DPP, v_cvt_*: profiles/archive/r02_valu_ceiling.md); the kernel's mix holds some full-rate f32 adds, so frac can approach but not pass "
                             "the full-rate peak"}
         line = {
             "metric": "encode Mpixels/s, 8K RGBA (limg_encode3d_test-equivalent: all 11 planes stored)",

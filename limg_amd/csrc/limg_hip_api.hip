@@ -642,7 +642,7 @@ namespace
     // the persistent kernel of sub-batch k.  On content with short searches (BASELINE configs 2 / 4: ~2 trials per block) the persistent kernel waits for its plane
     // stores a third of the time while k_fit_tpb is pure vector work: side by side they fill each other's gaps.  The persistent kernel leaves the float stage room
     // to be resident: 5 workgroups per CU instead of 6 (at 6 x 80 VGPRs nothing else fits on a SIMD) for every sub-batch but the last.
-    // Measured on 4096^2 random-gradient lists (profiles/r04_pipeline_sweep.md): 64 images 66.5 -> 73.3 Gpixel/s in sub-batches of 8 (4: 70.9, 16: 71.9); 16 images
+    // Measured on 4096^2 random-gradient lists (profiles/archive/r04_pipeline_sweep.md): 64 images 66.5 -> 73.3 Gpixel/s in sub-batches of 8 (4: 70.9, 16: 71.9); 16 images
     // +3.5 % in sub-batches of 4; 8 images and fewer: nothing to gain (the lone first float stage and the 5-workgroup launches cost what the overlap saves).
     size_t subImages = 0;
     if (fused && batchCount > 1 && p.prefit)
@@ -1959,7 +1959,7 @@ extern "C"
     limg_hip_result workerResult = limg_hip_success;
     double busy[3] = { 0, 0, 0 }; // worker: fit + search (incl. copies), chain walk, store launch
     const bool pcg = c->opt.dither_pcg != 0;
-    // One batch = everything the merge has published when the worker looks; one stream for the fit + search kernels.  Measured on one box (profiles/r04_blocked_pipeline.md):
+    // One batch = everything the merge has published when the worker looks; one stream for the fit + search kernels.  Measured on one box (profiles/archive/r04_blocked_pipeline.md):
     // batches capped at 8 K ... 64 K rectangles, two or four streams round-robin, a high-priority stream -- all within +-2 ms of this, most of them worse: the GPU
     // (similarity kernels 13 ms + fit / search kernels 13 ms per 8192^2 image) is as busy as the two host threads, so reordering its queue buys nothing.
     constexpr size_t kBatchRegions = (size_t)1 << 30;

@@ -477,7 +477,7 @@ namespace limg_hip
         // from chunk to chunk in the walker lanes' registers, so the order of the additions is the reference's whatever the rectangle's size, and nothing is parked in
         // global memory.  (Rounds 1-4 parked ALL N vectors of a pass in global scratch and walked them afterwards: 96 of the kernel's 117 bytes of HBM traffic per
         // pixel, and every walk a chain of global-memory round trips -- ~160 cycles per four terms, later ~40 with sixteen terms requested ahead; a batch's kernel
-        // ends with its largest rectangle, whose three walks were most of its life.  Counters: profiles/r05_final_blocked_summary.txt.)
+        // ends with its largest rectangle, whose three walks were most of its life.  Counters: profiles/archive/r05_final_blocked_summary.txt.)
         float walk = 0.0f; // lanes 0..3: the running sum of their slot plane
         auto park_and_walk = [&](const V4 &u, uint32_t count /* pixels of this chunk, 1..64: wave-uniform */) {
           s_park[0][lane] = u.a.x; s_park[1][lane] = u.a.y; s_park[2][lane] = u.b.x; s_park[3][lane] = u.b.y;

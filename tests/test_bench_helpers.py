@@ -67,7 +67,7 @@ def test_source_sha_is_stable_and_sees_the_kernels():
 def _final_lines():
     import glob
     out = []
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_bench_final*.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "%s_bench_final*.json" % bench.PMC_ROUND))):
         for raw in open(f):
             if raw.strip().startswith("{"):
                 out.append((os.path.basename(f), json.loads(raw)))
@@ -75,10 +75,10 @@ def _final_lines():
 
 
 def test_final_bench_lines_are_one_build_without_failed_legs():
-    """Evidence that cannot go stale silently: every `profiles/r05_bench_final*.json` line carries the build it was measured on; all of them were measured on ONE
+    """Evidence that cannot go stale silently: every `profiles/<round>_bench_final*.json` line carries the build it was measured on; all of them were measured on ONE
     build (same lib_sha, same src_sha) and none has a failed leg or an "error" anywhere."""
     lines = _final_lines()
-    assert lines, "no profiles/r05_bench_final*.json yet"
+    assert lines, "no profiles/%s_bench_final*.json yet" % bench.PMC_ROUND
     shas = {(l.get("lib_sha"), l.get("src_sha")) for _, l in lines}
     assert len(shas) == 1 and None not in next(iter(shas)), shas
     for name, l in lines:
@@ -90,7 +90,7 @@ def test_final_bench_lines_are_one_build_without_failed_legs():
 def test_profiles_index_is_current():
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "profiles_index.py"), "--check"])
-    assert r.returncode == 0, "profiles/README.md's round-5 index is out of date: run python tools/profiles_index.py"
+    assert r.returncode == 0, "profiles/README.md's index of this round's bench lines is out of date: run python tools/profiles_index.py"
 
 
 def test_isa_budget_tool_runs():

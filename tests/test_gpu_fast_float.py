@@ -3,7 +3,7 @@ SURVEY.md 8(c):
   Stage F (a4-a8)  : int16 extrema within +-2 LSB of the EXACT mode's on >= 99.9 % of blocks; end-to-end perceptual PSNR within 0.10 dB of EXACT.
                      One stated exception, measured not assumed: the THIRD direction of 4-channel synthetic gradients.  With opaque alpha a gradient block spans
                      two colour directions, so pass 3 fits a direction to the rounding residue of passes 1-2; any change of the arithmetic moves it -- the
-                     reference's own -ffast-math build differs from its strict build there on 0.3 % of the blocks by up to 21 LSB (profiles/r02_fast_float.md) at
+                     reference's own -ffast-math build differs from its strict build there on 0.3 % of the blocks by up to 21 LSB (profiles/archive/r02_fast_float.md) at
                      identical PSNR.  For those images the C extrema get >= 95 % of blocks instead of 99.9 % (measured: 96.2 %); A and B keep 99.9 % everywhere;
   Stage I (a9-a16) : bit-exact GIVEN the records and factor bytes the float stage produced -- checked here by feeding the GPU's own FAST-mode records and
                      pre-dither factor bytes to the oracle's integer stage (search, dither chain, plane packing, decode) block by block.

@@ -6,7 +6,7 @@ functions below decides.  A phase's static count is divided by the number of inl
 blocks with masked lanes --, the F step's per-factor body six times ...), which gives the instructions of ONE execution; the last column multiplies by how often a
 block executes the phase.  The dynamic totals (rocprofv3 SQ_INSTS_VALU / _SALU / _LDS per kernel, split path: one kernel per step) are printed next to the sums.
 
-usage: python tools/isa_budget.py [--pmc gpurun_out/profiles/pmc_by_workload.json] > profiles/r04_isa_budget.md"""
+usage: python tools/isa_budget.py [--pmc gpurun_out/profiles/pmc_by_workload.json] > profiles/archive/r04_isa_budget.md"""
 import argparse
 import collections
 import json
@@ -233,7 +233,7 @@ def main():
     print("\nThe static columns count every instruction of a phase's code, whichever way its branches go.  For straight-line vector code that is what executes; for scalar code it")
     print("is an UPPER BOUND -- guards (`if (e[0] & 0x20) rebuild_A`), both tails of the trial, both copies of the search loop, the generic-path and alpha branches of the F step")
     print("are all in the count although a block runs one side of each.  The scalar column is therefore not a budget; what can be checked is the two aggregates the counters")
-    print("measure directly (`profiles/r04_isa_calibration.md`): the block with the search bypassed, and the all-in cost of a trial.\n")
+    print("measure directly (`profiles/archive/r04_isa_calibration.md`): the block with the search bypassed, and the all-in cost of a trial.\n")
     try:
         cal = json.load(open(args.calibration))
         search_rows = [n for n in acc if n.startswith("search:")]

@@ -6,7 +6,7 @@ Input: rocprofv3 --pmc SQ_INSTS_VALU / _SALU / _LDS of the default bench on work
 search bypassed with forced shifts 0 and 4) + the per-block statistics of those workloads from the oracle (tools/search_stats.py).  Model, per 8x8 block:
     count = c0 + cT * trials + cR * real factor rebuilds + c8 * rebuilds to shift 8 + cS * block-error sums + cD * dithered factors
 Least squares over the workloads, for each of VALU / SALU / LDS; prints the coefficients, the per-workload residuals, and the headline workload's break-down.
-usage: python tools/isa_calibrate.py gpurun_out/r04_calib profiles/r04_search_stats.json"""
+usage: python tools/isa_calibrate.py gpurun_out/r04_calib profiles/archive/r04_search_stats.json"""
 import csv
 import glob
 import json

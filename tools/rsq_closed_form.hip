@@ -1,5 +1,5 @@
 // rsq_closed_form.hip -- experiment: the captured x86 RSQRTPS table equals round((2 / sqrt(x_mid) - 1) * 4096) for every one of its 2048 entries (x_mid = midpoint of
-// the 10-bit mantissa interval; checked in double precision by tools/isa... see profiles/r02_rsqrt_closed_form.md).  Can the GPU recompute the entry instead of
+// the 10-bit mantissa interval; checked in double precision by tools/isa... see profiles/archive/r02_rsqrt_closed_form.md).  Can the GPU recompute the entry instead of
 // gathering it?  This program evaluates candidate instruction sequences for all 2048 indices on the device and counts mismatches against the table.
 #include <hip/hip_runtime.h>
 #include <cstdio>

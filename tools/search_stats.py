@@ -2,7 +2,7 @@
 """Per-block statistics of the default shift search on the synthetic photo-noise workload, for tools/isa_budget.py's calibration: trials, factor rebuilds
 (real ones and those to shift 8 of factors B / C, which cost two moves), block-error sums (trials no pixel fails), dither calls -- per errorFactor.
 CPU only (the oracle's trial as the outcome function of the literal restatement of the reference's search, tools/make_search_table.py); test infrastructure.
-usage: python tools/search_stats.py [--blocks 1500] > profiles/r04_search_stats.json"""
+usage: python tools/search_stats.py [--blocks 1500] > profiles/archive/r04_search_stats.json"""
 import argparse
 import json
 import os
