@@ -1185,6 +1185,11 @@ def main():
                 line["config"]["multi_context"] = multi_context_rate(img, W, H, args, args.contexts)
             except Exception as e:
                 line["config"]["multi_context"] = leg_failed("multi_context", e)
+        if n_gpus == 1 and not args.no_host_rate and not (args.split or args.compact or ragged):
+            try:  # what a per-request service pays that makes a context per image: init + first encode (noise table, scratch) + shutdown
+                line["config"]["cold_context_per_image"] = cold_context_rate(dev, img, planes, W, H, args)
+            except Exception as e:
+                line["config"]["cold_context_per_image"] = leg_failed("cold_context_per_image", e)
         if n_gpus == 1 and not args.no_host_rate:
             try:
                 line["config"]["host_entry"] = host_entry_rate(g, W, H, args)
@@ -1376,6 +1381,26 @@ def multi_context_rate(img, W, H, args, K, n_each=6):
         raise RuntimeError("multi-context run failed: %r, outputs identical: %s" % (errs, same))
     n_img = K * n_each
     return {"contexts": K, "images": n_img, "ms_per_image": round(dt * 1e3 / n_img, 4), "Mpixels_per_s": round(n_img * W * H / dt / 1e6, 1), "outputs_identical": same}
+
+
+def cold_context_rate(dev, img, planes, W, H, args, n=4):
+    """limg_hip_init + ONE encode + limg_hip_shutdown per image, device-resident planes: the whole life of a context per request"""
+    import torch
+    import limg_amd
+    ts, nbytes = [], 0
+    for _ in range(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        c = limg_amd.LimgHip(dev)
+        c.set_options(float_fast=(args.float_mode == "fast"))
+        c.encode3d_device(img, not args.rgb, planes, error_factor=args.error_factor, pool_threads=args.pool_threads, fast=not args.accurate)
+        torch.cuda.synchronize()
+        c.check()
+        nbytes = c.device_bytes()
+        c.close()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return {"ms_per_image": round(min(ts), 3), "ms_all": [round(t, 2) for t in ts], "Mpixels_per_s": round(W * H / min(ts) / 1e3, 1), "context_device_bytes": int(nbytes),
+            "note": "init + first encode (dither noise table filled on the GPU, scratch allocated) + shutdown, per image; a warm context does the same encode in ms_per_step"}
 
 
 def host_entry_rate(g, W, H, args):

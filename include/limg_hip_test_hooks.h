@@ -35,8 +35,6 @@ typedef struct limg_hip_test_options
                                  chain times out (see limg_hip_check_device_status: such strips store nothing that depends on the chain) */
   int32_t blocked_no_order;   /* A/B, non-0: the merged-block encoder's per-rectangle launches take the rectangles in creation order instead of large-first
                                  (k_blocked_order, limg_hip_blocked.hip).  Same planes either way */
-  int32_t accurate_mapping;   /* A/B of the accurate search's kernel mapping: 0 = the product's choice, 1 = one block per wave (the fast search's mapping), 2 = four
-                                 blocks per wave with early exit per quarter wave */
 } limg_hip_test_options;
 
 void limg_hip_default_test_options_sized(limg_hip_test_options *pOptions, size_t structSize);

@@ -79,6 +79,10 @@ def main():
     rows.append("| two contexts on two streams, images alternating / first encode of a fresh context / `_perf` style (E step only) | %.3f per image / %.1f / %.3f | %s / — / %s | | `r06_bench_final.json` `config.two_streams`, `first_encode_ms`, `perf_style_ms` |"
                 % (cfg["two_streams"]["ms_per_image"], cfg["first_encode_ms"], cfg["perf_style_ms"], "{:,.0f}".format(cfg["two_streams"]["Mpixels_per_s"]).replace(",", " "),
                    "{:,.0f}".format(cfg["perf_style_Mpixels_per_s"]).replace(",", " ")))
+    cc = cfg.get("cold_context_per_image")
+    if cc:
+        rows.append("| a context per image: init + one encode + shutdown | %.2f | %s | (context: %.0f MB of device memory) | `r06_bench_final.json` `config.cold_context_per_image` |"
+                    % (cc["ms_per_image"], "{:,.0f}".format(cc["Mpixels_per_s"]).replace(",", " "), cc["context_device_bytes"] / 1e6))
     text = "\n".join(rows)
     if "--write" in sys.argv:
         p = os.path.join(ROOT, "DESIGN.md")
