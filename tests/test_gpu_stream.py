@@ -80,6 +80,25 @@ def test_device_roundtrip_full_size(gpu):
         del planes, st, dec
 
 
+def test_more_strips_than_one_scan_round(gpu):
+    """8192 x 8448 = 33 792 work strips: the strip scan of the packer (k_stream_scan_strips: 32 K strips per round, carry between rounds) takes its second round;
+    2056 x 4104 = 9 x 513 strips: the scalar (not a multiple of 4) path of the same kernel with a partial last strip per row.  decode(encode) == pDecoded on the device."""
+    import torch
+    for W, H in ((8192, 8448), (2056, 4104)):
+        img = gpu.synth_device("photo_noise", W, H, seed=3)
+        planes = gpu.alloc_planes_device(W, H)
+        gpu.encode3d_device(img, True, planes)
+        st, nbytes = gpu.encode_stream_device(img, True)
+        dec = gpu.decode_stream_device(st, nbytes, W, H)
+        torch.cuda.synchronize()
+        gpu.check()
+        assert torch.equal(dec, planes["pDecoded"]), (W, H)
+        hdr = st[:64].cpu().numpy().view(S.HEADER)[0]
+        assert int(hdr["totalBytes"]) == nbytes and int(hdr["sizeX"]) == W and int(hdr["sizeY"]) == H
+        del planes, st, dec, img
+        torch.cuda.empty_cache()
+
+
 def test_refuses_bad_streams(gpu, oracle):
     import limg_amd
     img = oracle.photo_noise(64, 64, 3)
