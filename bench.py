@@ -1294,7 +1294,12 @@ def collective_evidence(g, dist, rank, world, timeout_s=120.0):
     # collective issued beside it -- by this rank or by the ranks whose helper came back -- can hang the job the time limit was meant to protect.  The
     # views travel through the process group's store (TCP); a rank that cannot be heard from within the limit counts as hung.
     mine = [info["ranks"], info["rank"], info["rccl_version"], 1 if th.is_alive() else 0]
-    views = exchange_views(dist, rank, world, mine, timeout_s)
+    try:
+        views = exchange_views(dist, rank, world, mine, timeout_s)
+    except Exception as e:  # noqa: BLE001  (evidence must never sink the measurement)
+        ev["error"] = "views could not be exchanged over the store: %r" % (e,)
+        leg_warned("collective_evidence", ev["error"])
+        views = [list(mine) if r == rank else [-1, r, -1, 1] for r in range(world)]
     if any(v[3] for v in views):
         global COLLECTIVES_OFF
         COLLECTIVES_OFF = True  # no RCCL call of this job is safe any more: the callers skip the gather, the process leaves without destroy_process_group

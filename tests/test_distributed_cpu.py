@@ -112,3 +112,36 @@ def test_variable_size_stream_gather(tmp_path, world):
     port = _free_port()
     mp.spawn(_bytes_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert os.path.exists(os.path.join(str(tmp_path), "ok"))
+
+
+def _views_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    # every rank's view travels through the process group's store: no collective on the group (what bench.collective_evidence does after its helper thread,
+    # which may still sit inside RCCL, has been given up on)
+    views = bench.exchange_views(dist, rank, world, [world, rank, 22605, 1 if rank == 1 else 0], timeout_s=20.0)
+    assert [v[1] for v in views] == list(range(world)) and [v[3] for v in views] == [1 if r == 1 else 0 for r in range(world)], views
+    # a second exchange uses fresh keys
+    again = bench.exchange_views(dist, rank, world, [0, rank, 0, 0], timeout_s=20.0)
+    assert [v[0] for v in again] == [0] * world and [v[1] for v in again] == list(range(world)), again
+    # a rank that never answers is reported as hung, within the limit
+    if rank == 0:
+        import time
+        t0 = time.time()
+        late = bench.exchange_views(dist, rank, world, [1, 0, 1, 0], timeout_s=1.0)
+        assert time.time() - t0 < 10 and late[0][:2] == [1, 0] and all(v[3] == 1 for v in late[1:]), late
+        open(os.path.join(tmp, "ok"), "w").write("ok")
+    else:
+        import time
+        time.sleep(3.0)  # (does not take part in the third exchange)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_evidence_views_travel_over_the_store(tmp_path, world):
+    """bench.py --gpus N: after the RCCL evidence helper of ANY rank may have hung, the ranks agree on what they saw without another collective."""
+    mp.spawn(_views_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), "ok"))
