@@ -596,7 +596,7 @@ def run_blocked(args, g, dist, rank, world, W, H):
     import numpy as np
     if args.forced_shift >= 0:  # (kernel-time experiments: the per-rectangle search bypassed)
         g.set_options(forced_shift=(args.forced_shift,) * 3)
-    blocked_opts = dict(test_blocked_no_bound=args.no_match_bound, test_blocked_no_order=args.no_order)
+    blocked_opts = dict(test_blocked_no_bound=args.no_match_bound, test_blocked_no_order=args.no_order, test_blocked_no_vec_store=args.no_vec_store)
     if args.forced_shift >= 0:
         blocked_opts["forced_shift"] = (args.forced_shift,) * 3
     g.set_options(**blocked_opts)
@@ -919,6 +919,7 @@ def main():
     ap.add_argument("--blocked", action="store_true", help="merged-block encoder limg_blocked_encode3d_test (SURVEY 8(f) #1): GPU kernels + host merge / chain walk")
     ap.add_argument("--images", type=int, default=64, help="--config 4: images in the batch")
     ap.add_argument("--no-match-bound", action="store_true", help="--blocked: limg_hip_options.test_blocked_no_bound (A/B: the similarity kernel without its certain-match bound)")
+    ap.add_argument("--no-vec-store", action="store_true", help="--blocked A/B (LIMG_HIP_LIB=test): k_blocked_store with one pixel per lane instead of four")
     ap.add_argument("--no-order", action="store_true", help="--blocked A/B (LIMG_HIP_LIB=test): the per-rectangle launches take the rectangles in creation order instead of large-first (k_blocked_order)")
     ap.add_argument("--contexts", type=int, default=1, help="--blocked: also time a stream of images pipelined over this many contexts / host threads on the one GPU; "
                     "--config 4: spread the rank's images round-robin over this many contexts / HIP streams")

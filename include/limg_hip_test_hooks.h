@@ -35,6 +35,7 @@ typedef struct limg_hip_test_options
                                  chain times out (see limg_hip_check_device_status: such strips store nothing that depends on the chain) */
   int32_t blocked_no_order;   /* A/B, non-0: the merged-block encoder's per-rectangle launches take the rectangles in creation order instead of large-first
                                  (k_blocked_order, limg_hip_blocked.hip).  Same planes either way */
+  int32_t blocked_no_vec_store; /* A/B, non-0: the merged-block encoder's store kernel keeps one pixel per lane (what images with partial edge blocks always use) */
 } limg_hip_test_options;
 
 void limg_hip_default_test_options_sized(limg_hip_test_options *pOptions, size_t structSize);

@@ -73,7 +73,7 @@ class TestOptions(C.Structure):
     """include/limg_hip_test_hooks.h -- liblimg_hip_test.so only"""
     _fields_ = [("struct_size", C.c_uint32), ("record_limit", C.c_int32), ("batch_chunk", C.c_int32), ("wg_per_cu", C.c_int32), ("whole_image_ragged", C.c_int32),
                 ("pipeline", C.c_int32), ("fail_chain_phase1", C.c_int32), ("blocked_no_bound", C.c_int32), ("lookback_spins", C.c_int32), ("base_error_strip", C.c_int32),
-                ("skip_publish_strip", C.c_int32), ("blocked_no_order", C.c_int32)]
+                ("skip_publish_strip", C.c_int32), ("blocked_no_order", C.c_int32), ("blocked_no_vec_store", C.c_int32)]
 
 
 def load_library(path=None):

@@ -1953,6 +1953,17 @@ extern "C"
     uint32_t *dCallPx = (uint32_t *)(dCallOff + maxCalls);
     std::vector<uint32_t> npx(blocks);
     bp.scratchPx = (uint32_t *)c->bPx.p; bp.scratchFac = (uint8_t *)c->bFac.p; bp.scratchCap = (uint32_t)capMax;
+    {
+      // k_blocked_store's 4-pixels-per-lane form: whole blocks (every rectangle row is a multiple of 8 pixels, every scratch / noise offset a multiple of 4) and planes
+      // whose rows start 16-byte (32-bit planes) / 4-byte (byte planes) aligned
+      const limg_hip_blocked_encode3d_info &bi = bp.info;
+      uintptr_t w = 0, b8 = 0;
+      const void *words[] = { bi.pDecoded, bi.pShiftABCX, bi.pColAMin, bi.pColAMax, bi.pColBMin, bi.pColBMax, bi.pColCMin, bi.pColCMax, bi.pBlockIndex };
+      const void *bytes[] = { bi.pFactorsA, bi.pFactorsB, bi.pFactorsC, bi.pBitsPerPixel };
+      for (const void *q : words) w |= (uintptr_t)q;
+      for (const void *q : bytes) b8 |= (uintptr_t)q;
+      bp.vecStore = (sizeX % kBlock == 0 && sizeY % kBlock == 0 && (w & 15u) == 0 && (b8 & 3u) == 0 && TOPT(c, blocked_no_vec_store) == 0) ? 1 : 0;
+    }
     bp.noise = (const uint8_t *)c->bNoise.p;
 
     struct Pipe { std::mutex m; std::condition_variable cv; size_t ready = 0; bool finished = false; } pipe;

@@ -161,6 +161,7 @@ namespace limg_hip
     uint32_t nRegions;
     uint32_t regionBase;       // index of regions[0] in creation order (block index = regionBase + r + 1)
     RegionOut *out;
+    int32_t vecStore;          // k_blocked_store: 4 pixels per lane, 16-byte plane stores (image of whole blocks, sizeX % 4 == 0, every plane suitably aligned)
     uint32_t *order;           // per launch (or NULL): the rectangle each workgroup takes -- large ones first (k_blocked_order)
     uint32_t *scratchPx; // gathered pixels, region-major (src/limg.cpp:1747-1748)
     uint8_t *scratchFac; // 3 planes of scratchCap bytes: pre-dither factor bytes

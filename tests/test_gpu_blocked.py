@@ -173,7 +173,7 @@ def test_giant_rectangle(gpu, oracle):
     assert not bad, bad
 
 
-def test_large_first_order_changes_nothing(gpu, oracle):
+def test_large_first_order_and_vector_stores_change_nothing(gpu, oracle):
     """k_blocked_order (batches from 512 rectangles on: large rectangles first, counting sort by size, the rest in creation order) only changes which workgroup takes
     which rectangle: a 2048 x 1024 image of noise with flat and gradient patches (tens of thousands of rectangles of every size) with and without it (test hook
     blocked_no_order) -- every plane equal, and equal to the oracle."""
@@ -186,13 +186,14 @@ def test_large_first_order_changes_nothing(gpu, oracle):
     sizes = want["regions"]["rx"] * want["regions"]["ry"]
     assert len(want["regions"]) > 4096 and int(sizes.max()) > 16 and int((sizes > 4).sum()) > 50
     outs = {}
-    for no_order in (False, True):
-        gpu.set_options(test_blocked_no_order=no_order)
+    for no_order, no_vec in ((False, False), (True, False), (False, True)):
+        gpu.set_options(test_blocked_no_order=no_order, test_blocked_no_vec_store=no_vec)
         try:
-            outs[no_order] = gpu.blocked_encode3d(img, True)
+            outs[(no_order, no_vec)] = gpu.blocked_encode3d(img, True)
         finally:
             gpu.set_options()
     for k in BLOCKED_WRITTEN:
-        assert np.array_equal(outs[False][k], want[k]), ("ordered", k)
-        assert np.array_equal(outs[True][k], want[k]), ("creation order", k)
+        assert np.array_equal(outs[(False, False)][k], want[k]), ("ordered, four pixels per lane in the store kernel (the product's path)", k)
+        assert np.array_equal(outs[(True, False)][k], want[k]), ("creation order", k)
+        assert np.array_equal(outs[(False, True)][k], want[k]), ("one pixel per lane in the store kernel", k)
     gpu.check()

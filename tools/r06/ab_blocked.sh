@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/${1:-r06h}; mkdir -p $OUT
 export LIMG_HIP_LIB=test
 for rep in 1 2; do
-  for o in "" "--no-order"; do
+  for o in "" "${AB_FLAG:---no-order}"; do
     for w in photo_noise random_gradient; do
       python bench.py --blocked --workload $w --steps 6 --warmup 2 --contexts 4 --no-cpu-baseline $o > $OUT/blk_${w}_$rep$o.log 2>&1
       python - $OUT/blk_${w}_$rep$o.log "$w ${o:-ordered}" <<'PY'
