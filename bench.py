@@ -528,6 +528,27 @@ def verify_golden(args, units, rows, rank, world, dist, single_chain, W, H, kind
     tests/golden/fullsize.json (pn16384_strips: one chain through the image; pn16384_pool2_strips: the chain restarted per strip) -- no plane leaves the rank.
     A mismatch is a failed leg (non-zero exit)."""
     import torch
+    if args.config == 4:
+        # BASELINE config 4: every image this rank encoded (image i of the batch = seed 1 + i, image i -> rank i % world) against the real reference's whole-image
+        # checksums of all 11 planes (tests/golden/fullsize.json rg4096_batch64, seeds 1..64)
+        try:
+            from limg_amd import shard
+            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize.json")))["rg4096_batch64"]
+            if (W, H, kind) != (gold["w"], gold["h"], "random_gradient") or args.error_factor != 100 or args.images > len(gold["images"]):
+                raise RuntimeError("the golden entry rg4096_batch64 is for up to %d %dx%d random_gradient images, errorFactor 100" % (len(gold["images"]), gold["w"], gold["h"]))
+            mine = shard.batch_assignment(args.images, world, rank)
+            bad = ["image %d %s" % (i, n) for i, (img, planes) in zip(mine, units) for n, want in gold["images"][i]["sum64"].items() if sum64_device(planes[n]) != want]
+            flag = torch.tensor([len(bad)], dtype=torch.int64, device="cuda" if (dist is not None and dist.get_backend() == "nccl") else "cpu")
+            allchecked = [list(mine)]
+            if dist is not None:
+                dist.all_reduce(flag)
+                allchecked = [None] * world
+                dist.all_gather_object(allchecked, list(mine))
+            if int(flag.item()) != 0:
+                raise RuntimeError("planes differ from the reference's: %s (this rank), %d mismatches over all ranks" % (bad[:4], int(flag.item())))
+            return {"entry": "rg4096_batch64", "file": "tests/golden/fullsize.json", "images_checked_by_rank": allchecked, "planes_per_image": 11, "ok": True}
+        except Exception as e:
+            return leg_failed("verify_golden", e)
     entry = "pn16384_strips" if single_chain else "pn16384_pool2_strips"
     try:
         gold = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize.json")))[entry]
@@ -929,7 +950,7 @@ def main():
                                                                      "strips to streams, rank 0 gathers the bytes and decodes them into the full image")
     ap.add_argument("--single-chain", action="store_true", help="--config 5 on 8 ranks: one dither chain through all strips (limg_hip_encode3d_single_chain_device) instead of "
                                                                     "the reference's strip-restart semantics")
-    ap.add_argument("--verify-golden", action="store_true", help="--config 5 at its real size: every rank checks the strips it produced against the real reference's per-strip "
+    ap.add_argument("--verify-golden", action="store_true", help="--config 4 / 5 at their real size: every rank checks the images / strips it produced against the real reference's per-image / per-strip "
                                                                      "checksums (tests/golden/fullsize.json)")
     ap.add_argument("--share-gpus", action="store_true", help="rehearsal only: allow more ranks than GPUs (ranks share cards, gloo instead of RCCL)")
     ap.add_argument("--sub-images", type=int, default=0, help="--config 4: limg_hip_options.batch_sub_images -- the list as a pipeline of sub-batches of this many images "

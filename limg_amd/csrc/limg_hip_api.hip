@@ -1395,7 +1395,8 @@ extern "C"
     {
       hipEvent_t e;
       HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      c->hostEvents.push_back(e);
+      try { c->hostEvents.push_back(e); }
+      catch (...) { (void)hipEventDestroy(e); return limg_hip_error_MemoryAllocationFailure; } // (no exception may cross the extern "C" boundary)
     }
     if ((r = c->hostWords.ensure((2 * 64 + 2) * 8)) != limg_hip_success) return r;
     if (!c->devStatus.p)

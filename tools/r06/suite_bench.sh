@@ -7,7 +7,7 @@ run() { name=$1; shift; python bench.py "$@" > $O/bench_$name.json 2> $O/bench_$
 run default
 run accurate_rg4096 --accurate --size 4096 --workload random_gradient --steps 10 $Q
 run host_pool2 --steps 5 --pool-threads 2 --no-cpu-baseline
-run c4 --config 4 --steps 3 $Q
+run c4 --config 4 --steps 3 --verify-golden $Q
 run c4_contexts3 --config 4 --steps 3 --contexts 3 $Q
 run c4_8images --config 4 --steps 20 --images 8 $Q
 run rg4096 --size 4096 --workload random_gradient $Q
@@ -26,6 +26,8 @@ run 8190x8192_pool2 --steps 10 --warmup 1 --size 8190x8192 --pool-threads 2 $Q
 run 8190x8192_ctx4 --steps 5 --warmup 1 --size 8190x8192 --contexts 4 $Q
 run 1024x618 --steps 50 --size 1024x618 --rgb $Q
 run gpus2_c5_single_chain_rehearsal --gpus 2 --config 5 --single-chain --share-gpus --verify-golden --no-gather --steps 2 --warmup 1 $Q
+run gpus2_c4_rehearsal --gpus 2 --config 4 --images 16 --share-gpus --verify-golden --no-gather --steps 2 --warmup 1 $Q
+run gpus2_default_rehearsal --gpus 2 --share-gpus --steps 5 --warmup 2 $Q
 run gpus2_c5_rehearsal --gpus 2 --config 5 --share-gpus --verify-golden --no-gather --steps 2 --warmup 1 $Q
 run stream --stream $Q
 run blocked --blocked --steps 6 --contexts 4 $Q
