@@ -660,7 +660,8 @@ def run_blocked(args, g, dist, rank, world, W, H):
                     ctxs[i].blocked_encode3d_device(imgs[i], True, outs[i], error_factor=args.error_factor)
                 streams[i].synchronize()
 
-        for phase_n in (1, max(args.steps // 2, 2)):  # warm-up round, then the timed one
+        n_each = max(args.steps, 8)  # images per context in the timed round: the contexts start together, and it takes a few images before their phases have drifted apart
+        for phase_n in (1, n_each):  # warm-up round, then the timed one
             ths = [threading.Thread(target=worker, args=(i, phase_n)) for i in range(args.contexts)]
             t0 = time.perf_counter()
             for th in ths:
@@ -669,7 +670,7 @@ def run_blocked(args, g, dist, rank, world, W, H):
                 th.join()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-        n_img = args.contexts * max(args.steps // 2, 2)
+        n_img = args.contexts * n_each
         pipe = {"contexts": args.contexts, "images": n_img, "images_per_s": round(n_img / dt, 2), "Mpixels_per_s": round(n_img * W * H / dt / 1e6, 1),
                 "note": "K host threads x own context x own HIP stream on ONE GPU; every image is a different seed; all planes stay in HBM"}
         for c in ctxs:

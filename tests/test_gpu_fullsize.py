@@ -40,9 +40,13 @@ def test_encode3d_reference_hashes(gpu, oracle, name):
     img = gpu.synth_device(KIND[e["gen"]], e["w"], e["h"], seed=e["seed"])
     assert oracle.fnv(_host(img)) == e["input"], "the device generator and the golden input disagree"
     planes = gpu.alloc_planes_device(e["w"], e["h"])
-    gpu.encode3d_device(img, e["alpha"], planes, **e["kw"])
-    torch.cuda.synchronize()
-    gpu.check()
+    gpu.set_options(**e.get("options", {}))  # (e.g. the PCG dither: dither_pcg)
+    try:
+        gpu.encode3d_device(img, e["alpha"], planes, **e["kw"])
+        torch.cuda.synchronize()
+        gpu.check()
+    finally:
+        gpu.set_options()
     bad = [k for k in PLANES if oracle.fnv(_host(planes[k])) != e["planes"][k]]
     assert not bad, (name, bad)
     psnr, mse = gpu.compare_device(img, planes["pDecoded"], e["alpha"])
@@ -161,7 +165,7 @@ def test_blocked_reference_hashes(gpu, oracle, name):
     img = gpu.synth_device(KIND[e["gen"]], e["w"], e["h"], seed=e["seed"])
     assert oracle.fnv(_host(img)) == e["input"]
     planes = gpu.alloc_blocked_planes_device(e["w"], e["h"])
-    gpu.blocked_encode3d_device(img, e["alpha"], planes)
+    gpu.blocked_encode3d_device(img, e["alpha"], planes, **e["kw"])
     torch.cuda.synchronize()
     gpu.check()
     assert len(gpu.blocked_regions()) == e["regions"]

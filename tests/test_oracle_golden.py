@@ -29,7 +29,7 @@ def test_full_image_hashes(oracle, name):
     assert psnr == pytest.approx(e["psnr"], abs=1e-9) and mse == pytest.approx(e["mse"], rel=1e-12)
 
 
-@pytest.mark.parametrize("name", ["rg4096", "rg4096_pool2", "pn16384x2048_pool2", "rg4096_accurate"])
+@pytest.mark.parametrize("name", ["rg4096", "rg4096_pool2", "pn16384x2048_pool2", "rg4096_accurate", "rg4096_rgb_accurate"])
 def test_fullsize_hashes(oracle, name):
     """BASELINE sizes: the oracle against the real reference's plane hashes of tests/golden/fullsize.json (tools/make_golden_fullsize.py) -- config 2's 4096^2
     gradient image with one chain and with eight, and strip 0 of config 5.  (The 8192^2 entries take the scalar oracle a minute each; the GPU tests hash those.)"""

@@ -39,6 +39,14 @@ CASES = {
     "pn8192_accurate": ("pn", 8192, 8192, 1, {"fast": False}),
     "rg4096_accurate": ("rg", 4096, 4096, 1, {"fast": False}),
 }
+# rows a6 / a14 at full size: 3-channel input (hasAlpha = false: the cross-product C fit, src/limg_factorization.h:382-576) and the PCG dither (what upstream runs on
+# hosts without AES-NI, src/limg.cpp:799-822).  (generator, w, h, seed, hasAlpha, kwargs of limg_encode3d_test, limg_hip_options for the GPU side)
+CASES_X = {
+    "pn8192_rgb": ("pn", 8192, 8192, 1, False, {}, {}),
+    "pn8192_rgb_pool2": ("pn", 8192, 8192, 1, False, {"pool_threads": 2}, {}),
+    "pn8192_pcg": ("pn", 8192, 8192, 1, True, {"dither_mode": 1}, {"dither_pcg": True}),
+    "rg4096_rgb_accurate": ("rg", 4096, 4096, 1, False, {"fast": False}, {}),
+}
 # config 3's forced-shift half (bits = 8 .. 2 on all three factors = shift 0 .. 6): the planes that depend on the shift, from the reference's own block functions with
 # the search left out (oracle/ref_harness.cpp ref_encode3d_forced_shift; upstream has no such switch).  The six colour planes must equal those of "pn8192".
 FORCED = {"pn8192_forced%d" % s: ("pn", 8192, 8192, 1, (s, s, s)) for s in range(7)}
@@ -59,6 +67,12 @@ STRIPPED = {
 BLOCKED = {
     "blocked_pn4096": ("pn", 4096, 1), "blocked_rg4096": ("rg", 4096, 1),
     "blocked_pn8192": ("pn", 8192, 1), "blocked_rg8192": ("rg", 8192, 1),
+}
+# ... and with other settings of the caller (src/main.cpp:76-77: --error-factor, --accurate-bit-crushing): (generator, size, seed, kwargs)
+BLOCKED_X = {
+    "blocked_pn4096_ef25": ("pn", 4096, 1, {"error_factor": 25}),
+    "blocked_rg4096_ef400": ("rg", 4096, 1, {"error_factor": 400}),
+    "blocked_pn4096_accurate": ("pn", 4096, 1, {"fast": False}),
 }
 
 
@@ -90,6 +104,19 @@ def main():
         r = ref.encode3d(img, True, **kw)
         psnr, mse = ref.compare(img, r["pDecoded"], True)
         out[name] = {"kind": "encode3d", "gen": gen, "w": w, "h": h, "seed": seed, "alpha": True, "kw": kw, "input": orc.fnv(img), "psnr": psnr, "mse": mse,
+                     "planes": {k: orc.fnv(r[k]) for k in PLANES}, "sum64": {k: sum64(r[k]) for k in PLANES}}
+        print(name, "%.4f dB" % psnr, "%.1f s" % (time.time() - t0), flush=True)
+        del r, img
+        json.dump(out, open(OUT, "w"), indent=1)
+    for name, (gen, w, h, seed, alpha, kw, opts) in CASES_X.items():
+        if args.only is not None and name not in args.only:
+            continue
+        t0 = time.time()
+        img = make_input(orc, gen, w, h, seed)
+        r = ref.encode3d(img, alpha, **kw)
+        psnr, mse = ref.compare(img, r["pDecoded"], alpha)
+        gpu_kw = {k: v for k, v in kw.items() if k != "dither_mode"}
+        out[name] = {"kind": "encode3d", "gen": gen, "w": w, "h": h, "seed": seed, "alpha": alpha, "kw": gpu_kw, "options": opts, "input": orc.fnv(img), "psnr": psnr, "mse": mse,
                      "planes": {k: orc.fnv(r[k]) for k in PLANES}, "sum64": {k: sum64(r[k]) for k in PLANES}}
         print(name, "%.4f dB" % psnr, "%.1f s" % (time.time() - t0), flush=True)
         del r, img
@@ -132,6 +159,19 @@ def main():
                      "strips": [{"input": orc.fnv(img[i * rows:(i + 1) * rows]), "planes": {k: orc.fnv(r[k][i * rows:(i + 1) * rows]) for k in PLANES},
                                  "sum64": {k: sum64(r[k][i * rows:(i + 1) * rows]) for k in PLANES}} for i in range(8)]}
         print(name, "%.4f dB" % psnr, "%.1f s" % (time.time() - t0), flush=True)
+        del r, img
+        json.dump(out, open(OUT, "w"), indent=1)
+    for name, (gen, n, seed, kw) in BLOCKED_X.items():
+        if args.only is not None and name not in args.only:
+            continue
+        t0 = time.time()
+        img = make_input(orc, gen, n, n, seed)
+        r = ref.blocked_encode3d(img, True, **kw)
+        psnr, mse = ref.compare(img, r["pDecoded"], True)
+        out[name] = {"kind": "blocked", "gen": gen, "w": n, "h": n, "seed": seed, "alpha": True, "kw": kw, "input": orc.fnv(img), "psnr": psnr, "mse": mse,
+                     "regions": int(r["pBlockIndex"].max() & 0xFFFFFF), "planes": {k: orc.fnv(r[k]) for k in BLOCKED_WRITTEN},
+                     "sum64": {k: sum64(r[k]) for k in BLOCKED_WRITTEN}}
+        print(name, out[name]["regions"], "%.4f dB" % psnr, "%.1f s" % (time.time() - t0), flush=True)
         del r, img
         json.dump(out, open(OUT, "w"), indent=1)
     for name, (gen, n, seed) in BLOCKED.items():

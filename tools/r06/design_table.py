@@ -69,7 +69,7 @@ def main():
                    5.9 * 8192 * 8192 / ((st["k_stream_scan_strips"] + st["k_stream_pack_strips"]) * 1e-3) / 8e12, s["roofline"]["frac"],
                    s["roofline"]["algorithmic_bytes_per_launch"] / (st["k_stream_decode"] * 1e-3) / 8e12))
     b, brg = line("blocked"), line("blocked_rg")
-    rows.append("| merged-block encoder, photo-noise / gradient: one image; four contexts | %.1f / %.1f | %s / %s; %s / %s | kernel-only %.3f / %.3f | `r06_bench_final_blocked.json`, `_blocked_rg.json` |"
+    rows.append("| merged-block encoder, photo-noise / gradient: one image; four contexts (8+ images each) | %.1f / %.1f | %s / %s; %s / %s | kernel-only %.3f / %.3f | `r06_bench_final_blocked.json`, `_blocked_rg.json` |"
                 % (b["ms_per_step"], brg["ms_per_step"], "{:,.0f}".format(b["value"]).replace(",", " "), "{:,.0f}".format(brg["value"]).replace(",", " "),
                    "{:,.0f}".format(b["config"]["pipelined_stream"]["Mpixels_per_s"]).replace(",", " "), "{:,.0f}".format(brg["config"]["pipelined_stream"]["Mpixels_per_s"]).replace(",", " "),
                    b["roofline"]["frac"], brg["roofline"]["frac"]))
