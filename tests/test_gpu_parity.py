@@ -539,13 +539,14 @@ def test_host_entry_at_4096(gpu, oracle):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("shape", [(4096, 2048), (2056, 4104)])
 @pytest.mark.parametrize("pool", [0, 2, 3, 16])
-def test_host_entry_in_bands(gpu, oracle, pool):
+def test_host_entry_in_bands(gpu, oracle, pool, shape):
     """limg_hip_encode3d from 4 Mpixels on works in row bands (upload + kernels of band k + 1 under the download of band k; limg_hip_api.hip host_encode_banded): one
     chain through the bands (poolThreads 0: the chain entry's two halves per band, bases on the device) and a band per restarted chain (poolThreads > 0,
     src/limg.cpp:2114-2134; 16 threads = 64 chains of 4 block rows: the plain path).  Every plane == the device entry's single encode of the whole image."""
     import torch
-    W, H = 4096, 2048
+    W, H = shape  # (the second: 513 block rows -- bands and chains of unequal height -- and a width whose rows are not 16-byte multiples of the strip width)
     d_img = gpu.synth_device("photo_noise", W, H, seed=9)
     img = d_img.cpu().numpy().view(np.uint32)
     got = gpu.encode3d(img, True, pool_threads=pool)
