@@ -23,6 +23,12 @@ int main(void)
   /* host-side helpers: the reference's strip rule (src/limg.cpp:2114-2134) and the layout of the variable-size stream gather */
   if (limg_hip_host_partition(8192, 2, &chains, &rows) != limg_hip_success || chains != 8 || rows != 128) return 11;
   if (limg_hip_host_gather_offsets(sizes, 3, offs) != limg_hip_success || offs[0] != 0 || offs[1] != 112 || offs[2] != 112 || offs[3] != 160) return 12;
+  { /* options are versioned by their size: the header's inline passes sizeof as THIS compiler sees it (no device needed) */
+    struct limg_hip_options o;
+    memset(&o, 0xAB, sizeof o);
+    limg_hip_default_options(&o);
+    if (o.struct_size != sizeof o || o.forced_shift[0] != -1 || o.forced_shift[2] != -1 || o.dither_pcg != 0 || o.ragged_walk_threads != 0) return 18;
+  }
   {
     const enum limg_hip_result r = limg_hip_init(0, &ctx);
     if (r != limg_hip_success)
@@ -48,6 +54,19 @@ int main(void)
     printf("encoded %dx%d: PSNR %.2f dB\n", W, H, psnr);
     if (!(psnr > 25.0)) return 15;
     if (limg_hip_check_device_status(ctx) != limg_hip_success) return 16;
+    { /* set one option, read it back through a struct that is SHORTER than the library's (a caller built against an earlier header) */
+      struct limg_hip_options o;
+      struct { uint32_t struct_size; int32_t forced_shift[3]; } old_header;
+      limg_hip_default_options(&o);
+      o.forced_shift[0] = o.forced_shift[1] = o.forced_shift[2] = 3;
+      if (limg_hip_set_options(ctx, &o) != limg_hip_success) return 19;
+      old_header.struct_size = sizeof old_header;
+      if (limg_hip_get_options(ctx, (struct limg_hip_options *)&old_header) != limg_hip_success || old_header.struct_size != sizeof old_header || old_header.forced_shift[1] != 3) return 20;
+      old_header.forced_shift[0] = old_header.forced_shift[1] = old_header.forced_shift[2] = -1;
+      if (limg_hip_set_options(ctx, (const struct limg_hip_options *)&old_header) != limg_hip_success) return 21;
+      o.struct_size = sizeof o;
+      if (limg_hip_get_options(ctx, &o) != limg_hip_success || o.forced_shift[0] != -1 || o.batch_sub_images != 0) return 22;
+    }
   }
   limg_hip_shutdown(&ctx);
   return ctx == NULL ? 0 : 17;
