@@ -1450,8 +1450,18 @@ def host_entry_rate(g, W, H, args):
         if r != 0:
             raise RuntimeError("limg_hip_encode3d -> %d" % r)
     t = min(times[1:])
+    perf = []
+    for _ in range(4):  # limg_encode3d_test_perf's counterpart (what the reference's tool calls in its --count loop, src/main.cpp:278-323): 4 B/px up, nothing down
+        tp = time.perf_counter()
+        r = g.lib.limg_hip_encode3d_perf(g.ctx, host.ctypes.data_as(C.c_void_p), W, H, 1, args.error_factor, 0, 1)
+        perf.append(time.perf_counter() - tp)
+        if r != 0:
+            raise RuntimeError("limg_hip_encode3d_perf -> %d" % r)
+    tp = min(perf[1:])
     return {"entry": "limg_hip_encode3d (host pointers; pageable caller memory)", "ms": round(t * 1e3, 2), "Mpixels_per_s": round(W * H / t / 1e6, 1),
-            "bytes_over_pcie": W * H * 39, "GB_per_s": round(W * H * 39 / t / 1e9, 2)}
+            "bytes_over_pcie": W * H * 39, "GB_per_s": round(W * H * 39 / t / 1e9, 2),
+            "perf_entry": {"entry": "limg_hip_encode3d_perf (host pointer in, nothing stored)", "ms": round(tp * 1e3, 2), "Mpixels_per_s": round(W * H / tp / 1e6, 1),
+                           "bytes_over_pcie": W * H * 4, "GB_per_s": round(W * H * 4 / tp / 1e9, 2)}}
 
 
 if __name__ == "__main__":

@@ -1547,6 +1547,30 @@ extern "C"
     const size_t px = sizeX * sizeY;
     limg_hip_result r;
     if ((r = c->in.ensure(px * 4)) != limg_hip_success) return r;
+    if (px >= ((size_t)4 << 20) && sizeX % kBlock == 0 && sizeY % kBlock == 0 && sizeY >= 64 * kBlock && c->opt.collect_stats == 0)
+    { // Nothing is stored, so nothing depends on the dither chain (src/limg.cpp:2140-2173: fit + search only): the image goes up in 8 row bands on one stream and every
+      // band's fit + search runs on a second one as soon as its rows have arrived -- the kernels (1.2 ms for 8192^2) hide under the upload (5 ms)
+      const size_t rowsPer = ((sizeY / kBlock + 7) / 8) * kBlock;
+      const uint32_t nb = (uint32_t)((sizeY + rowsPer - 1) / rowsPer);
+      if (!c->hostStream) HIP_TRY(hipStreamCreateWithFlags(&c->hostStream, hipStreamNonBlocking));
+      if (!c->hostCopyStream) HIP_TRY(hipStreamCreateWithFlags(&c->hostCopyStream, hipStreamNonBlocking));
+      while (c->hostEvents.size() < nb)
+      {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        try { c->hostEvents.push_back(e); }
+        catch (...) { (void)hipEventDestroy(e); return limg_hip_error_MemoryAllocationFailure; }
+      }
+      for (uint32_t b = 0; b < nb; b++)
+      {
+        const size_t y0 = (size_t)b * rowsPer, rows = y0 + rowsPer < sizeY ? rowsPer : sizeY - y0, o = y0 * sizeX;
+        HIP_TRY(hipMemcpyAsync((uint32_t *)c->in.p + o, pIn + o, rows * sizeX * 4, hipMemcpyHostToDevice, c->hostCopyStream));
+        HIP_TRY(hipEventRecord(c->hostEvents[b], c->hostCopyStream));
+        HIP_TRY(hipStreamWaitEvent(c->hostStream, c->hostEvents[b], 0));
+        if ((r = encode_device(c, (const uint32_t *)c->in.p + o, sizeX, rows, hasAlpha, nullptr, nullptr, errorFactor, 0, fastBitCrushing, c->hostStream)) != limg_hip_success) return r;
+      }
+      return limg_hip_check_device_status(c);
+    }
     HIP_TRY(hipMemcpy(c->in.p, pIn, px * 4, hipMemcpyHostToDevice));
     if ((r = encode_device(c, (const uint32_t *)c->in.p, sizeX, sizeY, hasAlpha, nullptr, nullptr, errorFactor, poolThreads, fastBitCrushing, nullptr)) != limg_hip_success) return r;
     HIP_TRY(hipDeviceSynchronize());

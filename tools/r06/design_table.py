@@ -76,6 +76,10 @@ def main():
     he, hp = cfg["host_entry"], line("host_pool2")["config"]["host_entry"]
     rows.append("| host-pointer entry 8192² (PCIe-inclusive; never `value`), poolThreads 0 / 2 | %.2f / %.2f | %s / %s | — (%.1f GB/s over PCIe) | `r06_bench_final.json`, `_host_pool2.json` `config.host_entry` |"
                 % (he["ms"], hp["ms"], "{:,.0f}".format(he["Mpixels_per_s"]).replace(",", " "), "{:,.0f}".format(hp["Mpixels_per_s"]).replace(",", " "), he["GB_per_s"]))
+    if he.get("perf_entry"):
+        pe = he["perf_entry"]
+        rows.append("| `limg_hip_encode3d_perf` through host pointers (4 B/px up, nothing stored: the reference tool's `--count` loop) | %.2f | %s | — (%.1f GB/s over PCIe) | `r06_bench_final.json` `config.host_entry.perf_entry` |"
+                    % (pe["ms"], "{:,.0f}".format(pe["Mpixels_per_s"]).replace(",", " "), pe["GB_per_s"]))
     rows.append("| two contexts on two streams, images alternating / first encode of a fresh context / `_perf` style (E step only) | %.3f per image / %.1f / %.3f | %s / — / %s | | `r06_bench_final.json` `config.two_streams`, `first_encode_ms`, `perf_style_ms` |"
                 % (cfg["two_streams"]["ms_per_image"], cfg["first_encode_ms"], cfg["perf_style_ms"], "{:,.0f}".format(cfg["two_streams"]["Mpixels_per_s"]).replace(",", " "),
                    "{:,.0f}".format(cfg["perf_style_Mpixels_per_s"]).replace(",", " ")))

@@ -17,3 +17,10 @@ for pool in (0, 2):
         ts.append((time.perf_counter() - t) * 1e3)
         assert r == 0
     print(limg_amd.LIB_PATH, "pool", pool, "ms", " ".join("%.2f" % t for t in ts), flush=True)
+ts = []
+for _ in range(6):
+    t = time.perf_counter()
+    r = g.lib.limg_hip_encode3d_perf(g.ctx, img.ctypes.data_as(C.c_void_p), W, W, 1, 100, 0, 1)
+    ts.append((time.perf_counter() - t) * 1e3)
+    assert r == 0
+print(limg_amd.LIB_PATH, "limg_hip_encode3d_perf (host pointer, nothing stored) ms", " ".join("%.2f" % t for t in ts), flush=True)
