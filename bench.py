@@ -1275,7 +1275,7 @@ def exchange_views(dist, rank, world, mine, timeout_s):
 EXCHANGES = []
 
 
-def collective_evidence(g, dist, rank, world, timeout_s=120.0):
+def collective_evidence(g, dist, rank, world, timeout_s=60.0):
     """--gpus N > 1: what RCCL itself says about the job, so that a SCALE record shows the N ranks RCCL saw: torch.distributed's backend and world size, and -- through
     the library's own communicator (limg_hip_comm_init over the id rank 0 made; ncclCommCount / ncclGetVersion behind limg_hip_comm_info) -- every rank's view, all-gathered:
     the line is refused unless all ranks report the same `comm_ranks` == N.  Outside the timed region."""
